@@ -1,0 +1,184 @@
+"""ctypes binding of oracle/liborc.so -- the plain-C CPU restatement of the reference hot path.
+
+TEST INFRASTRUCTURE ONLY (see hif_oracle.h): may be imported from tests/,
+__graft_entry__.smoke() and the cpu_baseline leg of bench.py -- never from `hifir_amd`.
+
+Hierarchy format ("levels"): a list of dicts, one per hif::Prec (alg/Prec.hpp:309-323), exactly as
+`oracle.ref.RefHIF.levels()` returns them and as the golden fixtures store them:
+  m, n, {L,U,E,F}_{colptr,rowind,vals} (CCS), d, s, t, p, p_inv, q, q_inv,
+  and on the last level optionally dense_n + dense (unfactored, column-major).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "liborc.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            build()
+        _lib = C.CDLL(_PATH)
+        vp = C.c_void_p
+        for k in "dz":
+            g = lambda name: getattr(_lib, f"orc_{k}_{name}")
+            g("create").restype = vp
+            g("create").argtypes = [C.c_int]
+            g("destroy").argtypes = [vp]
+            g("set_level").argtypes = [vp, C.c_int, C.c_int64, C.c_int64] + [vp] * 9 + [C.c_int64] + [vp] * 10
+            g("set_dense").argtypes = [vp, C.c_int64, vp, C.c_double]
+            g("dense_rank").argtypes = [vp]
+            g("dense_rank").restype = C.c_int64
+            g("work_size").argtypes = [vp]
+            g("work_size").restype = C.c_int64
+            g("solve").argtypes = [vp, vp, vp, C.c_int64]
+            g("solve_batch").argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_int]
+            g("mmultiply").argtypes = [vp, vp, vp, C.c_int64]
+            g("hifir").argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int, vp, C.c_int64, vp, vp]
+            g("crs_mv").argtypes = [C.c_int64, vp, vp, vp, vp, vp]
+            g("ccs_kernel").argtypes = [C.c_int, C.c_int64, C.c_int64, vp, vp, vp, vp, vp]
+            g("ccs_kernel_mrhs").argtypes = [C.c_int, C.c_int64, C.c_int64, vp, vp, vp, C.c_int64, vp, vp]
+            g("qrcp").argtypes = [C.c_int64, vp, C.c_double, C.c_int, vp, C.c_int64, vp, vp]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _kind(*arrs):
+    return "z" if any(np.iscomplexobj(a) for a in arrs if a is not None) else "d"
+
+
+class Oracle:
+    """CPU restatement of hif::HIF<>::solve / mmultiply / hifir on a given hierarchy."""
+
+    def __init__(self, levels, rrqr_cond=0.0, dtype=None):
+        L = lib()
+        if dtype is None:
+            dtype = np.complex128 if any(np.iscomplexobj(lv["L_vals"]) or np.iscomplexobj(lv["d"]) for lv in levels) else np.float64
+        self.dtype = np.dtype(dtype)
+        self.k = "z" if self.dtype == np.complex128 else "d"
+        self.n = int(levels[0]["n"])
+        self.h = self._f("create")(len(levels))
+        keep = []
+        for l, lv in enumerate(levels):
+            m, n = int(lv["m"]), int(lv["n"])
+            a = {}
+            for nm in "LUEF":
+                a[nm] = (np.ascontiguousarray(lv[nm + "_colptr"], dtype=np.int64),
+                         np.ascontiguousarray(lv[nm + "_rowind"], dtype=np.int32),
+                         np.ascontiguousarray(lv[nm + "_vals"], dtype=self.dtype))
+            f_ncols = len(a["F"][0]) - 1
+            if a["F"][0][-1] == 0 and n - m == 0:
+                f_ncols = 0
+            vec = [np.ascontiguousarray(lv["d"], dtype=self.dtype),
+                   np.ascontiguousarray(lv["s"], dtype=np.float64), np.ascontiguousarray(lv["t"], dtype=np.float64)]
+            perms = [np.ascontiguousarray(lv[k], dtype=np.int32) for k in ("p", "p_inv", "q", "q_inv")]
+            keep += [a, vec, perms]
+            rc = self._f("set_level")(self.h, l, m, n, *[_p(x) for x in a["L"]], *[_p(x) for x in a["U"]],
+                                      *[_p(x) for x in a["E"]], f_ncols, *[_p(x) for x in a["F"]],
+                                      *[_p(x) for x in vec], *[_p(x) for x in perms])
+            assert rc == 0
+        last = levels[-1]
+        if int(last.get("dense_n", 0)) > 0:
+            mat = np.ascontiguousarray(last["dense"], dtype=self.dtype).ravel()
+            self._f("set_dense")(self.h, int(last["dense_n"]), _p(mat), float(rrqr_cond))
+
+    def _f(self, name):
+        return getattr(lib(), f"orc_{self.k}_{name}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._f("destroy")(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def dense_rank(self):
+        return self._f("dense_rank")(self.h)
+
+    def solve(self, b, rank=0):
+        b = np.ascontiguousarray(b, dtype=self.dtype)
+        x = np.zeros_like(b)
+        assert self._f("solve")(self.h, _p(b), _p(x), rank) == 0
+        return x
+
+    def solve_batch(self, B, rank=0, threads=1):
+        """B: (n, nrhs) row-interleaved (C-contiguous). Column-by-column solve."""
+        B = np.ascontiguousarray(B, dtype=self.dtype)
+        X = np.zeros_like(B)
+        assert self._f("solve_batch")(self.h, _p(B), _p(X), B.shape[1], rank, threads) == 0
+        return X
+
+    def mmultiply(self, x, rank=0):
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        y = np.zeros_like(x)
+        assert self._f("mmultiply")(self.h, _p(x), _p(y), rank) == 0
+        return y
+
+    def hifir(self, indptr, indices, vals, b, nirs, betas=None, rank=-1):
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        vals = np.ascontiguousarray(vals, dtype=self.dtype)
+        b = np.ascontiguousarray(b, dtype=self.dtype)
+        x = np.zeros_like(b)
+        st = np.zeros(2, dtype=np.int32)
+        bt = None if betas is None else np.ascontiguousarray(betas, dtype=np.float64)
+        assert self._f("hifir")(self.h, len(b), _p(indptr), _p(indices), _p(vals), _p(b), nirs, _p(bt), rank, _p(x), _p(st)) == 0
+        return x, (int(st[0]), int(st[1]))
+
+
+def crs_mv(indptr, indices, vals, x):
+    k = _kind(vals, x)
+    dt = np.complex128 if k == "z" else np.float64
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    vals = np.ascontiguousarray(vals, dtype=dt)
+    x = np.ascontiguousarray(x, dtype=dt)
+    y = np.zeros(len(indptr) - 1, dtype=dt)
+    getattr(lib(), f"orc_{k}_crs_mv")(len(indptr) - 1, _p(indptr), _p(indices), _p(vals), _p(x), _p(y))
+    return y
+
+
+def ccs_kernel(op, nrows, ncols, colptr, rowind, vals, x, nrhs=None):
+    """op 0 strict-lower solve, 1 strict-upper solve, 2 y = A x; nrhs: x is (n, nrhs) interleaved."""
+    k = _kind(vals, x)
+    dt = np.complex128 if k == "z" else np.float64
+    colptr = np.ascontiguousarray(colptr, dtype=np.int64)
+    rowind = np.ascontiguousarray(rowind, dtype=np.int32)
+    vals = np.ascontiguousarray(vals, dtype=dt)
+    x = np.ascontiguousarray(x, dtype=dt)
+    if nrhs is None:
+        y = np.zeros(nrows, dtype=dt) if op == 2 else x.copy()
+        getattr(lib(), f"orc_{k}_ccs_kernel")(op, nrows, ncols, _p(colptr), _p(rowind), _p(vals), _p(x), _p(y))
+    else:
+        y = np.zeros((nrows, nrhs), dtype=dt) if op == 2 else x.copy()
+        getattr(lib(), f"orc_{k}_ccs_kernel_mrhs")(op, nrows, ncols, _p(colptr), _p(rowind), _p(vals), nrhs, _p(x), _p(y))
+    return y
+
+
+def qrcp(mat_colmajor, b, op=0, rank=0, rrqr_cond=0.0):
+    k = _kind(mat_colmajor, b)
+    dt = np.complex128 if k == "z" else np.float64
+    mat = np.ascontiguousarray(mat_colmajor, dtype=dt).ravel()
+    b = np.ascontiguousarray(b, dtype=dt)
+    x = np.zeros_like(b)
+    rk = np.zeros(1, dtype=np.int64)
+    getattr(lib(), f"orc_{k}_qrcp")(len(b), _p(mat), rrqr_cond, op, _p(b), rank, _p(x), _p(rk))
+    return x, int(rk[0])

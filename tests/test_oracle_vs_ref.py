@@ -1,0 +1,95 @@
+"""CPU, only where the compiled reference (oracle/_ref/libhifref.so) exists: pins the C restatement
+to the real reference on fresh inputs -- bitwise on the sparse kernels, 1e-12 on the dense level,
+including rank-deficient QRCP truncation (the ?laic1 path, small_scale/QRCP.hpp:333-364)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import orc, ref
+from util import poisson2d, relerr
+
+pytestmark = [pytest.mark.ref, pytest.mark.skipif(not ref.available(), reason="compiled reference not present")]
+
+
+def _rand_tri(n, density, lower, rng):
+    A = sp.random(n, n, density=density, random_state=np.random.RandomState(rng.integers(1 << 30)), format="csc")
+    A = sp.tril(A, -1, format="csc") if lower else sp.triu(A, 1, format="csc")
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("n", [5, 64, 300])
+def test_ccs_kernels_bitwise(n):
+    # the reference's tests/test_cs_tri.cpp uses n in [5,300]; here bit-for-bit, not 1e-10
+    rng = np.random.default_rng(n)
+    for cplx in (False, True):
+        for op, lower in [(0, True), (1, False)]:
+            A = _rand_tri(n, 0.2, lower, rng)
+            v = A.data + (1j * rng.uniform(-1, 1, A.nnz) if cplx else 0)
+            x = rng.uniform(-1, 1, n) + (1j * rng.uniform(-1, 1, n) if cplx else 0)
+            y0 = ref.ccs_kernel(op, n, n, A.indptr, A.indices, v, x)
+            y1 = orc.ccs_kernel(op, n, n, A.indptr, A.indices, v, x)
+            assert np.array_equal(y0, y1)
+        R = sp.random(n + 3, n, density=0.3, random_state=np.random.RandomState(n), format="csc")
+        R.sort_indices()
+        v = R.data + (1j * rng.uniform(-1, 1, R.nnz) if cplx else 0)
+        x = rng.uniform(-1, 1, n) + (1j * rng.uniform(-1, 1, n) if cplx else 0)
+        assert np.array_equal(ref.ccs_kernel(2, n + 3, n, R.indptr, R.indices, v, x),
+                              orc.ccs_kernel(2, n + 3, n, R.indptr, R.indices, v, x))
+        C = R.T.tocsr()
+        C.sort_indices()
+        xs = rng.uniform(-1, 1, n + 3) + (1j * rng.uniform(-1, 1, n + 3) if cplx else 0)
+        vv = C.data + (1j * rng.uniform(-1, 1, C.nnz) if cplx else 0)
+        assert np.array_equal(ref.spmv(C.indptr, C.indices, vv, xs), orc.crs_mv(C.indptr, C.indices, vv, xs))
+    A = poisson2d(9)
+    x = rng.uniform(-1, 1, 81)
+    assert np.array_equal(ref.spmv(A.indptr, A.indices, A.data, x), orc.crs_mv(A.indptr, A.indices, A.data, x))
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_qrcp_full_and_deficient_rank(cplx):
+    rng = np.random.default_rng(11)
+    n = 40
+    A = rng.normal(size=(n, n)) + (1j * rng.normal(size=(n, n)) if cplx else 0)
+    b = rng.normal(size=n) + (1j * rng.normal(size=n) if cplx else 0)
+    x0, r0 = ref.qrcp(A.ravel(order="F"), b)
+    x1, r1 = orc.qrcp(A.ravel(order="F"), b)
+    assert r0 == r1 == n and relerr(x1, x0) <= 1e-12
+    # exact rank deficiency: 7 dependent columns -> truncation through ?laic1
+    A2 = A.copy()
+    A2[:, n - 7:] = A2[:, :7] @ rng.normal(size=(7, 7))
+    x0, r0 = ref.qrcp(A2.ravel(order="F"), b)
+    x1, r1 = orc.qrcp(A2.ravel(order="F"), b)
+    assert r0 == r1 == n - 7
+    assert relerr(x1, x0) <= 1e-9  # minimum-norm-like solution of a singular system: conditioning-limited
+    # graded singular values with a user cond threshold
+    U, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    V, _ = np.linalg.qr(rng.normal(size=(n, n)))
+    A3 = (U * np.logspace(0, -12, n)) @ V.T + (0j if cplx else 0)
+    for cond in (1e4, 1e8):
+        x0, r0 = ref.qrcp(A3.ravel(order="F"), b, rrqr_cond=cond)
+        x1, r1 = orc.qrcp(A3.ravel(order="F"), b, rrqr_cond=cond)
+        assert r0 == r1 and 0 < r0 < n
+        assert relerr(x1, x0) <= 1e-8
+    # explicit rank argument (prec_solve passes last_dim, QRCP.hpp:376-377)
+    x0, _ = ref.qrcp(A.ravel(order="F"), b, rank=10)
+    x1, _ = orc.qrcp(A.ravel(order="F"), b, rank=10)
+    assert relerr(x1, x0) <= 1e-12
+    y0, _ = ref.qrcp(A.ravel(order="F"), b, op=1)
+    y1, _ = orc.qrcp(A.ravel(order="F"), b, op=1)
+    assert relerr(y1, y0) <= 1e-12
+
+
+@pytest.mark.parametrize("nx,params", [(40, None), (150, (1e-2, 5.0, 3.0)), (200, None)])
+def test_fresh_hierarchies(nx, params):
+    A = poisson2d(nx)
+    P = None if params is None else ref.make_params(tau=params[0], kappa=params[1], alpha=params[2])
+    M = ref.RefHIF(A.indptr, A.indices, A.data, P)
+    O = orc.Oracle(M.levels())
+    rng = np.random.default_rng(nx)
+    b = rng.uniform(-1, 1, A.shape[0])
+    x0, x1 = M.solve(b), O.solve(b)
+    assert relerr(x1, x0) <= 1e-12
+    if M.levels()[-1]["dense_n"] == 0:
+        assert np.array_equal(x0, x1)
+    assert relerr(O.mmultiply(x0), M.mmultiply(x0)) <= 1e-10

@@ -1,0 +1,40 @@
+"""Shared helpers for the tests: fixture loading and synthetic matrices (no reference access)."""
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HIER_NAMES = ["p2d_5", "p2d_30", "p2d_64_deep", "p2d_100_tuned", "p3d_12", "cd2d_48", "demo_A", "young1c"]
+LEVEL_KEYS = ["m", "n", "dense_n", "dense_rank", "d", "s", "t", "p", "p_inv", "q", "q_inv", "dense"] + [
+    f"{a}_{b}" for a in "LUEF" for b in ("colptr", "rowind", "vals")]
+
+
+def load_hier(name):
+    """-> (levels, data): levels in the oracle.orc format, data = the other fixture arrays."""
+    z = np.load(os.path.join(GOLDEN, f"hier_{name}.npz"))
+    nl = int(z["nlevels"])
+    levels = []
+    for l in range(nl):
+        lv = {}
+        for k in LEVEL_KEYS:
+            key = f"L{l}_{k}"
+            if key in z.files:
+                v = z[key]
+                lv[k] = int(v) if v.ndim == 0 else v
+        levels.append(lv)
+    data = {k: z[k] for k in z.files if not k.startswith("L") or not k[1].isdigit()}
+    return levels, data
+
+
+def poisson2d(nx, ny=None):
+    ny = ny or nx
+    Tx = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(nx, nx), format="csr")
+    Ty = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(ny, ny), format="csr")
+    A = (sp.kron(sp.identity(ny), Tx) + sp.kron(Ty, sp.identity(nx))).tocsr()
+    A.sort_indices()
+    return A
+
+
+def relerr(x, ref):
+    return float(np.abs(x - ref).max() / max(np.abs(ref).max(), 1e-300))
