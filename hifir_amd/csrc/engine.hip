@@ -1,0 +1,1034 @@
+// engine.hip -- device residency of the hierarchy, the per-level kernel sequence of one apply
+// (captured once per batch shape into a hipGraph), batched iterative refinement, and the C ABI
+// of include/hifir_amd.h.  One handle = one HIP device + one stream + one work arena.
+//
+// Reference control flow restated: hif::prec_solve, src/hif/alg/prec_solve.hpp:332-412 (stages
+// S1..S7 of SURVEY 3.1), HIF::solve builder.hpp:409-423, IterRefine::iter_refine
+// alg/IterRefine.hpp:77-165.  There is NO host fallback: every compute path needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <tuple>
+
+#include "../../include/hifir_amd.h"
+#include "host.hpp"
+#include "kernels.hip.hpp"
+
+namespace hifamd {
+
+static thread_local std::string g_err;
+static thread_local bool g_has_err = false;
+
+static void set_err(const std::string &m) {
+  g_err = m;
+  g_has_err = true;
+}
+
+#define HIP_OK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      throw Error(HIFAMD_HIFIR_ERROR, std::string("HIP error: ") + hipGetErrorString(e_) + " at " \
+                                          #expr + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+  } while (0)
+
+template <class T>
+struct DevT;
+template <>
+struct DevT<double> {
+  typedef double type;
+};
+template <>
+struct DevT<zdouble> {
+  typedef cplx type;
+};
+
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+// -------------------------------------------------------------------------------------------
+// device containers
+// -------------------------------------------------------------------------------------------
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  void alloc(size_t b) {
+    release();
+    bytes = b;
+    if (b) HIP_OK(hipMalloc(&p, b));
+  }
+  template <class V>
+  void upload(const std::vector<V> &h) {
+    alloc(h.size() * sizeof(V));
+    if (bytes) HIP_OK(hipMemcpy(p, h.data(), bytes, hipMemcpyHostToDevice));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  ~DevBuf() { release(); }
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  template <class V>
+  V *as() const {
+    return (V *)p;
+  }
+};
+
+struct DevCsr {
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  DevBuf ptr, col, val, rowid, wfptr;
+  std::vector<int64_t> wf_ptr_host;  // wavefront boundaries (slots)
+  template <class T>
+  void upload(const Csr<T> &A, const Schedule *S) {
+    nrows = A.nrows;
+    ncols = A.ncols;
+    nnz = (int64_t)A.col.size();
+    ptr.upload(A.ptr);
+    col.upload(A.col);
+    val.upload(A.val);
+    rowid.upload(A.rowid);
+    if (S) {
+      wf_ptr_host = S->wf_ptr;
+      std::vector<int32_t> w32(S->wf_ptr.begin(), S->wf_ptr.end());
+      wfptr.upload(w32);
+    }
+  }
+};
+
+struct DevLevel {
+  int64_t m = 0, n = 0, F_ncols = 0;
+  DevCsr L, U, E, F;
+  DevBuf d, s, t, p, qinv;
+  DevBuf w, v;  // arena: n * Rmax each
+};
+
+struct DevDense {
+  int64_t n = 0, rank = 0;
+  DevBuf QH, Rinv, jpvt0, tmp;
+};
+
+struct GraphKey {
+  const void *B, *X;
+  int64_t ldb, ldx, nrhs, rank;
+  bool operator<(const GraphKey &o) const {
+    return std::tie(B, X, ldb, ldx, nrhs, rank) < std::tie(o.B, o.X, o.ldb, o.ldx, o.nrhs, o.rank);
+  }
+};
+
+struct GraphEntry {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int64_t launches = 0;
+  uint64_t stamp = 0;
+};
+
+class EngineBase {
+ public:
+  virtual ~EngineBase() {}
+  int vt = 0;
+};
+
+template <class T>
+class Engine : public EngineBase {
+ public:
+  typedef typename DevT<T>::type D;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool finalized = false;
+  int64_t Rmax = 0, max_nrhs = 0;
+  HostHierarchy<T> host;
+  std::vector<std::unique_ptr<DevLevel>> lv;
+  DevDense dn;
+  DevCsr A;
+  bool has_A = false;
+  std::map<GraphKey, GraphEntry> graphs;
+  uint64_t clock = 0;
+  int64_t last_launches = 0;
+  int thin_factor = 2;
+  bool use_graph = true;
+  // IR scratch
+  DevBuf ir_r, ir_xk, ir_part, stage_b, stage_x;
+  int64_t ir_cols = 0;
+
+  explicit Engine(int dev) : device(dev) {
+    // Import and host-side analysis (CCS -> CSR, level schedules, dense QRCP) need no GPU; the
+    // device is bound in finalize(), and every compute entry point requires a finalized handle.
+    thin_factor = env_int("HIFIR_AMD_THIN_FACTOR", 2);
+    use_graph = env_int("HIFIR_AMD_NO_GRAPH", 0) == 0;
+  }
+
+  void bind_device() {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
+      throw Error(HIFAMD_HIFIR_ERROR, "no HIP device available: the hifir_amd apply path has no CPU fallback");
+    if (device < 0) HIP_OK(hipGetDevice(&device));
+    if (device >= cnt) throw Error(HIFAMD_HIFIR_ERROR, "device ordinal out of range");
+    HIP_OK(hipSetDevice(device));
+    if (!stream) HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  }
+
+  ~Engine() override {
+    if (stream) (void)hipSetDevice(device);
+    clear_graphs();
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  void clear_graphs() {
+    for (auto &kv : graphs) {
+      if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+      if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    graphs.clear();
+  }
+
+  // ---- import ------------------------------------------------------------------------------
+  static Ccs<T> make_ccs(int64_t nrows, int64_t ncols, const int64_t *cp, const int32_t *ri, const T *v) {
+    Ccs<T> A;
+    A.nrows = nrows;
+    A.ncols = ncols;
+    A.colptr.assign((size_t)ncols + 1, 0);
+    if (ncols > 0 && cp) {
+      if (cp[0] != 0) throw Error(HIFAMD_MISMATCHED_SIZES, "CCS column pointer must start at 0");
+      for (int64_t j = 0; j < ncols; ++j)
+        if (cp[j + 1] < cp[j]) throw Error(HIFAMD_MISMATCHED_SIZES, "CCS column pointer not monotone");
+      A.colptr.assign(cp, cp + ncols + 1);
+      const int64_t nz = cp[ncols];
+      if (nz > 0 && (!ri || !v)) throw Error(HIFAMD_NULL_OBJ, "NULL index/value array with nnz > 0");
+      A.rowind.assign(ri, ri + nz);
+      A.vals.assign(v, v + nz);
+    }
+    return A;
+  }
+
+  void add_level(int64_t m, int64_t n, const int64_t *Lcp, const int32_t *Lri, const T *Lv,
+                 const int64_t *Ucp, const int32_t *Uri, const T *Uv, const int64_t *Ecp,
+                 const int32_t *Eri, const T *Ev, int64_t F_ncols, const int64_t *Fcp,
+                 const int32_t *Fri, const T *Fv, const T *d, const double *s, const double *t,
+                 const int32_t *p, const int32_t *p_inv, const int32_t *q, const int32_t *q_inv) {
+    if (finalized) throw Error(HIFAMD_BAD_PREC, "hierarchy already finalized");
+    if (host.has_dense) throw Error(HIFAMD_BAD_PREC, "the dense block must come after the last level");
+    if (m < 0 || n < m || n <= 0) throw Error(HIFAMD_MISMATCHED_SIZES, "need 0 <= m <= n, n > 0");
+    if (!host.levels.empty()) {
+      const auto &prev = host.levels.back();
+      if (prev.n - prev.m != n)
+        throw Error(HIFAMD_MISMATCHED_SIZES, "level size must equal the parent's Schur complement size n-m");
+    }
+    if (!s || !t || !p || !q_inv || (m > 0 && !d)) throw Error(HIFAMD_NULL_OBJ, "NULL level vector");
+    const int64_t nm = n - m;
+    if (F_ncols != 0 && F_ncols != nm) throw Error(HIFAMD_MISMATCHED_SIZES, "F must have n-m columns (or 0)");
+    HostLevel<T> H;
+    H.m = m;
+    H.n = n;
+    H.F_ncols = F_ncols;
+    H.L = make_ccs(m, m, Lcp, Lri, Lv);
+    H.U = make_ccs(m, m, Ucp, Uri, Uv);
+    H.E = make_ccs(nm, nm ? m : 0, nm ? Ecp : nullptr, Eri, Ev);
+    H.F = make_ccs(m, F_ncols, F_ncols ? Fcp : nullptr, Fri, Fv);
+    H.d.assign(d, d + m);
+    H.s.assign(s, s + n);
+    H.t.assign(t, t + n);
+    H.p.assign(p, p + n);
+    H.q_inv.assign(q_inv, q_inv + n);
+    if (p_inv) H.p_inv.assign(p_inv, p_inv + n);
+    if (q) H.q.assign(q, q + n);
+    for (int64_t i = 0; i < n; ++i)
+      if (H.p[(size_t)i] < 0 || H.p[(size_t)i] >= n || H.q_inv[(size_t)i] < 0 || H.q_inv[(size_t)i] >= n)
+        throw Error(HIFAMD_MISMATCHED_SIZES, "permutation entry out of range");
+    H.Lr = ccs_to_csr(H.L, false);
+    H.Ur = ccs_to_csr(H.U, true);
+    H.Er = ccs_to_csr(H.E, false);
+    H.Fr = ccs_to_csr(H.F, false);
+    H.Ls = level_schedule(H.Lr, true);
+    H.Us = level_schedule(H.Ur, false);
+    H.Lr = permute_rows(H.Lr, H.Ls.order);
+    H.Ur = permute_rows(H.Ur, H.Us.order);
+    host.levels.push_back(std::move(H));
+  }
+
+  void set_dense(int64_t nd, const T *mat, double rrqr_cond) {
+    if (finalized) throw Error(HIFAMD_BAD_PREC, "hierarchy already finalized");
+    if (host.levels.empty()) throw Error(HIFAMD_BAD_PREC, "add the sparse levels before the dense block");
+    const auto &last = host.levels.back();
+    if (nd != last.n - last.m) throw Error(HIFAMD_MISMATCHED_SIZES, "dense block size must be n-m of the last level");
+    if (!mat) throw Error(HIFAMD_NULL_OBJ, "NULL dense block");
+    dense_factorize(host.dense, mat, nd, rrqr_cond);
+    host.has_dense = true;
+  }
+
+  void finalize(int64_t max_nrhs_) {
+    if (finalized) throw Error(HIFAMD_BAD_PREC, "hierarchy already finalized");
+    if (host.levels.empty()) throw Error(HIFAMD_BAD_PREC, "empty hierarchy");
+    const auto &last = host.levels.back();
+    if (last.n != last.m && !host.has_dense)
+      throw Error(HIFAMD_BAD_PREC, "last level has a Schur complement but no dense block was set");
+    if (max_nrhs_ < 1) max_nrhs_ = 1;
+    max_nrhs = max_nrhs_;
+    Rmax = 1;
+    while (Rmax < max_nrhs && Rmax < 64) Rmax <<= 1;
+    bind_device();
+    for (auto &H : host.levels) {
+      std::unique_ptr<DevLevel> Lp(new DevLevel());
+      DevLevel &L = *Lp;
+      L.m = H.m;
+      L.n = H.n;
+      L.F_ncols = H.F_ncols;
+      L.L.upload(H.Lr, &H.Ls);
+      L.U.upload(H.Ur, &H.Us);
+      L.E.upload(H.Er, nullptr);
+      L.F.upload(H.Fr, nullptr);
+      L.d.upload(H.d);
+      L.s.upload(H.s);
+      L.t.upload(H.t);
+      L.p.upload(H.p);
+      L.qinv.upload(H.q_inv);
+      L.w.alloc((size_t)H.n * Rmax * sizeof(T));
+      L.v.alloc((size_t)H.n * Rmax * sizeof(T));
+      HIP_OK(hipMemset(L.w.p, 0, L.w.bytes));
+      HIP_OK(hipMemset(L.v.p, 0, L.v.bytes));
+      lv.push_back(std::move(Lp));
+    }
+    if (host.has_dense) {
+      dn.n = host.dense.n;
+      dn.rank = host.dense.rank;
+      dn.QH.upload(host.dense.QH);
+      dn.Rinv.upload(host.dense.Rinv);
+      dn.jpvt0.upload(host.dense.jpvt0);
+      dn.tmp.alloc((size_t)dn.n * Rmax * sizeof(T));
+      // the explicit operators are only needed on the device from here on
+      std::vector<T>().swap(host.dense.QH);
+      std::vector<T>().swap(host.dense.Rinv);
+    }
+    HIP_OK(hipDeviceSynchronize());
+    finalized = true;
+  }
+
+  void set_matrix(int64_t n, const int64_t *indptr, const int32_t *indices, const T *vals) {
+    if (!indptr || !indices || !vals) throw Error(HIFAMD_NULL_OBJ, "NULL CRS array");
+    if (!host.levels.empty() && n != host.levels[0].n)
+      throw Error(HIFAMD_MISMATCHED_SIZES, "matrix size differs from the preconditioner size");
+    const int64_t base = indptr[0];
+    if (base != 0 && base != 1) throw Error(HIFAMD_MISMATCHED_SIZES, "indptr must be 0- or 1-based");
+    const int64_t nz = indptr[n] - base;
+    if (nz > (int64_t)std::numeric_limits<int32_t>::max()) throw Error(HIFAMD_HIFIR_ERROR, "nnz(A) >= 2^31");
+    Csr<T> C;
+    C.nrows = C.ncols = n;
+    C.ptr.resize((size_t)n + 1);
+    for (int64_t i = 0; i <= n; ++i) C.ptr[(size_t)i] = (int32_t)(indptr[i] - base);
+    C.col.resize((size_t)nz);
+    for (int64_t k = 0; k < nz; ++k) {
+      const int64_t j = (int64_t)indices[k] - base;
+      if (j < 0 || j >= n) throw Error(HIFAMD_MISMATCHED_SIZES, "column index out of range");
+      C.col[(size_t)k] = (int32_t)j;
+    }
+    C.val.assign(vals, vals + nz);
+    if (!finalized) throw Error(HIFAMD_BAD_PREC, "attach the matrix after hifamd_finalize");
+    HIP_OK(hipSetDevice(device));
+    A.upload(C, nullptr);
+    has_A = true;
+  }
+
+  // ---- launch helpers ------------------------------------------------------------------------
+  static int log2i(int64_t R) {
+    int l = 0;
+    while ((1LL << l) < R) ++l;
+    return l;
+  }
+  static int pick_logR(int64_t nrhs) {
+    int64_t R = 1;
+    while (R < nrhs && R < 64) R <<= 1;
+    return log2i(R);
+  }
+  static unsigned grid_for(int64_t rows, int logR, int threads = 256) {
+    const int64_t G = 64 >> logR, rows_per_block = (threads / 64) * G;
+    int64_t g = (rows + rows_per_block - 1) / rows_per_block;
+    if (g < 1) g = 1;
+    if (g > 256 * 16) g = 256 * 16;  // grid-stride beyond that
+    return (unsigned)g;
+  }
+
+  template <bool LOWER>
+  void launch_trsv(hipStream_t st, const DevLevel &L, int logR, int64_t &count) {
+    const DevCsr &M = LOWER ? L.L : L.U;
+    if (M.nrows == 0) return;
+    D *w = L.w.as<D>(), *v = L.v.as<D>();
+    const int64_t G = 64 >> logR;
+    const int64_t thin_rows = (int64_t)thin_factor * 16 * G;
+    const auto &wf = M.wf_ptr_host;
+    const int64_t nwf = (int64_t)wf.size() - 1;
+    int64_t k = 0;
+    while (k < nwf) {
+      const int64_t rows = wf[(size_t)k + 1] - wf[(size_t)k];
+      if (rows <= thin_rows) {
+        int64_t k2 = k + 1;
+        while (k2 < nwf && wf[(size_t)k2 + 1] - wf[(size_t)k2] <= thin_rows) ++k2;
+        if (k2 - k >= 2) {
+          hipLaunchKernelGGL((k_trsv_seq<D, LOWER>), dim3(1), dim3(1024), 0, st, (int32_t)k, (int32_t)k2,
+                             M.wfptr.as<int32_t>(), M.ptr.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(),
+                             M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR);
+          ++count;
+          k = k2;
+          continue;
+        }
+      }
+      hipLaunchKernelGGL((k_trsv_wide<D, LOWER>), dim3(grid_for(rows, logR)), dim3(256), 0, st, wf[(size_t)k],
+                         wf[(size_t)k + 1], M.ptr.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(),
+                         M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR);
+      ++count;
+      ++k;
+    }
+  }
+
+  void launch_ldu(hipStream_t st, const DevLevel &L, int logR, int64_t &count) {
+    if (!L.m) return;
+    launch_trsv<true>(st, L, logR, count);
+    launch_trsv<false>(st, L, logR, count);
+  }
+
+  void launch_dense(hipStream_t st, const D *cin, D *zout, int logR, int64_t rank, int64_t &count);
+
+  int64_t eff_rank(int64_t rank) const {
+    if (rank == 0) return dn.rank;
+    if (rank < 0 || rank > dn.n) return dn.n;
+    return rank;
+  }
+
+  // one level of prec_solve (prec_solve.hpp:332-412); bin/yout may be user or arena pointers
+  void enqueue_level(hipStream_t st, size_t l, const D *bin, int64_t ldb, D *yout, int64_t ldy, int nrhs,
+                     int logR, int64_t rank, int64_t &count) {
+    DevLevel &L = *lv[l];
+    const int64_t m = L.m, n = L.n, nm = n - m;
+    const int64_t R = 1LL << logR;
+    D *w = L.w.as<D>(), *v = L.v.as<D>();
+    const bool last = (l + 1 == lv.size());
+    if (m) {  // S1  :359
+      hipLaunchKernelGGL((k_gather_scale<D>), dim3(grid_for(m, logR)), dim3(256), 0, st, bin, ldb, nrhs,
+                         L.p.as<int32_t>(), L.s.as<double>(), m, w, logR);
+      ++count;
+    }
+    if (nm) {
+      launch_ldu(st, L, logR, count);  // S2  :364
+      // S3  :366-368  -> w[m:n] (becomes the child's rhs, :386)
+      hipLaunchKernelGGL((k_spmm_epi<D>), dim3(grid_for(nm, logR)), dim3(256), 0, st, nm, L.E.ptr.as<int32_t>(),
+                         L.E.col.as<int32_t>(), L.E.val.as<D>(), v, bin, ldb, nrhs, L.p.as<int32_t>(),
+                         L.s.as<double>(), m, w + m * R, logR);
+      ++count;
+      if (last)
+        launch_dense(st, w + m * R, v + m * R, logR, rank, count);  // :371-381
+      else
+        enqueue_level(st, l + 1, w + m * R, R, v + m * R, R, (int)R, logR, rank, count);  // :383-388
+      // S5  :392-403   (v[m:n] already is "work[m:n] = y[m:n]")
+      if (m) {
+        if (L.F_ncols) {
+          hipLaunchKernelGGL((k_spmm_epi<D>), dim3(grid_for(m, logR)), dim3(256), 0, st, m, L.F.ptr.as<int32_t>(),
+                             L.F.col.as<int32_t>(), L.F.val.as<D>(), v + m * R, bin, ldb, nrhs,
+                             L.p.as<int32_t>(), L.s.as<double>(), (int64_t)0, w, logR);
+        } else {
+          hipLaunchKernelGGL((k_gather_scale<D>), dim3(grid_for(m, logR)), dim3(256), 0, st, bin, ldb, nrhs,
+                             L.p.as<int32_t>(), L.s.as<double>(), m, w, logR);
+        }
+        ++count;
+      }
+    }
+    launch_ldu(st, L, logR, count);  // S6  :406
+    // S7  :411
+    hipLaunchKernelGGL((k_scatter_scale<D>), dim3(grid_for(n, logR)), dim3(256), 0, st, v, L.qinv.as<int32_t>(),
+                       L.t.as<double>(), n, yout, ldy, nrhs, logR);
+    ++count;
+  }
+
+  // all kernels of one batched apply, nrhs tiled by 64 columns
+  int64_t enqueue_apply(hipStream_t st, const D *dB, int64_t ldb, D *dX, int64_t ldx, int64_t nrhs, int64_t rank) {
+    int64_t count = 0;
+    for (int64_t c0 = 0; c0 < nrhs; c0 += 64) {
+      const int64_t nc = std::min<int64_t>(64, nrhs - c0);
+      const int logR = pick_logR(nc);
+      enqueue_level(st, 0, dB + c0, ldb, dX + c0, ldx, (int)nc, logR, rank, count);
+    }
+    HIP_OK(hipGetLastError());
+    return count;
+  }
+
+  void check_batch(const void *B, int64_t ldb, const void *X, int64_t ldx, int64_t nrhs) const {
+    if (!finalized) throw Error(HIFAMD_BAD_PREC, "hierarchy not finalized (hifamd_finalize)");
+    if (!B || !X) throw Error(HIFAMD_NULL_OBJ, "NULL vector");
+    if (nrhs < 1) throw Error(HIFAMD_MISMATCHED_SIZES, "nrhs must be >= 1");
+    if (ldb < nrhs || ldx < nrhs) throw Error(HIFAMD_MISMATCHED_SIZES, "row stride smaller than nrhs");
+    if (std::min<int64_t>(nrhs, 64) > Rmax)
+      throw Error(HIFAMD_MISMATCHED_SIZES, "batch wider than the max_nrhs given to hifamd_finalize");
+    if (B == X) throw Error(HIFAMD_BAD_PREC, "b and x must not alias");
+  }
+
+  // graph-cached batched apply on device pointers
+  void solve_dev(const D *dB, int64_t ldb, D *dX, int64_t ldx, int64_t nrhs, int64_t rank, hipStream_t user) {
+    check_batch(dB, ldb, dX, ldx, nrhs);
+    HIP_OK(hipSetDevice(device));
+    hipStream_t st = user ? user : stream;
+    if (!use_graph) {
+      last_launches = enqueue_apply(st, dB, ldb, dX, ldx, nrhs, rank);
+      return;
+    }
+    GraphKey key{dB, dX, ldb, ldx, nrhs, host.has_dense ? eff_rank(rank) : 0};
+    auto it = graphs.find(key);
+    if (it == graphs.end()) {
+      if (graphs.size() >= 8) {  // evict the least recently used
+        auto old = graphs.begin();
+        for (auto jt = graphs.begin(); jt != graphs.end(); ++jt)
+          if (jt->second.stamp < old->second.stamp) old = jt;
+        (void)hipGraphExecDestroy(old->second.exec);
+        (void)hipGraphDestroy(old->second.graph);
+        graphs.erase(old);
+      }
+      GraphEntry ge;
+      HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+      try {
+        ge.launches = enqueue_apply(stream, dB, ldb, dX, ldx, nrhs, rank);
+      } catch (...) {
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        throw;
+      }
+      HIP_OK(hipStreamEndCapture(stream, &ge.graph));
+      HIP_OK(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+      it = graphs.emplace(key, ge).first;
+    }
+    it->second.stamp = ++clock;
+    last_launches = it->second.launches;
+    HIP_OK(hipGraphLaunch(it->second.exec, st));
+  }
+
+  void solve_host(const T *B, int64_t ldb, T *X, int64_t ldx, int64_t nrhs, int64_t rank) {
+    check_batch(B, ldb, X, ldx, nrhs);
+    HIP_OK(hipSetDevice(device));
+    const int64_t n = lv[0]->n;
+    const size_t need = (size_t)n * nrhs * sizeof(T);
+    if (stage_b.bytes < need) stage_b.alloc(need);
+    if (stage_x.bytes < need) stage_x.alloc(need);
+    HIP_OK(hipMemcpy2DAsync(stage_b.p, nrhs * sizeof(T), B, ldb * sizeof(T), nrhs * sizeof(T), n,
+                            hipMemcpyHostToDevice, stream));
+    solve_dev(stage_b.as<D>(), nrhs, stage_x.as<D>(), nrhs, nrhs, rank, nullptr);
+    HIP_OK(hipMemcpy2DAsync(X, ldx * sizeof(T), stage_x.p, nrhs * sizeof(T), nrhs * sizeof(T), n,
+                            hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+  }
+
+  // ---- SpMV + iterative refinement -----------------------------------------------------------
+  void spmv_dev(const D *dX, int64_t ldx, D *dY, int64_t ldy, int64_t nrhs, hipStream_t user) {
+    if (!finalized) throw Error(HIFAMD_BAD_PREC, "hierarchy not finalized (hifamd_finalize)");
+    if (!has_A) throw Error(HIFAMD_BAD_PREC, "no matrix attached (hifamd_set_matrix)");
+    if (!dX || !dY) throw Error(HIFAMD_NULL_OBJ, "NULL vector");
+    HIP_OK(hipSetDevice(device));
+    hipStream_t st = user ? user : stream;
+    for (int64_t c0 = 0; c0 < nrhs; c0 += 64) {
+      const int nc = (int)std::min<int64_t>(64, nrhs - c0);
+      const int logR = pick_logR(nc);
+      hipLaunchKernelGGL((k_crs_spmm<D, false>), dim3(grid_for(A.nrows, logR)), dim3(256), 0, st, A.nrows,
+                         A.ptr.as<int32_t>(), A.col.as<int32_t>(), A.val.as<D>(), dX + c0, ldx, (const D *)nullptr,
+                         (int64_t)0, dY + c0, ldy, nc, logR);
+    }
+    HIP_OK(hipGetLastError());
+  }
+
+  void resid_dev(const D *dB, int64_t ldb, const D *dX, int64_t ldx, D *dR, int64_t ldr, int64_t nrhs) {
+    for (int64_t c0 = 0; c0 < nrhs; c0 += 64) {
+      const int nc = (int)std::min<int64_t>(64, nrhs - c0);
+      const int logR = pick_logR(nc);
+      hipLaunchKernelGGL((k_crs_spmm<D, true>), dim3(grid_for(A.nrows, logR)), dim3(256), 0, stream, A.nrows,
+                         A.ptr.as<int32_t>(), A.col.as<int32_t>(), A.val.as<D>(), dX + c0, ldx, dB + c0, ldb,
+                         dR + c0, ldr, nc, logR);
+    }
+    HIP_OK(hipGetLastError());
+  }
+
+  void vec_op(int op, int64_t n, int64_t nrhs, D *y, int64_t ldy, const D *x, int64_t ldx, const D *z, int64_t ldz) {
+    int64_t g = (n * nrhs + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL((k_vec_op<D>), dim3((unsigned)g), dim3(256), 0, stream, op, n, (int)nrhs, y, ldy, x, ldx, z, ldz);
+  }
+
+  // per-column 2-norms of an [n][nrhs] block (nrhs <= 64 per pass); result on the host
+  void col_norms(const D *x, int64_t ldx, int64_t n, int64_t nrhs, std::vector<double> &out) {
+    out.assign((size_t)nrhs, 0.0);
+    const int nblk = 512;
+    if (ir_part.bytes < (size_t)nblk * 64 * sizeof(double)) ir_part.alloc((size_t)nblk * 64 * sizeof(double));
+    std::vector<double> part((size_t)nblk * 64);
+    for (int64_t c0 = 0; c0 < nrhs; c0 += 64) {
+      const int nc = (int)std::min<int64_t>(64, nrhs - c0);
+      hipLaunchKernelGGL((k_colnorm2_partial<D>), dim3(nblk), dim3(256), 0, stream, n, nc, x + c0, ldx,
+                         ir_part.as<double>());
+      HIP_OK(hipMemcpyAsync(part.data(), ir_part.p, (size_t)nblk * nc * sizeof(double), hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+      for (int c = 0; c < nc; ++c) {
+        double tot = 0.0;
+        for (int b = 0; b < nblk; ++b) tot += part[(size_t)b * nc + c];
+        out[(size_t)(c0 + c)] = std::sqrt(tot);
+      }
+    }
+  }
+
+  // IterRefine::iter_refine for a whole block (IterRefine.hpp:77-105 and :121-165)
+  void hifir_dev(const D *dB, int64_t ldb, D *dX, int64_t ldx, int64_t nrhs, int nirs, const double *betas,
+                 int64_t rank, int *ir_status) {
+    check_batch(dB, ldb, dX, ldx, nrhs);
+    HIP_OK(hipSetDevice(device));
+    const int64_t n = lv[0]->n;
+    if (nirs <= 1) {  // :83-87 / :128-132
+      solve_dev(dB, ldb, dX, ldx, nrhs, rank, nullptr);
+      HIP_OK(hipStreamSynchronize(stream));
+      if (ir_status)
+        for (int64_t c = 0; c < nrhs; ++c) ir_status[2 * c] = 1, ir_status[2 * c + 1] = -1;
+      return;
+    }
+    if (!has_A) throw Error(HIFAMD_BAD_PREC, "iterative refinement needs the matrix (hifamd_set_matrix)");
+    const size_t need = (size_t)n * nrhs * sizeof(T);
+    if (ir_r.bytes < need) ir_r.alloc(need);
+    if (ir_xk.bytes < need) ir_xk.alloc(need);
+    D *r = ir_r.as<D>(), *xk = ir_xk.as<D>();
+    if (!betas) {
+      // x = 0; repeat N: xk = x; r = (i ? b - A xk : b); x = M^{-1} r + xk
+      vec_op(0, n, nrhs, dX, ldx, nullptr, 0, nullptr, 0);
+      for (int i = 0; i < nirs; ++i) {
+        vec_op(1, n, nrhs, xk, nrhs, dX, ldx, nullptr, 0);
+        if (i)
+          resid_dev(dB, ldb, xk, nrhs, r, nrhs, nrhs);
+        else
+          vec_op(1, n, nrhs, r, nrhs, dB, ldb, nullptr, 0);
+        // M.solve(x, _r): the reference solves into _r and then x = _r + _xk (:102-103)
+        solve_dev(r, nrhs, dX, ldx, nrhs, rank, nullptr);
+        vec_op(2, n, nrhs, dX, ldx, xk, nrhs, nullptr, 0);  // x = M^{-1} r + xk  (a + b commutes bitwise)
+      }
+      HIP_OK(hipStreamSynchronize(stream));
+      if (ir_status)
+        for (int64_t c = 0; c < nrhs; ++c) ir_status[2 * c] = nirs, ir_status[2 * c + 1] = -1;
+      return;
+    }
+    // bounded variant, per column; columns that finished keep iterating harmlessly only until all
+    // are done?  No: a finished column must keep the x it had -- freeze it by masking its update.
+    std::vector<double> bnorm, rnorm;
+    col_norms(dB, ldb, n, nrhs, bnorm);
+    std::vector<int> iters((size_t)nrhs, 0), flag((size_t)nrhs, 0);
+    std::vector<char> active((size_t)nrhs, 1);
+    vec_op(0, n, nrhs, dX, ldx, nullptr, 0, nullptr, 0);
+    for (int64_t c = 0; c < nrhs; ++c)
+      if (bnorm[(size_t)c] == 0.0) active[(size_t)c] = 0;  // :134-137: x = 0, (0, 0)
+    vec_op(1, n, nrhs, r, nrhs, dB, ldb, nullptr, 0);
+    DevBuf mask;
+    mask.alloc((size_t)nrhs * sizeof(int));
+    std::vector<int> hmask((size_t)nrhs);
+    int nactive = 0;
+    for (char a : active) nactive += a;
+    while (nactive > 0) {
+      solve_dev(r, nrhs, xk, nrhs, nrhs, rank, nullptr);  // xk = M^{-1} r
+      for (int64_t c = 0; c < nrhs; ++c) hmask[(size_t)c] = active[(size_t)c];
+      HIP_OK(hipMemcpyAsync(mask.p, hmask.data(), (size_t)nrhs * sizeof(int), hipMemcpyHostToDevice, stream));
+      launch_masked_add(n, nrhs, dX, ldx, xk, nrhs, mask.as<int>());  // x += xk on active columns
+      for (int64_t c = 0; c < nrhs; ++c)
+        if (active[(size_t)c] && ++iters[(size_t)c] >= nirs) {
+          flag[(size_t)c] = -1;
+          active[(size_t)c] = 0;
+        }
+      nactive = 0;
+      for (char a : active) nactive += a;
+      if (!nactive) break;
+      resid_dev(dB, ldb, dX, ldx, r, nrhs, nrhs);  // r = b - A x
+      col_norms(r, nrhs, n, nrhs, rnorm);
+      for (int64_t c = 0; c < nrhs; ++c) {
+        if (!active[(size_t)c]) continue;
+        const double res = rnorm[(size_t)c] / bnorm[(size_t)c];
+        if (res <= betas[0])
+          active[(size_t)c] = 0;
+        else if (res > betas[1]) {
+          flag[(size_t)c] = 1;
+          active[(size_t)c] = 0;
+        }
+      }
+      nactive = 0;
+      for (char a : active) nactive += a;
+    }
+    HIP_OK(hipStreamSynchronize(stream));
+    if (ir_status)
+      for (int64_t c = 0; c < nrhs; ++c) ir_status[2 * c] = iters[(size_t)c], ir_status[2 * c + 1] = flag[(size_t)c];
+  }
+
+  void launch_masked_add(int64_t n, int64_t nrhs, D *y, int64_t ldy, const D *x, int64_t ldx, const int *mask);
+
+  void hifir_host(const T *B, int64_t ldb, T *X, int64_t ldx, int64_t nrhs, int nirs, const double *betas,
+                  int64_t rank, int *ir_status) {
+    check_batch(B, ldb, X, ldx, nrhs);
+    HIP_OK(hipSetDevice(device));
+    const int64_t n = lv[0]->n;
+    const size_t need = (size_t)n * nrhs * sizeof(T);
+    if (stage_b.bytes < need) stage_b.alloc(need);
+    if (stage_x.bytes < need) stage_x.alloc(need);
+    HIP_OK(hipMemcpy2DAsync(stage_b.p, nrhs * sizeof(T), B, ldb * sizeof(T), nrhs * sizeof(T), n,
+                            hipMemcpyHostToDevice, stream));
+    hifir_dev(stage_b.as<D>(), nrhs, stage_x.as<D>(), nrhs, nrhs, nirs, betas, rank, ir_status);
+    HIP_OK(hipMemcpy2DAsync(X, ldx * sizeof(T), stage_x.p, nrhs * sizeof(T), nrhs * sizeof(T), n,
+                            hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+  }
+
+  // ---- stats ----------------------------------------------------------------------------------
+  void stats(double *o) const {
+    for (int i = 0; i < 16; ++i) o[i] = 0.0;
+    const double sv = sizeof(T), si = 4, sp = 8, ss = 8;
+    double bmat = 0, bvec = 0;
+    int64_t wfL = 0, wfU = 0;
+    for (const auto &H : host.levels) {
+      const double m = (double)H.m, n = (double)H.n;
+      const double nl = (double)H.L.nnz(), nu = (double)H.U.nnz(), ne = (double)H.E.nnz(), nf = (double)H.F.nnz();
+      o[0] += n;
+      o[1] += m;
+      o[2] += nl + nu;
+      o[3] += ne + nf;
+      // matrices streamed once per use (LU twice), vectors once per stage
+      bmat += 2 * (nl + nu) * (sv + si) + (ne + nf) * (sv + si) + 2 * m * sv + 4 * (m + 1) * sp + (n + 2) * sp +
+              n * (2 * si + 2 * ss);
+      bvec += sv * (7 * n + 4 * m);
+      wfL += H.Ls.nwf();
+      wfU += H.Us.nwf();
+    }
+    if (host.has_dense) {
+      o[4] = (double)host.dense.n;
+      bmat += (double)host.dense.n * (double)host.dense.n * sv;
+    }
+    o[5] = bmat;
+    o[6] = bvec;
+    o[7] = (double)wfL;
+    o[8] = (double)wfU;
+    o[9] = (double)last_launches;
+    o[10] = (double)host.levels.size();
+  }
+
+  int64_t nnz_total() const {
+    int64_t z = 0;
+    for (const auto &H : host.levels) {
+      if (H.m) z += H.L.nnz() + H.U.nnz() + H.m;
+      if (H.n - H.m) z += H.E.nnz() + H.F.nnz();
+    }
+    if (host.has_dense) z += host.dense.n * host.dense.n;
+    return z;
+  }
+};
+
+// masked axpy kernel for the bounded IR variant
+template <class D>
+__global__ void __launch_bounds__(256) k_masked_add(int64_t n, int nrhs, D *y, int64_t ldy, const D *x, int64_t ldx,
+                                                    const int *mask) {
+  const int64_t total = n * nrhs;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / nrhs;
+    const int c = (int)(e - i * nrhs);
+    if (mask[c]) y[i * ldy + c] = vadd(y[i * ldy + c], x[i * ldx + c]);
+  }
+}
+
+template <class T>
+void Engine<T>::launch_masked_add(int64_t n, int64_t nrhs, D *y, int64_t ldy, const D *x, int64_t ldx, const int *mask) {
+  int64_t g = (n * nrhs + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL((k_masked_add<D>), dim3((unsigned)g), dim3(256), 0, stream, n, (int)nrhs, y, ldy, x, ldx, mask);
+}
+
+// dense last level: z = P * [ Rinv(1:rk,1:rk) * (Q^H c)(1:rk) ; 0 ]   (QRCP::_solve_nt, QRCP.hpp:371-411)
+template <>
+void Engine<double>::launch_dense(hipStream_t st, const double *cin, double *zout, int logR, int64_t rank, int64_t &count) {
+  const int nd = (int)dn.n, rk = (int)eff_rank(rank);
+  const unsigned g = (unsigned)((((nd + 15) / 16) + 3) / 4);
+  double *tmp = dn.tmp.as<double>();
+  // T1 = Q^H(1:rk, :) c   (rows >= rk come out as zeros and are never read)
+  hipLaunchKernelGGL(k_dense_gemm_d, dim3(g), dim3(256), 0, st, nd, rk, nd, 0, dn.QH.as<double>(), nd, cin, logR,
+                     (const int32_t *)nullptr, tmp);
+  // z[jpvt[i]] = sum_{k>=i} Rinv(i,k) T1[k], i < rk; zero rows beyond rk
+  hipLaunchKernelGGL(k_dense_gemm_d, dim3(g), dim3(256), 0, st, nd, rk, rk, 1, dn.Rinv.as<double>(), nd, tmp, logR,
+                     dn.jpvt0.as<int32_t>(), zout);
+  count += 2;
+}
+
+template <>
+void Engine<zdouble>::launch_dense(hipStream_t st, const cplx *cin, cplx *zout, int logR, int64_t rank, int64_t &count) {
+  const int nd = (int)dn.n, rk = (int)eff_rank(rank);
+  cplx *tmp = dn.tmp.as<cplx>();
+  hipLaunchKernelGGL(k_dense_gemm_z, dim3(grid_for(nd, logR)), dim3(256), 0, st, nd, rk, nd, 0, dn.QH.as<cplx>(), nd, cin,
+                     logR, (const int32_t *)nullptr, tmp);
+  hipLaunchKernelGGL(k_dense_gemm_z, dim3(grid_for(nd, logR)), dim3(256), 0, st, nd, rk, rk, 1, dn.Rinv.as<cplx>(), nd, tmp,
+                     logR, dn.jpvt0.as<int32_t>(), zout);
+  count += 2;
+}
+
+}  // namespace hifamd
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+using namespace hifamd;
+
+struct HifAmdPrec {
+  int vt;
+  EngineBase *eng;
+};
+
+#define API_BEGIN                                      \
+  if (!h || !h->eng) {                                 \
+    set_err("NULL handle");                            \
+    return HIFAMD_NULL_OBJ;                            \
+  }                                                    \
+  try {
+#define API_END                                        \
+  }                                                    \
+  catch (const Error &e) {                             \
+    set_err(e.what());                                 \
+    return (HifAmdStatus)e.code;                       \
+  }                                                    \
+  catch (const std::exception &e) {                    \
+    set_err(e.what());                                 \
+    return HIFAMD_HIFIR_ERROR;                         \
+  }                                                    \
+  return HIFAMD_SUCCESS;
+
+#define ENG_D ((Engine<double> *)h->eng)
+#define ENG_Z ((Engine<zdouble> *)h->eng)
+#define DISPATCH(call_d, call_z) \
+  if (h->vt == HIFAMD_D) {       \
+    call_d;                      \
+  } else {                       \
+    call_z;                      \
+  }
+
+template <class E>
+static int64_t q_nrows(E *e) {
+  return e->host.levels.empty() ? 0 : e->host.levels[0].n;
+}
+
+template <class E>
+static int64_t q_levels(E *e) {
+  return (int64_t)e->host.levels.size() + (e->host.has_dense ? 1 : 0);
+}
+
+template <class E>
+static int64_t q_schur_size(E *e) {
+  return e->host.levels.empty() ? 0 : e->host.levels.back().n - e->host.levels.back().m;
+}
+
+template <class E>
+static int64_t q_schur_rank(E *e) {
+  return e->host.has_dense ? e->host.dense.rank : 0;
+}
+
+template <class E>
+static void do_schedule(E *e, int level, int which, int64_t *nwf, int32_t *order, int64_t *wf_ptr) {
+  if (level < 0 || level >= (int)e->host.levels.size()) throw Error(HIFAMD_MISMATCHED_SIZES, "level out of range");
+  const Schedule &S = which == 0 ? e->host.levels[(size_t)level].Ls : e->host.levels[(size_t)level].Us;
+  if (nwf) *nwf = S.nwf();
+  if (order) std::copy(S.order.begin(), S.order.end(), order);
+  if (wf_ptr) std::copy(S.wf_ptr.begin(), S.wf_ptr.end(), wf_ptr);
+}
+
+template <class E, class D>
+static void do_time(E *e, const D *dB, int64_t ldb, D *dX, int64_t ldx, int64_t nrhs, int64_t rank, int warmup, int reps,
+                    double *ms_avg) {
+  if (!ms_avg) throw Error(HIFAMD_NULL_OBJ, "NULL output");
+  for (int i = 0; i < warmup; ++i) e->solve_dev(dB, ldb, dX, ldx, nrhs, rank, nullptr);
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0));
+  HIP_OK(hipEventCreate(&e1));
+  HIP_OK(hipEventRecord(e0, e->stream));
+  for (int i = 0; i < reps; ++i) e->solve_dev(dB, ldb, dX, ldx, nrhs, rank, nullptr);
+  HIP_OK(hipEventRecord(e1, e->stream));
+  HIP_OK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_avg = (double)ms / (reps > 0 ? reps : 1);
+}
+
+template <class E>
+static void do_sync(E *e) {
+  if (!e->finalized) throw Error(HIFAMD_BAD_PREC, "hierarchy not finalized (hifamd_finalize)");
+  HIP_OK(hipSetDevice(e->device));
+  HIP_OK(hipStreamSynchronize(e->stream));
+}
+
+extern "C" {
+
+const char *hifamd_version(void) { return "hifir_amd 0.1.0 (gfx950)"; }
+
+const char *hifamd_last_error(void) {
+  if (!g_has_err) return nullptr;
+  g_has_err = false;
+  return g_err.c_str();
+}
+
+int hifamd_device_count(void) {
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+  return cnt;
+}
+
+HifAmdStatus hifamd_create(HifAmdValueType vt, int device, HifAmdHdl *out) {
+  if (!out) {
+    set_err("NULL output handle");
+    return HIFAMD_NULL_OBJ;
+  }
+  *out = nullptr;
+  try {
+    EngineBase *e = nullptr;
+    if (vt == HIFAMD_D)
+      e = new Engine<double>(device);
+    else if (vt == HIFAMD_Z)
+      e = new Engine<zdouble>(device);
+    else
+      throw Error(HIFAMD_BAD_PREC, "unknown value type");
+    HifAmdPrec *h = new HifAmdPrec{(int)vt, e};
+    *out = h;
+  } catch (const Error &e) {
+    set_err(e.what());
+    return (HifAmdStatus)e.code;
+  } catch (const std::exception &e) {
+    set_err(e.what());
+    return HIFAMD_HIFIR_ERROR;
+  }
+  return HIFAMD_SUCCESS;
+}
+
+HifAmdStatus hifamd_destroy(HifAmdHdl h) {
+  if (!h) return HIFAMD_SUCCESS;
+  delete h->eng;
+  delete h;
+  return HIFAMD_SUCCESS;
+}
+
+HifAmdStatus hifamd_add_level(HifAmdHdl h, int64_t m, int64_t n, const int64_t *Lcp, const int32_t *Lri,
+                              const void *Lv, const int64_t *Ucp, const int32_t *Uri, const void *Uv,
+                              const int64_t *Ecp, const int32_t *Eri, const void *Ev, int64_t F_ncols,
+                              const int64_t *Fcp, const int32_t *Fri, const void *Fv, const void *d,
+                              const double *s, const double *t, const int32_t *p, const int32_t *p_inv,
+                              const int32_t *q, const int32_t *q_inv) {
+  API_BEGIN
+  DISPATCH(ENG_D->add_level(m, n, Lcp, Lri, (const double *)Lv, Ucp, Uri, (const double *)Uv, Ecp, Eri,
+                            (const double *)Ev, F_ncols, Fcp, Fri, (const double *)Fv, (const double *)d, s, t, p,
+                            p_inv, q, q_inv),
+           ENG_Z->add_level(m, n, Lcp, Lri, (const zdouble *)Lv, Ucp, Uri, (const zdouble *)Uv, Ecp, Eri,
+                            (const zdouble *)Ev, F_ncols, Fcp, Fri, (const zdouble *)Fv, (const zdouble *)d, s, t,
+                            p, p_inv, q, q_inv))
+  API_END
+}
+
+HifAmdStatus hifamd_set_dense(HifAmdHdl h, int64_t nd, const void *mat, double rrqr_cond) {
+  API_BEGIN
+  DISPATCH(ENG_D->set_dense(nd, (const double *)mat, rrqr_cond), ENG_Z->set_dense(nd, (const zdouble *)mat, rrqr_cond))
+  API_END
+}
+
+HifAmdStatus hifamd_finalize(HifAmdHdl h, int64_t max_nrhs) {
+  API_BEGIN
+  DISPATCH(ENG_D->finalize(max_nrhs), ENG_Z->finalize(max_nrhs))
+  API_END
+}
+
+#define QUERY(expr_d, expr_z) \
+  if (!h || !h->eng) return 0; \
+  return h->vt == HIFAMD_D ? (expr_d) : (expr_z);
+
+
+int64_t hifamd_nrows(HifAmdHdl h) { QUERY(q_nrows(ENG_D), q_nrows(ENG_Z)) }
+int64_t hifamd_levels(HifAmdHdl h) { QUERY(q_levels(ENG_D), q_levels(ENG_Z)) }
+int64_t hifamd_nnz(HifAmdHdl h) { QUERY(ENG_D->nnz_total(), ENG_Z->nnz_total()) }
+int64_t hifamd_schur_size(HifAmdHdl h) { QUERY(q_schur_size(ENG_D), q_schur_size(ENG_Z)) }
+int64_t hifamd_schur_rank(HifAmdHdl h) { QUERY(q_schur_rank(ENG_D), q_schur_rank(ENG_Z)) }
+
+HifAmdStatus hifamd_stats(HifAmdHdl h, double *stats16) {
+  API_BEGIN
+  if (!stats16) throw Error(HIFAMD_NULL_OBJ, "NULL stats array");
+  DISPATCH(ENG_D->stats(stats16), ENG_Z->stats(stats16))
+  API_END
+}
+
+
+HifAmdStatus hifamd_level_schedule(HifAmdHdl h, int level, int which, int64_t *nwf, int32_t *order, int64_t *wf_ptr) {
+  API_BEGIN
+  DISPATCH(do_schedule(ENG_D, level, which, nwf, order, wf_ptr), do_schedule(ENG_Z, level, which, nwf, order, wf_ptr))
+  API_END
+}
+
+HifAmdStatus hifamd_solve(HifAmdHdl h, const void *b, void *x, int64_t rank) {
+  API_BEGIN
+  DISPATCH(ENG_D->solve_host((const double *)b, 1, (double *)x, 1, 1, rank),
+           ENG_Z->solve_host((const zdouble *)b, 1, (zdouble *)x, 1, 1, rank))
+  API_END
+}
+
+HifAmdStatus hifamd_solve_batch(HifAmdHdl h, const void *B, int64_t ldb, void *X, int64_t ldx, int64_t nrhs, int64_t rank) {
+  API_BEGIN
+  DISPATCH(ENG_D->solve_host((const double *)B, ldb, (double *)X, ldx, nrhs, rank),
+           ENG_Z->solve_host((const zdouble *)B, ldb, (zdouble *)X, ldx, nrhs, rank))
+  API_END
+}
+
+HifAmdStatus hifamd_solve_batch_dev(HifAmdHdl h, const void *dB, int64_t ldb, void *dX, int64_t ldx, int64_t nrhs,
+                                    int64_t rank, void *stream) {
+  API_BEGIN
+  DISPATCH(ENG_D->solve_dev((const double *)dB, ldb, (double *)dX, ldx, nrhs, rank, (hipStream_t)stream),
+           ENG_Z->solve_dev((const cplx *)dB, ldb, (cplx *)dX, ldx, nrhs, rank, (hipStream_t)stream))
+  API_END
+}
+
+HifAmdStatus hifamd_set_matrix(HifAmdHdl h, int64_t n, const int64_t *indptr, const int32_t *indices, const void *vals) {
+  API_BEGIN
+  DISPATCH(ENG_D->set_matrix(n, indptr, indices, (const double *)vals),
+           ENG_Z->set_matrix(n, indptr, indices, (const zdouble *)vals))
+  API_END
+}
+
+HifAmdStatus hifamd_spmv_batch_dev(HifAmdHdl h, const void *dX, int64_t ldx, void *dY, int64_t ldy, int64_t nrhs,
+                                   void *stream) {
+  API_BEGIN
+  DISPATCH(ENG_D->spmv_dev((const double *)dX, ldx, (double *)dY, ldy, nrhs, (hipStream_t)stream),
+           ENG_Z->spmv_dev((const cplx *)dX, ldx, (cplx *)dY, ldy, nrhs, (hipStream_t)stream))
+  API_END
+}
+
+HifAmdStatus hifamd_hifir_batch(HifAmdHdl h, const void *B, int64_t ldb, void *X, int64_t ldx, int64_t nrhs, int nirs,
+                                const double *betas, int64_t rank, int *ir_status) {
+  API_BEGIN
+  DISPATCH(ENG_D->hifir_host((const double *)B, ldb, (double *)X, ldx, nrhs, nirs, betas, rank, ir_status),
+           ENG_Z->hifir_host((const zdouble *)B, ldb, (zdouble *)X, ldx, nrhs, nirs, betas, rank, ir_status))
+  API_END
+}
+
+HifAmdStatus hifamd_hifir_batch_dev(HifAmdHdl h, const void *dB, int64_t ldb, void *dX, int64_t ldx, int64_t nrhs,
+                                    int nirs, const double *betas, int64_t rank, int *ir_status) {
+  API_BEGIN
+  DISPATCH(ENG_D->hifir_dev((const double *)dB, ldb, (double *)dX, ldx, nrhs, nirs, betas, rank, ir_status),
+           ENG_Z->hifir_dev((const cplx *)dB, ldb, (cplx *)dX, ldx, nrhs, nirs, betas, rank, ir_status))
+  API_END
+}
+
+
+HifAmdStatus hifamd_time_apply(HifAmdHdl h, const void *dB, int64_t ldb, void *dX, int64_t ldx, int64_t nrhs,
+                               int64_t rank, int warmup, int reps, double *ms_avg) {
+  API_BEGIN
+  DISPATCH(do_time(ENG_D, (const double *)dB, ldb, (double *)dX, ldx, nrhs, rank, warmup, reps, ms_avg),
+           do_time(ENG_Z, (const cplx *)dB, ldb, (cplx *)dX, ldx, nrhs, rank, warmup, reps, ms_avg))
+  API_END
+}
+
+
+HifAmdStatus hifamd_sync(HifAmdHdl h) {
+  API_BEGIN
+  DISPATCH(do_sync(ENG_D), do_sync(ENG_Z))
+  API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,458 @@
+// host.hpp -- host side of the MI355X-native HIFIR apply path: the imported hierarchy, CCS -> CSR
+// conversion in processing order, level scheduling of the triangular factors, and the dense
+// last-level factorization (QR with column pivoting, explicit Q^H and R^{-1} for the MFMA GEMMs).
+//
+// Nothing here runs per apply: it is the one-time "ship the factored hierarchy to HBM" step of
+// BASELINE.json's north_star.  Reference data contract: hif::Prec, src/hif/alg/Prec.hpp:82-334.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace hifamd {
+
+typedef std::complex<double> zdouble;
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+// ---------------------------------------------------------------------------------------------
+// matrices
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct Ccs {  // as the reference stores L_B, U_B, E, F (Prec::mat_type = ccs_type, Prec.hpp:86,90)
+  int64_t nrows = 0, ncols = 0;
+  std::vector<int64_t> colptr;
+  std::vector<int32_t> rowind;
+  std::vector<T> vals;
+  int64_t nnz() const { return colptr.empty() ? 0 : colptr.back(); }
+};
+
+template <class T>
+struct Csr {  // device-side form: row gather.  ptr is indexed by SLOT (processing order), see rowid
+  int64_t nrows = 0, ncols = 0;
+  std::vector<int32_t> ptr;    // nrows+1
+  std::vector<int32_t> col;    // nnz, per-row order == the reference's per-row accumulation order
+  std::vector<T> val;
+  std::vector<int32_t> rowid;  // slot -> row id (identity for E, F, A)
+};
+
+// CCS -> CSR keeping, inside every row, the order in which the reference's column sweep touches
+// that row: ascending column for the forward sweeps (solve_as_strict_lower CompressedStorage.hpp:2268,
+// multiply_nt_low :2079), descending column for solve_as_strict_upper (:2357).
+template <class T>
+Csr<T> ccs_to_csr(const Ccs<T> &A, bool descending_cols) {
+  Csr<T> B;
+  B.nrows = A.nrows;
+  B.ncols = A.ncols;
+  const int64_t nz = A.nnz();
+  if (nz > (int64_t)std::numeric_limits<int32_t>::max())
+    throw Error(4, "matrix has more than 2^31-1 nonzeros: int32 device row pointers overflow");
+  B.ptr.assign((size_t)A.nrows + 1, 0);
+  for (int64_t k = 0; k < nz; ++k) {
+    const int32_t r = A.rowind[(size_t)k];
+    if (r < 0 || r >= A.nrows) throw Error(2, "row index out of range in imported CCS matrix");
+    ++B.ptr[(size_t)r + 1];
+  }
+  for (int64_t i = 0; i < A.nrows; ++i) B.ptr[(size_t)i + 1] += B.ptr[(size_t)i];
+  B.col.resize((size_t)nz);
+  B.val.resize((size_t)nz);
+  std::vector<int32_t> fill(B.ptr.begin(), B.ptr.end() - 1);
+  auto put = [&](int64_t j) {
+    for (int64_t k = A.colptr[(size_t)j]; k < A.colptr[(size_t)j + 1]; ++k) {
+      const int32_t r = A.rowind[(size_t)k];
+      const int32_t pos = fill[(size_t)r]++;
+      B.col[(size_t)pos] = (int32_t)j;
+      B.val[(size_t)pos] = A.vals[(size_t)k];
+    }
+  };
+  if (!descending_cols)
+    for (int64_t j = 0; j < A.ncols; ++j) put(j);
+  else
+    for (int64_t j = A.ncols - 1; j >= 0; --j) put(j);
+  B.rowid.resize((size_t)A.nrows);
+  for (int64_t i = 0; i < A.nrows; ++i) B.rowid[(size_t)i] = (int32_t)i;
+  return B;
+}
+
+// ---------------------------------------------------------------------------------------------
+// level scheduling
+// ---------------------------------------------------------------------------------------------
+struct Schedule {
+  std::vector<int32_t> order;   // slot -> row id, wavefront by wavefront
+  std::vector<int64_t> wf_ptr;  // wavefront w owns slots [wf_ptr[w], wf_ptr[w+1])
+  int64_t nwf() const { return (int64_t)wf_ptr.size() - 1; }
+};
+
+// Wavefront (dependency depth) of every row of a strict triangle in CSR: a row can be solved as
+// soon as every row it references is done.  lower: references j < i, rows visited ascending;
+// upper: references j > i, rows visited descending.  Rows inside a wavefront keep that visiting
+// order, so slot order is a valid sequential order too.
+template <class T>
+Schedule level_schedule(const Csr<T> &A, bool lower) {
+  const int64_t m = A.nrows;
+  std::vector<int32_t> depth((size_t)m, 0);
+  int32_t maxd = -1;
+  for (int64_t ii = 0; ii < m; ++ii) {
+    const int64_t i = lower ? ii : m - 1 - ii;
+    int32_t d = 0;
+    for (int32_t k = A.ptr[(size_t)i]; k < A.ptr[(size_t)i + 1]; ++k) {
+      const int32_t j = A.col[(size_t)k];
+      if (lower ? (j >= i) : (j <= i)) throw Error(3, "triangular factor is not strict");
+      d = std::max(d, depth[(size_t)j] + 1);
+    }
+    depth[(size_t)i] = d;
+    maxd = std::max(maxd, d);
+  }
+  Schedule S;
+  S.wf_ptr.assign((size_t)(maxd + 2), 0);
+  for (int64_t i = 0; i < m; ++i) ++S.wf_ptr[(size_t)depth[(size_t)i] + 1];
+  for (size_t w = 0; w + 1 < S.wf_ptr.size(); ++w) S.wf_ptr[w + 1] += S.wf_ptr[w];
+  S.order.resize((size_t)m);
+  std::vector<int64_t> fill(S.wf_ptr.begin(), S.wf_ptr.end() - 1);
+  for (int64_t ii = 0; ii < m; ++ii) {
+    const int64_t i = lower ? ii : m - 1 - ii;
+    S.order[(size_t)fill[(size_t)depth[(size_t)i]]++] = (int32_t)i;
+  }
+  return S;
+}
+
+// Physically permute the CSR rows into slot order so that the matrix streams through HBM in the
+// order the kernels consume it (coalesced index/value reads for every batch width).
+template <class T>
+Csr<T> permute_rows(const Csr<T> &A, const std::vector<int32_t> &order) {
+  Csr<T> B;
+  B.nrows = A.nrows;
+  B.ncols = A.ncols;
+  B.ptr.assign((size_t)A.nrows + 1, 0);
+  B.col.resize(A.col.size());
+  B.val.resize(A.val.size());
+  B.rowid = order;
+  int32_t pos = 0;
+  for (int64_t s = 0; s < A.nrows; ++s) {
+    const int32_t i = order[(size_t)s];
+    B.ptr[(size_t)s] = pos;
+    for (int32_t k = A.ptr[(size_t)i]; k < A.ptr[(size_t)i + 1]; ++k, ++pos) {
+      B.col[(size_t)pos] = A.col[(size_t)k];
+      B.val[(size_t)pos] = A.val[(size_t)k];
+    }
+  }
+  B.ptr[(size_t)A.nrows] = pos;
+  return B;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one level + the whole hierarchy (host copy)
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct HostLevel {
+  int64_t m = 0, n = 0, F_ncols = 0;
+  Ccs<T> L, U, E, F;  // as imported
+  std::vector<T> d;
+  std::vector<double> s, t;
+  std::vector<int32_t> p, p_inv, q, q_inv;
+  // derived
+  Csr<T> Lr, Ur, Er, Fr;
+  Schedule Ls, Us;
+};
+
+// Dense last level: A P = Q R (GEQP3 semantics), numerical rank as QRCP::factorize decides it
+// (small_scale/QRCP.hpp:107-179).  For the device the factors are expanded once into two explicit
+// column-major operators so that the apply is two MFMA GEMMs plus a row scatter:
+//   QH   = Q^H                    (n x n)
+//   Rinv = R^{-1} upper triangle  (n x n; the leading rk x rk block is R(1:rk,1:rk)^{-1})
+template <class T>
+struct HostDense {
+  int64_t n = 0, rank = 0;
+  std::vector<T> qr, tau;      // GEQP3 layout
+  std::vector<int32_t> jpvt0;  // 0-based column permutation
+  std::vector<T> QH, Rinv;     // explicit operators, column-major
+};
+
+inline double abs_(double x) { return std::fabs(x); }
+inline double abs_(const zdouble &x) { return std::abs(x); }
+inline double conj_(double x) { return x; }
+inline zdouble conj_(const zdouble &x) { return std::conj(x); }
+inline double real_(double x) { return x; }
+inline double real_(const zdouble &x) { return x.real(); }
+
+template <class T>
+double col_norm(const T *x, int64_t n) {
+  double scale = 0.0, ssq = 1.0;
+  auto acc = [&](double a) {
+    a = std::fabs(a);
+    if (a == 0.0) return;
+    if (scale < a) {
+      const double r = scale / a;
+      ssq = 1.0 + ssq * r * r;
+      scale = a;
+    } else {
+      const double r = a / scale;
+      ssq += r * r;
+    }
+  };
+  for (int64_t i = 0; i < n; ++i) {
+    acc(real_(x[i]));
+    if (sizeof(T) == sizeof(zdouble)) acc(reinterpret_cast<const double *>(x + i)[1]);
+  }
+  return scale * std::sqrt(ssq);
+}
+
+// Householder QR with column pivoting (LAPACK ?geqp3 semantics: pivot on the largest remaining
+// partial column norm, norms downdated and recomputed on cancellation).
+template <class T>
+void qr_colpiv(int64_t n, std::vector<T> &A, std::vector<int32_t> &jpvt0, std::vector<T> &tau) {
+  std::vector<double> vn1((size_t)n), vn2((size_t)n);
+  jpvt0.resize((size_t)n);
+  tau.assign((size_t)n, T(0));
+  const double tol3z = std::sqrt(std::numeric_limits<double>::epsilon() * 0.5);
+  for (int64_t j = 0; j < n; ++j) {
+    jpvt0[(size_t)j] = (int32_t)j;
+    vn1[(size_t)j] = vn2[(size_t)j] = col_norm(&A[(size_t)(j * n)], n);
+  }
+  std::vector<T> w((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t pvt = i;
+    for (int64_t j = i + 1; j < n; ++j)
+      if (vn1[(size_t)j] > vn1[(size_t)pvt]) pvt = j;
+    if (pvt != i) {
+      std::swap_ranges(A.begin() + pvt * n, A.begin() + pvt * n + n, A.begin() + i * n);
+      std::swap(jpvt0[(size_t)pvt], jpvt0[(size_t)i]);
+      vn1[(size_t)pvt] = vn1[(size_t)i];
+      vn2[(size_t)pvt] = vn2[(size_t)i];
+    }
+    T *v = &A[(size_t)(i + i * n)];
+    const int64_t len = n - i;
+    // reflector: H = I - tau v v^H, v[0] = 1, H^H x = beta e1 with beta real
+    const double xnorm = col_norm(v + 1, len - 1);
+    const T alpha = v[0];
+    const double ar = real_(alpha), ai = sizeof(T) == sizeof(zdouble) ? reinterpret_cast<const double *>(&alpha)[1] : 0.0;
+    if (xnorm == 0.0 && ai == 0.0) {
+      tau[(size_t)i] = T(0);
+    } else {
+      double beta = std::sqrt(ar * ar + ai * ai + xnorm * xnorm);
+      if (ar >= 0.0) beta = -beta;
+      T tq;
+      if (sizeof(T) == sizeof(zdouble)) {
+        double *tp = reinterpret_cast<double *>(&tq);
+        tp[0] = (beta - ar) / beta;
+        tp[1] = -ai / beta;
+      } else
+        tq = T((beta - ar) / beta);
+      tau[(size_t)i] = tq;
+      const T sc = T(1.0) / (alpha - T(beta));
+      for (int64_t r = 1; r < len; ++r) v[r] *= sc;
+      v[0] = T(beta);
+    }
+    if (i + 1 < n && tau[(size_t)i] != T(0)) {
+      const T beta_keep = v[0];
+      v[0] = T(1);
+      const T ctau = conj_(tau[(size_t)i]);
+      for (int64_t j = i + 1; j < n; ++j) {
+        T *c = &A[(size_t)(i + j * n)];
+        T dot = T(0);
+        for (int64_t r = 0; r < len; ++r) dot += conj_(v[r]) * c[r];
+        dot *= ctau;
+        for (int64_t r = 0; r < len; ++r) c[r] -= v[r] * dot;
+      }
+      v[0] = beta_keep;
+    }
+    for (int64_t j = i + 1; j < n; ++j) {
+      if (vn1[(size_t)j] == 0.0) continue;
+      double temp = abs_(A[(size_t)(i + j * n)]) / vn1[(size_t)j];
+      temp = std::max(0.0, 1.0 - temp * temp);
+      const double r = vn1[(size_t)j] / vn2[(size_t)j];
+      if (temp * r * r <= tol3z) {
+        vn1[(size_t)j] = (i + 1 < n) ? col_norm(&A[(size_t)(i + 1 + j * n)], n - i - 1) : 0.0;
+        vn2[(size_t)j] = vn1[(size_t)j];
+      } else
+        vn1[(size_t)j] *= std::sqrt(temp);
+    }
+  }
+}
+
+// Incremental condition estimation step (LAPACK ?laic1), used only when the diagonal filter of
+// QRCP::factorize fires (QRCP.hpp:150-163 -> _est_rank_2norm :333-364).
+template <class T>
+void laic1(int job, int64_t j, const T *x, double sest, const T *w, T gamma, double &sestpr, T &s, T &c) {
+  const double eps = std::numeric_limits<double>::epsilon() * 0.5;
+  T alpha = T(0);
+  for (int64_t i = 0; i < j; ++i) alpha += conj_(x[i]) * w[i];
+  const double absalp = abs_(alpha), absgam = abs_(gamma), absest = std::fabs(sest);
+  auto nrm = [](const T &a, const T &b) { return std::sqrt(abs_(a) * abs_(a) + abs_(b) * abs_(b)); };
+  if (job == 1) {
+    if (sest == 0.0) {
+      const double s1 = std::max(absgam, absalp);
+      if (s1 == 0.0) {
+        s = T(0), c = T(1), sestpr = 0.0;
+      } else {
+        s = alpha / s1, c = gamma / s1;
+        const double tmp = nrm(s, c);
+        s /= tmp, c /= tmp, sestpr = s1 * tmp;
+      }
+    } else if (absgam <= eps * absest) {
+      s = T(1), c = T(0);
+      const double tmp = std::max(absest, absalp), s1 = absest / tmp, s2 = absalp / tmp;
+      sestpr = tmp * std::sqrt(s1 * s1 + s2 * s2);
+    } else if (absalp <= eps * absest) {
+      if (absgam <= absest)
+        s = T(1), c = T(0), sestpr = absest;
+      else
+        s = T(0), c = T(1), sestpr = absgam;
+    } else if (absest <= eps * absalp || absest <= eps * absgam) {
+      const double s1 = absgam, s2 = absalp;
+      if (s1 <= s2) {
+        const double tmp = s1 / s2, scl = std::sqrt(1.0 + tmp * tmp);
+        sestpr = s2 * scl, s = (alpha / s2) / scl, c = (gamma / s2) / scl;
+      } else {
+        const double tmp = s2 / s1, scl = std::sqrt(1.0 + tmp * tmp);
+        sestpr = s1 * scl, s = (alpha / s1) / scl, c = (gamma / s1) / scl;
+      }
+    } else {
+      const T z1 = alpha / absest, z2 = gamma / absest;
+      const double b = (1.0 - abs_(z1) * abs_(z1) - abs_(z2) * abs_(z2)) * 0.5, cc = abs_(z1) * abs_(z1);
+      const double t = b > 0.0 ? cc / (b + std::sqrt(b * b + cc)) : std::sqrt(b * b + cc) - b;
+      const T sine = -z1 / t, cosine = -z2 / (1.0 + t);
+      const double tmp = nrm(sine, cosine);
+      s = sine / tmp, c = cosine / tmp, sestpr = std::sqrt(t + 1.0) * absest;
+    }
+    return;
+  }
+  if (sest == 0.0) {
+    sestpr = 0.0;
+    T sine, cosine;
+    if (std::max(absgam, absalp) == 0.0)
+      sine = T(1), cosine = T(0);
+    else
+      sine = -conj_(gamma), cosine = conj_(alpha);
+    const double s1 = std::max(abs_(sine), abs_(cosine));
+    s = sine / s1, c = cosine / s1;
+    const double tmp = nrm(s, c);
+    s /= tmp, c /= tmp;
+  } else if (absgam <= eps * absest) {
+    s = T(0), c = T(1), sestpr = absgam;
+  } else if (absalp <= eps * absest) {
+    if (absgam <= absest)
+      s = T(0), c = T(1), sestpr = absgam;
+    else
+      s = T(1), c = T(0), sestpr = absest;
+  } else if (absest <= eps * absalp || absest <= eps * absgam) {
+    const double s1 = absgam, s2 = absalp;
+    if (s1 <= s2) {
+      const double tmp = s1 / s2, scl = std::sqrt(1.0 + tmp * tmp);
+      sestpr = absest * (tmp / scl), s = -(conj_(gamma) / s2) / scl, c = (conj_(alpha) / s2) / scl;
+    } else {
+      const double tmp = s2 / s1, scl = std::sqrt(1.0 + tmp * tmp);
+      sestpr = absest / scl, s = -(conj_(gamma) / s1) / scl, c = (conj_(alpha) / s1) / scl;
+    }
+  } else {
+    const T z1 = alpha / absest, z2 = gamma / absest;
+    const double a1 = abs_(z1), a2 = abs_(z2), a12 = abs_(conj_(z1) * z2);
+    const double norma = std::max(1.0 + a1 * a1 + a12, a12 + a2 * a2);
+    const double test = 1.0 + 2.0 * (a1 - a2) * (a1 + a2);
+    T sine, cosine;
+    if (test >= 0.0) {
+      const double b = (a1 * a1 + a2 * a2 + 1.0) * 0.5, cc = a2 * a2;
+      const double t = cc / (b + std::sqrt(std::fabs(b * b - cc)));
+      sine = z1 / (1.0 - t), cosine = -z2 / t;
+      sestpr = std::sqrt(t + 4.0 * eps * eps * norma) * absest;
+    } else {
+      const double b = (a2 * a2 + a1 * a1 - 1.0) * 0.5, cc = a1 * a1;
+      const double t = b >= 0.0 ? -cc / (b + std::sqrt(b * b + cc)) : b - std::sqrt(b * b + cc);
+      sine = -z1 / t, cosine = -z2 / (1.0 + t);
+      sestpr = std::sqrt(1.0 + t + 4.0 * eps * eps * norma) * absest;
+    }
+    const double tmp = nrm(sine, cosine);
+    s = sine / tmp, c = cosine / tmp;
+  }
+}
+
+template <class T>
+void dense_factorize(HostDense<T> &D, const T *mat_colmajor, int64_t n, double rrqr_cond) {
+  D.n = n;
+  D.qr.assign(mat_colmajor, mat_colmajor + n * n);
+  qr_colpiv(n, D.qr, D.jpvt0, D.tau);
+  const double eps = std::numeric_limits<double>::epsilon();
+  const double diag_tol = std::sqrt(eps), cond_tol = 1.0 / std::pow(eps, 2.0 / 3.0);
+  const double cond_thres = rrqr_cond <= 0.0 ? cond_tol : rrqr_cond;
+  const T *A = D.qr.data();
+  bool cond_test = false;
+  const double diag_eps = diag_tol * abs_(A[0]);
+  for (int64_t i = n; i != 0; --i)
+    if (abs_(A[(i - 1) + (i - 1) * n]) < diag_eps) {
+      cond_test = true;
+      break;
+    }
+  D.rank = n;
+  if (cond_test) {
+    std::vector<T> x((size_t)n, T(0)), y((size_t)n, T(0));
+    x[0] = y[0] = T(1);
+    double smax = abs_(A[0]), smin = smax, sminpr = 0, smaxpr = 0;
+    T s1, c1, s2, c2;
+    int64_t rk = 0;
+    for (; rk < n; ++rk) {
+      laic1(2, rk, x.data(), smin, A + rk * n, A[rk + rk * n], sminpr, s1, c1);
+      laic1(1, rk, y.data(), smax, A + rk * n, A[rk + rk * n], smaxpr, s2, c2);
+      if (!(smaxpr <= sminpr * cond_thres)) break;
+      for (int64_t i = 0; i < rk; ++i) x[(size_t)i] *= s1, y[(size_t)i] *= s2;
+      x[(size_t)rk] = c1, y[(size_t)rk] = c2;
+      smin = sminpr, smax = smaxpr;
+    }
+    D.rank = rk;
+  }
+  // explicit Q^H: start from I and apply H(0)^H, H(1)^H, ... to its columns (Q^H = H(n-1)^H...H(0)^H)
+  D.QH.assign((size_t)(n * n), T(0));
+  for (int64_t j = 0; j < n; ++j) D.QH[(size_t)(j + j * n)] = T(1);
+  for (int64_t i = 0; i < n; ++i) {
+    const T ctau = conj_(D.tau[(size_t)i]);
+    if (ctau == T(0)) continue;
+    const T *v = A + i + i * n;  // v[0] is implicit 1
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < n; ++j) {
+      T *c = &D.QH[(size_t)(i + j * n)];
+      T dot = c[0];
+      for (int64_t r = 1; r < n - i; ++r) dot += conj_(v[r]) * c[r];
+      dot *= ctau;
+      c[0] -= dot;
+      for (int64_t r = 1; r < n - i; ++r) c[r] -= v[r] * dot;
+    }
+  }
+  // explicit R^{-1} (upper triangular), column by column: R X = I  =>  back substitution
+  D.Rinv.assign((size_t)(n * n), T(0));
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int64_t j = 0; j < n; ++j) {
+    T *x = &D.Rinv[(size_t)(j * n)];
+    x[j] = T(1);
+    for (int64_t k = j; k >= 0; --k) {  // column-oriented sweep: contiguous reads of R(:,k)
+      const T rkk = A[k + k * n];
+      if (rkk == T(0)) {  // exactly singular pivot: such columns lie beyond any usable rank
+        for (int64_t i = 0; i <= j; ++i) x[i] = T(0);
+        break;
+      }
+      x[k] /= rkk;
+      const T xk = x[k];
+      const T *rk = A + k * n;
+      for (int64_t i = 0; i < k; ++i) x[i] -= rk[i] * xk;
+    }
+  }
+}
+
+template <class T>
+struct HostHierarchy {
+  std::vector<HostLevel<T>> levels;
+  bool has_dense = false;
+  HostDense<T> dense;
+  // the user's matrix for IR (0-based CRS after normalisation)
+  Csr<T> A;
+  bool has_A = false;
+};
+
+}  // namespace hifamd

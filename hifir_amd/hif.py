@@ -1,0 +1,252 @@
+"""class HIF -- Python mirror of hif::HIF<ValueType,int> (reference src/hif/builder.hpp:109) for the
+apply path, over the C ABI.  The names and argument meaning follow the reference:
+
+  reference                                   here
+  HIF::solve(b, x, trans=false, r=0)   :410   HIF.solve(b, rank=0) -> x
+  HIF::solve_mrhs<Nrhs>(b, x, r)       :434   HIF.solve_mrhs(B, rank=0) -> X      (B is [n][nrhs])
+  HIF::hifir(A, b, N, x, trans, r)     :459   HIF.hifir(b, N, rank=-1) -> x
+  HIF::hifir(A, b, N, betas, x, ...)   :482   HIF.hifir(b, N, betas=(lo, hi)) -> (x, iters, flag)
+  HIF::levels()/nnz()/rank()/schur_*   :141-190  same names
+
+numpy arrays use the host-pointer entry points; torch CUDA tensors (device memory is the only thing
+torch is used for) use the device-pointer entry points and are not synchronized.
+Errors follow the reference convention (status code + message, libhifir.cpp:34-53): a non-zero
+HifAmdStatus raises HifAmdError carrying the code and the library's message.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib
+
+STATUS = {0: "HIFAMD_SUCCESS", 1: "HIFAMD_NULL_OBJ", 2: "HIFAMD_MISMATCHED_SIZES", 3: "HIFAMD_BAD_PREC",
+          4: "HIFAMD_HIFIR_ERROR"}
+
+
+class HifAmdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def _check(code):
+    if code != 0:
+        m = lib().hifamd_last_error()
+        raise HifAmdError(code, m.decode() if m else "")
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class HIF:
+    """A multilevel preconditioner resident on one MI355X."""
+
+    def __init__(self, dtype=np.float64, device=-1):
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float64), np.dtype(np.complex128)):
+            raise HifAmdError(3, "only float64 and complex128 hierarchies are supported")
+        self._h = C.c_void_p()
+        _check(lib().hifamd_create(0 if self.dtype == np.float64 else 1, device, C.byref(self._h)))
+        self._A = None
+
+    # ---- construction --------------------------------------------------------------------------
+    @classmethod
+    def from_levels(cls, levels, max_nrhs=64, rrqr_cond=0.0, device=-1, dtype=None):
+        """levels: list of dicts with the fields of hif::Prec (alg/Prec.hpp:309-323), CCS matrices:
+        m, n, {L,U,E,F}_{colptr,rowind,vals}, d, s, t, p, q_inv (+ p_inv, q), and on the last one
+        optionally dense_n, dense (unfactored column-major Schur complement)."""
+        if dtype is None:
+            cplx = any(np.iscomplexobj(lv["L_vals"]) or np.iscomplexobj(lv["d"]) or np.iscomplexobj(lv["E_vals"])
+                       for lv in levels)
+            dtype = np.complex128 if cplx else np.float64
+        self = cls(dtype, device)
+        for lv in levels:
+            self.add_level(lv)
+        last = levels[-1]
+        if int(last.get("dense_n", 0)) > 0:
+            self.set_dense(last["dense"], rrqr_cond)
+        self.finalize(max_nrhs)
+        return self
+
+    def add_level(self, lv):
+        dt = self.dtype
+        m, n = int(lv["m"]), int(lv["n"])
+        mats = []
+        for k in "LUEF":
+            mats += [np.ascontiguousarray(lv[k + "_colptr"], dtype=np.int64),
+                     np.ascontiguousarray(lv[k + "_rowind"], dtype=np.int32),
+                     np.ascontiguousarray(lv[k + "_vals"], dtype=dt)]
+        f_ncols = len(mats[9]) - 1 if (n - m) else 0
+        if f_ncols and mats[9][-1] == 0 and len(mats[9]) - 1 != n - m:
+            f_ncols = 0
+        d = np.ascontiguousarray(lv["d"], dtype=dt)
+        s = np.ascontiguousarray(lv["s"], dtype=np.float64)
+        t = np.ascontiguousarray(lv["t"], dtype=np.float64)
+        perms = [None if lv.get(k) is None else np.ascontiguousarray(lv[k], dtype=np.int32)
+                 for k in ("p", "p_inv", "q", "q_inv")]
+        _check(lib().hifamd_add_level(self._h, m, n, *[_p(a) for a in mats[:9]], f_ncols, *[_p(a) for a in mats[9:]],
+                                      _p(d), _p(s), _p(t), *[_p(a) for a in perms]))
+
+    def set_dense(self, mat_colmajor, rrqr_cond=0.0):
+        mat = np.ascontiguousarray(mat_colmajor, dtype=self.dtype).ravel()
+        nd = int(round(np.sqrt(mat.size)))
+        _check(lib().hifamd_set_dense(self._h, nd, _p(mat), float(rrqr_cond)))
+
+    def finalize(self, max_nrhs=64):
+        _check(lib().hifamd_finalize(self._h, int(max_nrhs)))
+
+    def set_matrix(self, indptr, indices, vals):
+        """Attach the user's CRS matrix for iterative refinement (what lhf?Setup keeps, libhifir.cpp:413)."""
+        ip = np.ascontiguousarray(indptr, dtype=np.int64)
+        ix = np.ascontiguousarray(indices, dtype=np.int32)
+        v = np.ascontiguousarray(vals, dtype=self.dtype)
+        _check(lib().hifamd_set_matrix(self._h, len(ip) - 1, _p(ip), _p(ix), _p(v)))
+        self._A = True
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().hifamd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- queries (builder.hpp:141-190) ------------------------------------------------------------
+    def nrows(self):
+        return lib().hifamd_nrows(self._h)
+
+    ncols = nrows
+
+    def levels(self):
+        return lib().hifamd_levels(self._h)
+
+    def nnz(self):
+        return lib().hifamd_nnz(self._h)
+
+    def schur_size(self):
+        return lib().hifamd_schur_size(self._h)
+
+    def schur_rank(self):
+        return lib().hifamd_schur_rank(self._h)
+
+    def rank(self):
+        return self.nrows() - (self.schur_size() - self.schur_rank()) if self.schur_size() else self.nrows()
+
+    def stats(self):
+        s = np.zeros(16)
+        _check(lib().hifamd_stats(self._h, _p(s)))
+        keys = ["sum_n", "sum_m", "nnz_LU", "nnz_EF", "dense_n", "B_mat", "B_vec", "wavefronts_L", "wavefronts_U",
+                "launches", "sparse_levels"]
+        return {k: float(s[i]) for i, k in enumerate(keys)}
+
+    def algorithmic_bytes(self, nrhs):
+        """B_alg(nrhs) = B_mat + nrhs * B_vec of SURVEY 8(d), for the hierarchy actually resident."""
+        st = self.stats()
+        return st["B_mat"] + nrhs * st["B_vec"]
+
+    def level_schedule(self, level, which):
+        """(order, wf_ptr) of the L (which=0) or U (which=1) factor of a level."""
+        nwf = C.c_int64()
+        _check(lib().hifamd_level_schedule(self._h, level, which, C.byref(nwf), None, None))
+        stt = np.zeros(16)
+        lib().hifamd_stats(self._h, _p(stt))
+        # m is not exported separately: take it from wf_ptr's last entry
+        wf = np.zeros(nwf.value + 1, dtype=np.int64)
+        _check(lib().hifamd_level_schedule(self._h, level, which, None, None, _p(wf)))
+        order = np.zeros(int(wf[-1]), dtype=np.int32)
+        _check(lib().hifamd_level_schedule(self._h, level, which, None, _p(order), None))
+        return order, wf
+
+    # ---- apply -----------------------------------------------------------------------------------
+    def solve(self, b, x=None, trans=False, rank=0):
+        """x = M^{-1} b  (HIF::solve, builder.hpp:409-423)."""
+        if trans:
+            raise HifAmdError(3, "transpose solve (LHF_SH) is not part of the GPU path yet")
+        if _is_torch(b):
+            return self.solve_mrhs(b.reshape(-1, 1), None if x is None else x.reshape(-1, 1), rank).reshape(-1)
+        b = np.ascontiguousarray(b, dtype=self.dtype)
+        if b.ndim != 1 or b.shape[0] != self.nrows():
+            raise HifAmdError(2, "unmatched sizes")
+        if x is None:
+            x = np.empty_like(b)
+        _check(lib().hifamd_solve(self._h, _p(b), _p(x), int(rank)))
+        return x
+
+    def solve_mrhs(self, B, X=None, rank=0, stream=None):
+        """X = M^{-1} B for an [n][nrhs] row-interleaved block (the layout of
+        Array<std::array<T,Nrhs>>, CompressedStorage.hpp:2127); nrhs is a run-time value here."""
+        if _is_torch(B):
+            import torch
+
+            if X is None:
+                X = torch.empty_like(B)
+            if B.dim() != 2 or B.shape[0] != self.nrows() or X.shape != B.shape:
+                raise HifAmdError(2, "unmatched sizes")
+            if B.stride(1) != 1 or X.stride(1) != 1:
+                raise HifAmdError(2, "blocks must be row-interleaved (unit column stride)")
+            _check(lib().hifamd_solve_batch_dev(self._h, B.data_ptr(), B.stride(0), X.data_ptr(), X.stride(0),
+                                               B.shape[1], int(rank), stream))
+            return X
+        B = np.ascontiguousarray(B, dtype=self.dtype)
+        if B.ndim != 2 or B.shape[0] != self.nrows():
+            raise HifAmdError(2, "unmatched sizes")
+        if X is None:
+            X = np.empty_like(B)
+        _check(lib().hifamd_solve_batch(self._h, _p(B), B.shape[1], _p(X), X.shape[1], B.shape[1], int(rank)))
+        return X
+
+    def spmv(self, X, Y=None, stream=None):
+        """Y = A X on the device (torch CUDA tensors, [n][nrhs] or [n])."""
+        import torch
+
+        X2 = X.reshape(X.shape[0], -1)
+        if Y is None:
+            Y = torch.empty_like(X)
+        Y2 = Y.reshape(Y.shape[0], -1)
+        _check(lib().hifamd_spmv_batch_dev(self._h, X2.data_ptr(), X2.stride(0), Y2.data_ptr(), Y2.stride(0),
+                                          X2.shape[1], stream))
+        return Y
+
+    def hifir(self, b, N, betas=None, rank=-1):
+        """Iterative refinement (HIF::hifir, builder.hpp:459-489).  b: [n] or [n][nrhs].
+        Without betas returns x; with betas returns (x, iters, flags) per column (ints for a vector)."""
+        vec = (b.ndim == 1)
+        bt = None if betas is None else np.ascontiguousarray(betas, dtype=np.float64)
+        if _is_torch(b):
+            import torch
+
+            B = b.reshape(b.shape[0], -1)
+            X = torch.empty_like(B)
+            st = np.zeros(2 * B.shape[1], dtype=np.int32)
+            _check(lib().hifamd_hifir_batch_dev(self._h, B.data_ptr(), B.stride(0), X.data_ptr(), X.stride(0),
+                                               B.shape[1], int(N), _p(bt), int(rank), _p(st)))
+        else:
+            B = np.ascontiguousarray(b, dtype=self.dtype).reshape(b.shape[0], -1)
+            X = np.empty_like(B)
+            st = np.zeros(2 * B.shape[1], dtype=np.int32)
+            _check(lib().hifamd_hifir_batch(self._h, _p(B), B.shape[1], _p(X), X.shape[1], B.shape[1], int(N), _p(bt),
+                                           int(rank), _p(st)))
+        x = X.reshape(-1) if vec else X
+        if betas is None:
+            return x
+        it, fl = st[0::2].copy(), st[1::2].copy()
+        return (x, int(it[0]), int(fl[0])) if vec else (x, it, fl)
+
+    def time_apply(self, B, X, rank=0, warmup=2, reps=10):
+        """Average device milliseconds of one batched apply, HIP events on the handle's stream."""
+        ms = C.c_double()
+        _check(lib().hifamd_time_apply(self._h, B.data_ptr(), B.stride(0), X.data_ptr(), X.stride(0), B.shape[1],
+                                      int(rank), int(warmup), int(reps), C.byref(ms)))
+        return ms.value
+
+    def sync(self):
+        _check(lib().hifamd_sync(self._h))

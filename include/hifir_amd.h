@@ -1,0 +1,144 @@
+/* hifir_amd.h -- C ABI of the MI355X-native HIFIR preconditioner-apply path.
+ *
+ * Plain C, plain pointers and sizes, no C++/torch types.  This is the drop-in boundary for the
+ * reference's hot path: the reference keeps factorizing on the host, hands each level of its
+ * hif::Precs list to this library once (hifamd_add_level / hifamd_set_dense, the field set of
+ * hif::Prec::export_sparse_data + inquire_or_export_dense), and from then on every
+ * HIF::solve / HIF::hifir / lhf?Solve / lhf?Apply(LHF_S) call is served from HBM by hand-written
+ * gfx950 kernels.  INTEGRATION.md shows the reference-side binding.
+ *
+ * All file:line citations are relative to the reference tree (HIFIR v0.2.0).
+ *
+ * Conventions
+ *   - every function returns a HifAmdStatus (values mirror LhfStatus, libhifir/include/libhifir.h:148-154);
+ *     the message of the last failure on the calling thread is returned by hifamd_last_error()
+ *     (cf. lhfGetErrorMsg, libhifir.h:255).
+ *   - value type: double (HIFAMD_D) or double complex (HIFAMD_Z, C99 layout == std::complex<double>);
+ *     index type int32 (LhfInt), pointer type int64 (LhfIndPtr = ptrdiff_t), libhifir.h:47-83.
+ *   - a handle is NOT thread-safe (same rule as the reference: HIF::solve mutates `mutable _prec_work`,
+ *     src/hif/builder.hpp:579); distinct handles may be used from distinct threads.
+ *   - multi-RHS blocks are row-interleaved [n][nrhs] with an explicit row stride (ld, in elements),
+ *     i.e. the layout of hif::Array<std::array<T,Nrhs>> (src/hif/ds/CompressedStorage.hpp:2127).
+ *   - there is no CPU fallback: without a usable HIP device every compute entry point fails with
+ *     HIFAMD_HIFIR_ERROR.
+ */
+#ifndef HIFIR_AMD_H
+#define HIFIR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum HifAmdStatus {
+  HIFAMD_SUCCESS = 0,      /* LHF_SUCCESS */
+  HIFAMD_NULL_OBJ,         /* LHF_NULL_OBJ */
+  HIFAMD_MISMATCHED_SIZES, /* LHF_MISMATCHED_SIZES */
+  HIFAMD_BAD_PREC,         /* LHF_BAD_PREC */
+  HIFAMD_HIFIR_ERROR       /* LHF_HIFIR_ERROR */
+} HifAmdStatus;
+
+typedef enum HifAmdValueType { HIFAMD_D = 0, HIFAMD_Z = 1 } HifAmdValueType;
+
+typedef struct HifAmdPrec *HifAmdHdl; /* opaque: one multilevel preconditioner resident in HBM */
+
+/* ---- library ------------------------------------------------------------------------------ */
+const char *hifamd_version(void);
+/* message of the last error on this thread, or NULL; cleared by the call (libhifir.cpp:224-229) */
+const char *hifamd_last_error(void);
+/* number of visible HIP devices (0 without a GPU; never fails) */
+int hifamd_device_count(void);
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+/* replaces `new HIF<>` in lhf?Create (libhifir.cpp:383-396); device = HIP ordinal, -1 = current */
+HifAmdStatus hifamd_create(HifAmdValueType vt, int device, HifAmdHdl *out);
+HifAmdStatus hifamd_destroy(HifAmdHdl h); /* NULL-safe, frees HBM (cf. lhf?Destroy, libhifir.h:619) */
+
+/* ---- hierarchy import (host pointers; data is copied) ------------------------------------- */
+/* One call per hif::Prec, in list order (src/hif/alg/Prec.hpp:309-323).  The four matrices are
+ * CCS exactly as the reference stores them (Prec::mat_type = ccs_type, Prec.hpp:86,90):
+ *   L_B, U_B : m x m strict triangles, implicit unit diagonal, sorted row indices
+ *   E        : (n-m) x m,   F : m x F_ncols (F_ncols == n-m, or 0 when absent; prec_solve.hpp:395)
+ * d: m values; s,t: n REAL scalings (Prec.hpp:96-99); p, q_inv: n 0-based permutations.
+ * p_inv and q are only needed by the transpose / product operators and may be NULL. */
+HifAmdStatus hifamd_add_level(HifAmdHdl h, int64_t m, int64_t n,
+                              const int64_t *L_colptr, const int32_t *L_rowind, const void *L_vals,
+                              const int64_t *U_colptr, const int32_t *U_rowind, const void *U_vals,
+                              const int64_t *E_colptr, const int32_t *E_rowind, const void *E_vals,
+                              int64_t F_ncols,
+                              const int64_t *F_colptr, const int32_t *F_rowind, const void *F_vals,
+                              const void *d, const double *s, const double *t,
+                              const int32_t *p, const int32_t *p_inv,
+                              const int32_t *q, const int32_t *q_inv);
+/* The UNFACTORED column-major nd x nd Schur complement of the last level, as
+ * Prec::inquire_or_export_dense hands it out (Prec.hpp:275-293).  Factorized here on the host by
+ * QR with column pivoting + rank determination (QRCP::factorize, small_scale/QRCP.hpp:107-179);
+ * rrqr_cond <= 0 selects the reference default eps^(-2/3) (QRCP.hpp:110-117). */
+HifAmdStatus hifamd_set_dense(HifAmdHdl h, int64_t nd, const void *mat_colmajor, double rrqr_cond);
+/* Converts CCS -> schedule-ordered CSR, level-schedules the triangular factors, ships everything to
+ * HBM and sizes the work arena for batches of up to max_nrhs (the reference sizes its work buffer
+ * on first use only, builder.hpp:414-416 -- not replicated). */
+HifAmdStatus hifamd_finalize(HifAmdHdl h, int64_t max_nrhs);
+
+/* ---- queries (cf. lhf?GetLevels/GetNnz/GetSchurSize/GetSchurRank, libhifir.h:722-740) ------ */
+int64_t hifamd_nrows(HifAmdHdl h);
+int64_t hifamd_levels(HifAmdHdl h);     /* counts the dense block as a level (builder.hpp:141-147) */
+int64_t hifamd_nnz(HifAmdHdl h);        /* Prec::nnz summed (Prec.hpp:170-176) */
+int64_t hifamd_schur_size(HifAmdHdl h);
+int64_t hifamd_schur_rank(HifAmdHdl h);
+/* stats[0..15]: 0 sum n_l, 1 sum m_l, 2 nnz(L)+nnz(U), 3 nnz(E)+nnz(F), 4 dense n, 5 B_mat bytes,
+ * 6 B_vec bytes per RHS (SURVEY 8d formula), 7 #wavefronts L (all levels), 8 #wavefronts U,
+ * 9 kernel launches per apply at the last captured batch width, 10 sparse levels, 11..15 reserved */
+HifAmdStatus hifamd_stats(HifAmdHdl h, double *stats16);
+/* level schedule of one triangular factor (host-side analysis; usable without a GPU):
+ * which = 0 (L_B) / 1 (U_B).  *nwf = number of wavefronts; if order != NULL it receives the m row
+ * ids in processing order and wf_ptr (nwf+1 entries) the wavefront boundaries into it. */
+HifAmdStatus hifamd_level_schedule(HifAmdHdl h, int level, int which, int64_t *nwf,
+                                   int32_t *order, int64_t *wf_ptr);
+
+/* ---- apply: x = M^{-1} b ------------------------------------------------------------------ */
+/* rank: 0 = numerical rank of the dense level, <0 or > size = full (QRCP.hpp:376-377) */
+/* HIF::solve (builder.hpp:409-423) / lhf?Solve (libhifir.h:698): host pointers, one RHS */
+HifAmdStatus hifamd_solve(HifAmdHdl h, const void *b, void *x, int64_t rank);
+/* batched, HOST pointers: B, X are [n][nrhs] row-interleaved with row strides ldb, ldx */
+HifAmdStatus hifamd_solve_batch(HifAmdHdl h, const void *B, int64_t ldb, void *X, int64_t ldx,
+                                int64_t nrhs, int64_t rank);
+/* batched, DEVICE pointers on the handle's device; enqueued on `stream` (a hipStream_t, NULL = the
+ * handle's own stream) and NOT synchronized.  B and X must not alias (libhifir Ownership note). */
+HifAmdStatus hifamd_solve_batch_dev(HifAmdHdl h, const void *dB, int64_t ldb, void *dX, int64_t ldx,
+                                    int64_t nrhs, int64_t rank, void *stream);
+
+/* ---- outer matrix, SpMV and iterative refinement ------------------------------------------ */
+/* user matrix A in CRS (copied to HBM): what lhf?Setup borrows for IR (libhifir.cpp:413);
+ * 0- or 1-based like the reference (builder.hpp:311-329) */
+HifAmdStatus hifamd_set_matrix(HifAmdHdl h, int64_t n, const int64_t *indptr, const int32_t *indices,
+                               const void *vals);
+/* Y = A X, row dot-products in CRS order (CRS::multiply_nt_low, CompressedStorage.hpp:1109-1127;
+ * mt::multiply_nt, utils/mt_mv.hpp:58-73); device pointers, [n][nrhs] */
+HifAmdStatus hifamd_spmv_batch_dev(HifAmdHdl h, const void *dX, int64_t ldx, void *dY, int64_t ldy,
+                                   int64_t nrhs, void *stream);
+/* HIF::hifir (builder.hpp:459-489, alg/IterRefine.hpp:77-165) for nrhs columns at once; host
+ * pointers.  betas == NULL: fixed nirs sweeps.  betas = {lower, upper}: per-column relative
+ * residual test; ir_status (2*nrhs ints, may be NULL) gets {iterations, flag} per column with
+ * flag 0 converged / 1 diverged / -1 reached nirs (IterRefine.hpp:119-120). */
+HifAmdStatus hifamd_hifir_batch(HifAmdHdl h, const void *B, int64_t ldb, void *X, int64_t ldx,
+                                int64_t nrhs, int nirs, const double *betas, int64_t rank,
+                                int *ir_status);
+/* same with device pointers for B and X (ir_status stays a host array) */
+HifAmdStatus hifamd_hifir_batch_dev(HifAmdHdl h, const void *dB, int64_t ldb, void *dX, int64_t ldx,
+                                    int64_t nrhs, int nirs, const double *betas, int64_t rank,
+                                    int *ir_status);
+
+/* ---- instrumentation ---------------------------------------------------------------------- */
+/* Average device time (ms) of the last `hifamd_solve_batch_dev`-shaped graph over `reps` replays,
+ * measured with HIP events on the handle's stream (the stream the kernels run on). */
+HifAmdStatus hifamd_time_apply(HifAmdHdl h, const void *dB, int64_t ldb, void *dX, int64_t ldx,
+                               int64_t nrhs, int64_t rank, int warmup, int reps, double *ms_avg);
+HifAmdStatus hifamd_sync(HifAmdHdl h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIFIR_AMD_H */

@@ -1,0 +1,135 @@
+"""GPU (-m gpu): the HIP apply path, called through the C ABI, against the oracle (oracle/liborc.so,
+the C restatement pinned to the real reference) and against the committed golden vectors.
+
+Bars: sparse stages bit-exact (real, no dense level); dense level and complex within 1e-12
+(relative, infinity norm) -- BASELINE.json north_star "residual within 1e-12 of CPU reference"."""
+import numpy as np
+import pytest
+
+import hifir_amd
+from oracle import orc
+from util import HIER_NAMES, load_hier, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def cache():
+    return {}
+
+
+def _get(cache, name):
+    if name not in cache:
+        levels, d = load_hier(name)
+        M = hifir_amd.HIF.from_levels(levels, max_nrhs=64)
+        M.set_matrix(d["A_indptr"], d["A_indices"], d["A_vals"])
+        cache[name] = (levels, d, M, orc.Oracle(levels))
+    return cache[name]
+
+
+def _exact(levels, d):
+    return int(levels[-1].get("dense_n", 0)) == 0 and not np.iscomplexobj(d["b"])
+
+
+@pytest.mark.parametrize("name", HIER_NAMES)
+def test_solve_single_rhs(cache, name):
+    levels, d, M, O = _get(cache, name)
+    assert M.levels() == len(levels) + (1 if levels[-1].get("dense_n", 0) else 0)
+    x = M.solve(d["b"])
+    xo = O.solve(d["b"])
+    if _exact(levels, d):
+        assert np.array_equal(x, xo), f"sparse-only hierarchy must be bit-identical, relerr={relerr(x, xo):.3e}"
+    assert relerr(x, xo) <= TOL
+    assert relerr(x, d["x"]) <= TOL  # the real reference's HIF::solve output
+
+
+@pytest.mark.parametrize("name", HIER_NAMES)
+@pytest.mark.parametrize("nrhs", [1, 2, 3, 8, 17, 64, 100])
+def test_solve_batch(cache, name, nrhs):
+    levels, d, M, O = _get(cache, name)
+    n = len(d["b"])
+    rng = np.random.default_rng(nrhs)
+    B = rng.uniform(-1, 1, size=(n, nrhs)).astype(d["b"].dtype)
+    if np.iscomplexobj(B):
+        B = B + 1j * rng.uniform(-1, 1, size=(n, nrhs))
+    B[:, 0] = d["b"]
+    X = M.solve_mrhs(B)
+    Xo = O.solve_batch(B, threads=4)
+    if _exact(levels, d):
+        assert np.array_equal(X, Xo), f"relerr={relerr(X, Xo):.3e}"
+    assert relerr(X, Xo) <= TOL
+    assert relerr(X[:, 0], d["x"]) <= TOL
+
+
+@pytest.mark.parametrize("name", ["p2d_100_tuned", "p2d_64_deep", "young1c"])
+def test_device_pointer_api_and_strides(cache, name):
+    torch = pytest.importorskip("torch")
+    levels, d, M, O = _get(cache, name)
+    n = len(d["b"])
+    nrhs, ld = 5, 9  # padded row stride: B and X are views into wider blocks
+    rng = np.random.default_rng(3)
+    Bh = rng.uniform(-1, 1, size=(n, nrhs)).astype(d["b"].dtype)
+    Bw = torch.zeros((n, ld), dtype=torch.from_numpy(Bh).dtype, device="cuda")
+    Bw[:, :nrhs] = torch.from_numpy(Bh).cuda()
+    Xw = torch.full((n, ld), 7.0, dtype=Bw.dtype, device="cuda")
+    M.solve_mrhs(Bw[:, :nrhs], Xw[:, :nrhs])
+    M.sync()
+    Xh = Xw.cpu().numpy()
+    assert np.all(Xh[:, nrhs:] == 7.0), "columns beyond nrhs must not be touched"
+    assert relerr(Xh[:, :nrhs], O.solve_batch(Bh)) <= TOL
+    # replays of the cached graph give identical bits
+    X2 = torch.empty_like(Xw)
+    M.solve_mrhs(Bw[:, :nrhs], X2[:, :nrhs])
+    M.solve_mrhs(Bw[:, :nrhs], X2[:, :nrhs])
+    M.sync()
+    assert torch.equal(X2[:, :nrhs], Xw[:, :nrhs])
+
+
+@pytest.mark.parametrize("name", HIER_NAMES)
+def test_iterative_refinement(cache, name):
+    levels, d, M, O = _get(cache, name)
+    x4 = M.hifir(d["b"], 4)
+    assert relerr(x4, d["x_ir4"]) <= 1e-11
+    xb, it, fl = M.hifir(d["b"], 16, betas=(1e-10, 1e3))
+    assert (it, fl) == tuple(int(v) for v in d["irb_status"])
+    assert relerr(xb, d["x_irb"]) <= 1e-11
+    # batched IR: every column behaves like its own call
+    B = d["B4"]
+    X, its, fls = M.hifir(B, 16, betas=(1e-10, 1e3))
+    for k in range(B.shape[1]):
+        xo, (ito, flo) = O.hifir(d["A_indptr"], d["A_indices"], d["A_vals"], B[:, k].copy(), 16, [1e-10, 1e3])
+        assert (int(its[k]), int(fls[k])) == (ito, flo)
+        assert relerr(X[:, k], xo) <= 1e-11
+
+
+def test_spmv_bitwise(cache):
+    torch = pytest.importorskip("torch")
+    levels, d, M, O = _get(cache, "cd2d_48")
+    n = len(d["b"])
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-1, 1, size=(n, 6))
+    Y = M.spmv(torch.from_numpy(X).cuda()).cpu().numpy()
+    for k in range(6):
+        assert np.array_equal(Y[:, k], orc.crs_mv(d["A_indptr"], d["A_indices"], d["A_vals"], X[:, k].copy()))
+
+
+def test_rank_argument(cache):
+    levels, d, M, O = _get(cache, "p2d_30")
+    for rank in (0, -1, 100, 215, 10 ** 6):
+        assert relerr(M.solve(d["b"], rank=rank), O.solve(d["b"], rank=rank)) <= TOL
+
+
+def test_error_paths(cache):
+    levels, d, M, O = _get(cache, "p2d_5")
+    with pytest.raises(hifir_amd.HifAmdError) as e:
+        M.solve(np.zeros(7))
+    assert e.value.code == 2
+    with pytest.raises(hifir_amd.HifAmdError):
+        M.solve(d["b"], trans=True)
+    import ctypes as C
+    b = np.ascontiguousarray(d["b"])
+    rc = hifir_amd.lib().hifamd_solve(M._h, b.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), 0)
+    assert rc == 3  # aliasing b and x is refused (libhifir Ownership: b and x must not alias)
+    assert b"alias" in hifir_amd.lib().hifamd_last_error()
