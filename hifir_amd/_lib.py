@@ -57,6 +57,15 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `make -C hifir_amd/csrc` "
                 "(or __graft_entry__.build()); hifir_amd has no Python/CPU fallback")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as
+        # /opt/rocm's).  If torch is going to be used for device memory / torch.distributed it must
+        # be loaded FIRST so that this library binds to the same runtime; loading ours first and
+        # torch later leaves torch with "No HIP GPUs are available".
+        if os.environ.get("HIFIR_AMD_NO_TORCH", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
