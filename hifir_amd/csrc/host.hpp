@@ -125,6 +125,52 @@ Schedule level_schedule(const Csr<T> &A, bool lower) {
   return S;
 }
 
+// Thin runs: maximal groups of >= 2 consecutive wavefronts that are each at most thin_rows wide
+// (and together at most max_rows rows: one LDS flag per row).  For every row of a run, split[slot]
+// is the position of its first nonzero whose source row belongs to the run; all earlier nonzeros
+// refer to rows finished before the run starts.  Outside runs split[slot] = end of the row.
+struct RunPlan {
+  std::vector<int32_t> wf0, wf1;   // runs as wavefront ranges [wf0, wf1)
+  std::vector<int32_t> split;      // per slot
+  std::vector<int32_t> srcslot;    // per nonzero (slot order): slot of the source row
+};
+
+template <class T>
+RunPlan plan_runs(const Csr<T> &A /* rows in slot order */, const Schedule &S, int64_t thin_rows, int64_t max_rows) {
+  RunPlan P;
+  const int64_t m = A.nrows;
+  std::vector<int32_t> slot_of((size_t)m);
+  for (int64_t s = 0; s < m; ++s) slot_of[(size_t)A.rowid[(size_t)s]] = (int32_t)s;
+  P.srcslot.resize(A.col.size());
+  for (size_t k = 0; k < A.col.size(); ++k) P.srcslot[k] = slot_of[(size_t)A.col[k]];
+  P.split.resize((size_t)m);
+  for (int64_t s = 0; s < m; ++s) P.split[(size_t)s] = A.ptr[(size_t)s + 1];
+  const int64_t nwf = S.nwf();
+  int64_t k = 0;
+  while (k < nwf) {
+    if (S.wf_ptr[(size_t)k + 1] - S.wf_ptr[(size_t)k] > thin_rows) {
+      ++k;
+      continue;
+    }
+    int64_t k2 = k + 1;
+    while (k2 < nwf && S.wf_ptr[(size_t)k2 + 1] - S.wf_ptr[(size_t)k2] <= thin_rows &&
+           S.wf_ptr[(size_t)k2 + 1] - S.wf_ptr[(size_t)k] <= max_rows)
+      ++k2;
+    if (k2 - k >= 2) {
+      P.wf0.push_back((int32_t)k);
+      P.wf1.push_back((int32_t)k2);
+      const int32_t s0 = (int32_t)S.wf_ptr[(size_t)k];
+      for (int64_t s = s0; s < S.wf_ptr[(size_t)k2]; ++s) {
+        int32_t kk = A.ptr[(size_t)s];
+        while (kk < A.ptr[(size_t)s + 1] && P.srcslot[(size_t)kk] < s0) ++kk;
+        P.split[(size_t)s] = kk;
+      }
+    }
+    k = k2;
+  }
+  return P;
+}
+
 // Physically permute the CSR rows into slot order so that the matrix streams through HBM in the
 // order the kernels consume it (coalesced index/value reads for every batch width).
 template <class T>
@@ -162,6 +208,7 @@ struct HostLevel {
   // derived
   Csr<T> Lr, Ur, Er, Fr;
   Schedule Ls, Us;
+  RunPlan Lp, Up;
 };
 
 // Dense last level: A P = Q R (GEQP3 semantics), numerical rank as QRCP::factorize decides it

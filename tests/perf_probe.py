@@ -1,0 +1,54 @@
+"""Development probe (tests-side, may use the compiled reference in oracle/_ref): factorizes a 2-D
+Poisson matrix with the REAL reference on the host, imports the hierarchy into the HIP path, checks
+parity and times the batched apply.  Usage: python tests/perf_probe.py NX default|tuned NRHS [reps]"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __file__.rsplit("/tests/", 1)[0])
+sys.path.insert(0, __file__.rsplit("/", 1)[0])
+import torch  # noqa: E402
+
+import hifir_amd  # noqa: E402
+from oracle import orc, ref  # noqa: E402
+from util import poisson2d, relerr  # noqa: E402
+
+nx = int(sys.argv[1])
+mode = sys.argv[2]
+nrhs = int(sys.argv[3])
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+A = poisson2d(nx)
+n = A.shape[0]
+P = None if mode == "default" else ref.make_params(tau=1e-2, kappa=5.0, alpha=3.0)
+t0 = time.time()
+R = ref.RefHIF(A.indptr, A.indices, A.data, P)
+t1 = time.time()
+levels = R.levels()
+print(f"reference factorize {t1 - t0:.1f}s levels={R.nlevels} nnz={R.nnz}", flush=True)
+t0 = time.time()
+M = hifir_amd.HIF.from_levels(levels, max_nrhs=min(nrhs, 64))
+print(f"import+upload {time.time() - t0:.1f}s stats={M.stats()}", flush=True)
+rng = np.random.default_rng(20260101)
+B = rng.uniform(-1, 1, size=(n, nrhs))
+B[:, 0] = np.sin(0.001 * np.arange(n)) + 1
+Bd = torch.from_numpy(B).cuda()
+Xd = torch.empty_like(Bd)
+t0 = time.time()
+M.solve_mrhs(Bd, Xd)
+M.sync()
+print(f"first apply (graph capture) {time.time() - t0:.2f}s launches={M.stats()['launches']}", flush=True)
+X = Xd.cpu().numpy()
+t0 = time.time()
+x0 = R.solve(B[:, 0].copy())
+tref = time.time() - t0
+print(f"reference solve 1 rhs: {tref * 1e3:.1f} ms; GPU col0 relerr vs reference {relerr(X[:, 0], x0):.3e}", flush=True)
+O = orc.Oracle(levels)
+t0 = time.time()
+xo = O.solve(B[:, nrhs - 1].copy())
+print(f"oracle solve 1 rhs: {(time.time() - t0) * 1e3:.1f} ms; GPU last col relerr vs oracle {relerr(X[:, nrhs - 1], xo):.3e} "
+      f"bit-exact={np.array_equal(X[:, nrhs - 1], xo)}", flush=True)
+ms = M.time_apply(Bd, Xd, warmup=2, reps=reps)
+balg = M.algorithmic_bytes(nrhs)
+print(f"RESULT nx={nx} mode={mode} nrhs={nrhs}: {ms:.3f} ms/batch  {nrhs / ms * 1e3:.0f} RHS-applies/s  "
+      f"B_alg={balg / 1e9:.3f} GB  {balg / ms / 1e6:.1f} GB/s  frac_of_8TB/s={balg / ms / 1e6 / 8000:.4f}", flush=True)
