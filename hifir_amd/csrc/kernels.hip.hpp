@@ -264,40 +264,46 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
         e_nn = HIFAMD_KEND(s_nn);
       }
     }
-    // ---- consume the current item, eight nonzeros per batch
-    for (int32_t t = 0; t < cnt; t += 8) {
-      const int nb = min(8, cnt - t);
-      int32_t j[8], ss[8];
-      T a[8], xv[8];
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const int idx = min(t + b, 63);
-        j[b] = rl32(colv, idx);
-        a[b] = rlv(valv, idx);
-        ss[b] = (MODE == 2) ? rl32(ssv, idx) : -1;
-      }
+    // ---- consume the current item in order.  MODE 2: the item's source slots sit one per lane, so
+    // ONE LDS instruction polls the flags of all its in-run dependencies; the ready prefix of the
+    // item is consumed (eight gathers per batch) and only then is the rest polled again.
+    int32_t t = 0;
+    unsigned spins = 0;
+    while (t < cnt) {
+      int32_t lim = cnt;
       if (MODE == 2) {
-        unsigned spins = 0;
-        for (;;) {
-          bool ok = true;
-#pragma unroll
-          for (int b = 0; b < 8; ++b)
-            if (b < nb && ss[b] >= slot0)
-              ok = ok && (__hip_atomic_load(&flag[ss[b] - slot0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0);
-          if (ok) break;  // wave-uniform
+        const bool inrun = lane >= t && lane < cnt && ssv >= slot0;
+        bool rdy = true;
+        if (inrun) rdy = __hip_atomic_load(&flag[ssv - slot0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+        const unsigned long long pending = ~__ballot(rdy);
+        if (pending) lim = min(cnt, (int32_t)__builtin_ctzll(pending));
+        if (lim <= t) {
           __builtin_amdgcn_s_sleep(1);
           if ((++spins & 4095u) == 0 && spins > (1u << 24)) {
             if (lane == 0) __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
           }
+          continue;
         }
       }
+      while (t < lim) {
+        const int nb = min(8, lim - t);
+        int32_t j[8];
+        T a[8], xv[8];
 #pragma unroll
-      for (int b = 0; b < 8; ++b)
-        if (b < nb) xv[b] = x[((int64_t)j[b] << 6) + lane];
+        for (int b = 0; b < 8; ++b) {
+          const int idx = min(t + b, 63);
+          j[b] = rl32(colv, idx);
+          a[b] = rlv(valv, idx);
+        }
 #pragma unroll
-      for (int b = 0; b < 8; ++b)
-        if (b < nb) acc = vsub(acc, vmul(a[b], xv[b]));
+        for (int b = 0; b < 8; ++b)
+          if (b < nb) xv[b] = x[((int64_t)j[b] << 6) + lane];
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+          if (b < nb) acc = vsub(acc, vmul(a[b], xv[b]));
+        t += nb;
+      }
     }
     if (row_done) {
       x[((int64_t)i_c << 6) + lane] = acc;
