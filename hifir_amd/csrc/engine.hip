@@ -85,88 +85,32 @@ struct DevBuf {
 
 struct DevCsr {
   int64_t nrows = 0, ncols = 0, nnz = 0;
-  DevBuf ptr, col, val, rowid, wfptr;
-  std::vector<int64_t> wf_ptr_host;  // wavefront boundaries (slots)
-  // sync-free solve: dependency metadata in slot order ...
-  DevBuf srcslot;  // per nonzero: slot of the row that its column refers to
-  DevBuf split;    // per slot: first nonzero that depends on the row's own thin run (host.hpp RunPlan)
-  std::vector<int32_t> run_wf0, run_wf1;
-  DevBuf waitcol;  // per slot: the dependency produced last (largest source slot), -1 if none
-  // ... and per batch width (logR = 0..6) a plan, built lazily on the host:
-  //   wide part  = wavefronts [0, tail_wf0): chunk table + per-chunk useful-wave hint (k_trsv_sf)
-  //   thin tail  = wavefronts [tail_wf0, nwf): one workgroup with LDS flags (k_trsv_tail)
-  DevBuf chunk[7], hint[7];
-  unsigned nchunks[7] = {0, 0, 0, 0, 0, 0, 0};
-  int32_t tail_wf0[7] = {0, 0, 0, 0, 0, 0, 0};
-  bool plan_ready[7] = {false, false, false, false, false, false, false};
+  DevBuf ptr, col, val, rowid;
+  // band plan of a triangle (host.hpp BandPlan); empty for E, F, A
+  DevBuf srcslot, split, wg_grp_ptr, grp_slot_ptr;
+  std::vector<int32_t> band_wg_ptr, band_slot_ptr;
+  std::vector<uint8_t> band_prefix;
 
   template <class T>
-  void upload(const Csr<T> &A, const Schedule *S) {
+  void upload(const Csr<T> &A, const BandPlan *P) {
     nrows = A.nrows;
     ncols = A.ncols;
     nnz = (int64_t)A.col.size();
     ptr.upload(A.ptr);
-    col.upload(A.col, 80);  // padded: prefetches may run past a row's end
+    col.upload(A.col, 80);  // padded: a 64-wide item load may start at the last nonzero
     val.upload(A.val, 80);
     rowid.upload(A.rowid);
-    if (S) {
-      wf_ptr_host = S->wf_ptr;
-      std::vector<int32_t> w32(S->wf_ptr.begin(), S->wf_ptr.end());
-      wfptr.upload(w32);
+    if (P) {
+      srcslot.upload(P->srcslot, 80);
+      split.upload(P->split);
+      wg_grp_ptr.upload(P->wg_grp_ptr);
+      grp_slot_ptr.upload(P->grp_slot_ptr);
+      band_wg_ptr = P->band_wg_ptr;
+      band_prefix = P->band_prefix;
+      band_slot_ptr.clear();
+      for (size_t b = 0; b < band_wg_ptr.size(); ++b)
+        band_slot_ptr.push_back(P->grp_slot_ptr[(size_t)P->wg_grp_ptr[(size_t)band_wg_ptr[b]]]);
     }
-  }
-
-  template <class T>
-  void upload_deps(const Csr<T> &A /* rows already in slot order */, const RunPlan &P) {
-    std::vector<int32_t> wc((size_t)A.nrows, -1);
-    for (int64_t s = 0; s < A.nrows; ++s) {
-      int32_t best = -1;
-      for (int32_t k = A.ptr[(size_t)s]; k < A.ptr[(size_t)s + 1]; ++k)
-        if (P.srcslot[(size_t)k] > best) {
-          best = P.srcslot[(size_t)k];
-          wc[(size_t)s] = A.col[(size_t)k];
-        }
-    }
-    srcslot.upload(P.srcslot, 80);  // padded: a 64-wide item load may start at the last nonzero
-    waitcol.upload(wc);
-    split.upload(P.split);
-    run_wf0 = P.wf0;
-    run_wf1 = P.wf1;
-  }
-
-  void build_plan(int logR, int tail_rows_per_G, int tail_max) {
-    if (plan_ready[logR]) return;
-    const int64_t G = 64 >> logR, CH = std::max<int64_t>(64, 4 * G);
-    const int64_t nwf = (int64_t)wf_ptr_host.size() - 1;
-    // thin tail: the maximal suffix of wavefronts that are each at most T rows wide
-    const int64_t T = (int64_t)tail_rows_per_G * G;
-    int64_t t0 = nwf;
-    while (t0 > 0 && wf_ptr_host[(size_t)t0] - wf_ptr_host[(size_t)t0 - 1] <= T &&
-           wf_ptr_host[(size_t)nwf] - wf_ptr_host[(size_t)t0 - 1] <= tail_max)
-      --t0;
-    t0 = nwf;  // (the sync-free experiment covers the whole triangle; thin runs are a hybrid-mode feature)
-    tail_wf0[logR] = (int32_t)t0;
-    std::vector<int32_t> cp, hn;
-    cp.push_back(0);
-    for (int64_t w = 0; w < t0; ++w) {
-      const int64_t s0 = wf_ptr_host[(size_t)w], s1 = wf_ptr_host[(size_t)w + 1], r = s1 - s0;
-      // whole turns of G rows, never across a wavefront boundary (rows of one turn must be
-      // independent); up to ~256 chunks per wavefront so that many waves share a mid-size one
-      int64_t c = (r + 255) / 256;
-      c = ((c + G - 1) / G) * G;
-      c = std::min(std::max(c, G), CH);
-      const int64_t nch = (r + c - 1) / c;
-      const int32_t useful = (int32_t)std::min<int64_t>(4096, std::max<int64_t>(32, 4 * nch + 32));
-      for (int64_t s = s0; s < s1; s += c) {
-        cp.push_back((int32_t)std::min(s + c, s1));
-        hn.push_back(useful);
-      }
-    }
-    nchunks[logR] = (unsigned)(cp.size() - 1);
-    hn.push_back(4096);
-    chunk[logR].upload(cp);
-    hint[logR].upload(hn);
-    plan_ready[logR] = true;
   }
 };
 
@@ -175,7 +119,6 @@ struct DevLevel {
   DevCsr L, U, E, F;
   DevBuf d, s, t, p, qinv;
   DevBuf w, v;  // arena: n * Rmax each
-  DevBuf y, u;  // sync-free solves: L output (undivided) and U input (= y / d), m * Rmax each
 };
 
 struct DevDense {
@@ -220,12 +163,9 @@ class Engine : public EngineBase {
   std::map<GraphKey, GraphEntry> graphs;
   uint64_t clock = 0;
   int64_t last_launches = 0;
-  int thin_factor = 2;
   bool use_graph = true;
-  bool syncfree = false;   // experimental: one ticket/sentinel launch per triangle (k_trsv_sf)
-  int tail_rows = 32;      // a wavefront of <= tail_rows * G rows is "thin" (handled by the tail workgroup)
-  DevBuf tickets, errflag;  // ticket counters of the sync-free launches of one apply; sticky error word
-  int nticket = 0;
+  BandOptions band_opt;  // how triangles are cut into bands (host.hpp)
+  DevBuf errflag;        // sticky error word: a bounded spin of k_trsv_band expired
   // IR scratch
   DevBuf ir_r, ir_xk, ir_part, stage_b, stage_x;
   int64_t ir_cols = 0;
@@ -233,10 +173,12 @@ class Engine : public EngineBase {
   explicit Engine(int dev) : device(dev) {
     // Import and host-side analysis (CCS -> CSR, level schedules, dense QRCP) need no GPU; the
     // device is bound in finalize(), and every compute entry point requires a finalized handle.
-    thin_factor = env_int("HIFIR_AMD_THIN_FACTOR", 2);
     use_graph = env_int("HIFIR_AMD_NO_GRAPH", 0) == 0;
-    syncfree = env_int("HIFIR_AMD_TRSV_SYNCFREE", 0) != 0;
-    tail_rows = env_int("HIFIR_AMD_TAIL_ROWS", 32);
+    band_opt.thin_rows = env_int("HIFIR_AMD_THIN_ROWS", 32);
+    band_opt.band_depth = env_int("HIFIR_AMD_BAND_DEPTH", 32);
+    band_opt.max_wgs = env_int("HIFIR_AMD_BAND_WGS", 1024);
+    band_opt.max_comp_weight = env_int("HIFIR_AMD_BAND_WEIGHT", 1024);
+    band_opt.max_wg_rows = HIFAMD_TAIL_MAX;
   }
 
   void bind_device() {
@@ -322,10 +264,12 @@ class Engine : public EngineBase {
     H.Fr = ccs_to_csr(H.F, false);
     H.Ls = level_schedule(H.Lr, true);
     H.Us = level_schedule(H.Ur, false);
-    H.Lr = permute_rows(H.Lr, H.Ls.order);
-    H.Ur = permute_rows(H.Ur, H.Us.order);
-    H.Lp = plan_runs(H.Lr, H.Ls, tail_rows, HIFAMD_TAIL_MAX);
-    H.Up = plan_runs(H.Ur, H.Us, tail_rows, HIFAMD_TAIL_MAX);
+    H.Lp = plan_bands(H.Lr, H.Ls, true, band_opt);
+    H.Up = plan_bands(H.Ur, H.Us, false, band_opt);
+    H.Lr = permute_rows(H.Lr, H.Lp.order);
+    H.Ur = permute_rows(H.Ur, H.Up.order);
+    finish_band_plan(H.Lp, H.Lr);
+    finish_band_plan(H.Up, H.Ur);
     host.levels.push_back(std::move(H));
   }
 
@@ -356,10 +300,8 @@ class Engine : public EngineBase {
       L.m = H.m;
       L.n = H.n;
       L.F_ncols = H.F_ncols;
-      L.L.upload(H.Lr, &H.Ls);
-      L.U.upload(H.Ur, &H.Us);
-      L.L.upload_deps(H.Lr, H.Lp);
-      L.U.upload_deps(H.Ur, H.Up);
+      L.L.upload(H.Lr, &H.Lp);
+      L.U.upload(H.Ur, &H.Up);
       L.E.upload(H.Er, nullptr);
       L.F.upload(H.Fr, nullptr);
       L.d.upload(H.d);
@@ -371,12 +313,7 @@ class Engine : public EngineBase {
       L.v.alloc((size_t)H.n * Rmax * sizeof(T));
       HIP_OK(hipMemset(L.w.p, 0, L.w.bytes));
       HIP_OK(hipMemset(L.v.p, 0, L.v.bytes));
-      if (syncfree && H.m) {
-        L.y.alloc((size_t)H.m * Rmax * sizeof(T));
-        L.u.alloc((size_t)H.m * Rmax * sizeof(T));
-        HIP_OK(hipMemset(L.y.p, 0, L.y.bytes));
-        HIP_OK(hipMemset(L.u.p, 0, L.u.bytes));
-      }
+
       lv.push_back(std::move(Lp));
     }
     if (host.has_dense) {
@@ -390,33 +327,19 @@ class Engine : public EngineBase {
       std::vector<T>().swap(host.dense.QH);
       std::vector<T>().swap(host.dense.Rinv);
     }
-    nticket = (int)(4 * host.levels.size());
-    tickets.alloc((size_t)nticket * sizeof(unsigned));
     errflag.alloc(sizeof(unsigned));
-    HIP_OK(hipMemset(tickets.p, 0, tickets.bytes));
     HIP_OK(hipMemset(errflag.p, 0, errflag.bytes));
     HIP_OK(hipDeviceSynchronize());
     finalized = true;
   }
 
-  // host-side plan for one batch width: chunk tables of every triangle (no-op once built)
-  void ensure_plan(int logR) {
-    if (!syncfree) return;
-    for (auto &Lp : lv) {
-      if (!Lp->m) continue;
-      Lp->L.build_plan(logR, tail_rows, HIFAMD_TAIL_MAX);
-      Lp->U.build_plan(logR, tail_rows, HIFAMD_TAIL_MAX);
-    }
-  }
-
-  // the sticky error word of the sync-free solves (a bounded spin expired); checked at sync points
+  // the sticky error word of the band kernels (a bounded spin expired); checked at sync points
   void check_device_error() {
     unsigned e = 0;
     HIP_OK(hipMemcpy(&e, errflag.p, sizeof(e), hipMemcpyDeviceToHost));
     if (e) {
       HIP_OK(hipMemset(errflag.p, 0, sizeof(e)));
-      throw Error(HIFAMD_HIFIR_ERROR, "sync-free triangular solve timed out waiting for a dependency "
-                                      "(a right-hand side containing the reserved NaN pattern, or a device fault)");
+      throw Error(HIFAMD_HIFIR_ERROR, "a triangular-solve workgroup timed out waiting for a dependency (device fault)");
     }
   }
 
@@ -464,70 +387,35 @@ class Engine : public EngineBase {
     return (unsigned)g;
   }
 
-  // Level-scheduled solve: one launch per wide wavefront.  Every thin run (host.hpp RunPlan) costs
-  // two launches: a PREFIX pass over all its rows on the whole chip, then ONE workgroup that walks
-  // the dependent rest with LDS hand-offs (k_trsv_tail).
+  // One triangle = its bands in order (host.hpp BandPlan): an optional PREFIX pass on the whole
+  // chip, then ONE launch whose workgroups each own whole dependency components of the band.
   template <bool LOWER>
   void launch_trsv(hipStream_t st, const DevLevel &L, int logR, int64_t &count) {
     const DevCsr &M = LOWER ? L.L : L.U;
     if (M.nrows == 0) return;
     D *w = L.w.as<D>(), *v = L.v.as<D>();
-    const auto &wf = M.wf_ptr_host;
-    const int64_t nwf = (int64_t)wf.size() - 1;
-    size_t r = 0;
-    int64_t k = 0;
-    while (k < nwf) {
-      if (r < M.run_wf0.size() && M.run_wf0[r] == k) {
-        const int64_t k2 = M.run_wf1[r], s0 = wf[(size_t)k], s1 = wf[(size_t)k2];
+    const size_t nb = M.band_wg_ptr.size() - 1;
+    for (size_t b = 0; b < nb; ++b) {
+      const int32_t g0 = M.band_wg_ptr[b], g1 = M.band_wg_ptr[b + 1];
+      if (M.band_prefix[b]) {
+        const int64_t s0 = M.band_slot_ptr[b], s1 = M.band_slot_ptr[b + 1];
         hipLaunchKernelGGL((k_trsv_wide<D, LOWER, true>), dim3(grid_for(s1 - s0, logR)), dim3(256), 0, st, s0, s1,
                            M.ptr.as<int32_t>(), M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(),
                            M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR);
-        hipLaunchKernelGGL((k_trsv_tail<D, LOWER>), dim3(1), dim3(1024), 0, st, (int32_t)k, (int32_t)k2,
-                           M.wfptr.as<int32_t>(), M.ptr.as<int32_t>(), M.split.as<int32_t>(), M.col.as<int32_t>(),
-                           M.val.as<D>(), M.srcslot.as<int32_t>(), M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR,
-                           errflag.as<unsigned>());
-        count += 2;
-        k = k2;
-        ++r;
-        continue;
+        ++count;
       }
-      const int64_t rows = wf[(size_t)k + 1] - wf[(size_t)k];
-      hipLaunchKernelGGL((k_trsv_wide<D, LOWER, false>), dim3(grid_for(rows, logR)), dim3(256), 0, st, wf[(size_t)k],
-                         wf[(size_t)k + 1], M.ptr.as<int32_t>(), M.split.as<int32_t>(), M.col.as<int32_t>(),
-                         M.val.as<D>(), M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR);
-      ++count;
-      ++k;
-    }
-  }
-
-  template <bool LOWER>
-  void launch_trsv_sf(hipStream_t st, DevLevel &L, int logR, int64_t &count, int tk) {
-    DevCsr &M = LOWER ? L.L : L.U;
-    D *rhs = LOWER ? L.w.as<D>() : L.u.as<D>();
-    D *out = LOWER ? L.y.as<D>() : L.v.as<D>();
-    D *out2 = LOWER ? L.u.as<D>() : (D *)nullptr;
-    const unsigned nch = M.nchunks[logR];
-    if (nch) {
-      unsigned grid = (nch + 15) / 16;
-      if (grid > 256) grid = 256;  // one 16-wave workgroup per CU: co-resident, few first-ticket atomics
-      hipLaunchKernelGGL((k_trsv_sf<D, LOWER>), dim3(grid), dim3(1024), 0, st, M.chunk[logR].as<int32_t>(),
-                         M.hint[logR].as<int32_t>(), nch, tickets.as<unsigned>() + tk, M.ptr.as<int32_t>(),
-                         M.col.as<int32_t>(), M.val.as<D>(), M.rowid.as<int32_t>(), M.waitcol.as<int32_t>(),
-                         L.d.as<D>(), rhs, out, out2, logR, errflag.as<unsigned>());
+      hipLaunchKernelGGL((k_trsv_band<D, LOWER>), dim3((unsigned)(g1 - g0)), dim3(1024), 0, st, g0,
+                         M.wg_grp_ptr.as<int32_t>(), M.grp_slot_ptr.as<int32_t>(), M.ptr.as<int32_t>(),
+                         M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(), M.srcslot.as<int32_t>(),
+                         M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR, errflag.as<unsigned>());
       ++count;
     }
   }
 
-  // pass = 0 / 1: first / second LDU of the level (distinct ticket counters within one apply)
-  void launch_ldu(hipStream_t st, DevLevel &L, size_t l, int pass, int logR, int64_t &count) {
+  void launch_ldu(hipStream_t st, DevLevel &L, int logR, int64_t &count) {
     if (!L.m) return;
-    if (syncfree) {
-      launch_trsv_sf<true>(st, L, logR, count, (int)(4 * l + 2 * pass));
-      launch_trsv_sf<false>(st, L, logR, count, (int)(4 * l + 2 * pass + 1));
-    } else {
-      launch_trsv<true>(st, L, logR, count);
-      launch_trsv<false>(st, L, logR, count);
-    }
+    launch_trsv<true>(st, L, logR, count);
+    launch_trsv<false>(st, L, logR, count);
   }
 
   void launch_dense(hipStream_t st, const D *cin, D *zout, int logR, int64_t rank, int64_t &count);
@@ -545,20 +433,18 @@ class Engine : public EngineBase {
     const int64_t m = L.m, n = L.n, nm = n - m;
     const int64_t R = 1LL << logR;
     D *w = L.w.as<D>(), *v = L.v.as<D>();
-    // sync-free solves poll y (L) and v[0:m] (U): the kernel that writes the rhs re-arms them
-    D *rs1 = syncfree ? L.y.as<D>() : (D *)nullptr, *rs2 = syncfree ? v : (D *)nullptr;
     const bool last = (l + 1 == lv.size());
     if (m) {  // S1  :359
       hipLaunchKernelGGL((k_gather_scale<D>), dim3(grid_for(m, logR)), dim3(256), 0, st, bin, ldb, nrhs,
-                         L.p.as<int32_t>(), L.s.as<double>(), m, w, logR, rs1, rs2);
+                         L.p.as<int32_t>(), L.s.as<double>(), m, w, logR);
       ++count;
     }
     if (nm) {
-      launch_ldu(st, L, l, 0, logR, count);  // S2  :364
+      launch_ldu(st, L, logR, count);  // S2  :364
       // S3  :366-368  -> w[m:n] (becomes the child's rhs, :386)
       hipLaunchKernelGGL((k_spmm_epi<D>), dim3(grid_for(nm, logR)), dim3(256), 0, st, nm, L.E.ptr.as<int32_t>(),
                          L.E.col.as<int32_t>(), L.E.val.as<D>(), v, bin, ldb, nrhs, L.p.as<int32_t>(),
-                         L.s.as<double>(), m, w + m * R, logR, (D *)nullptr, (D *)nullptr);
+                         L.s.as<double>(), m, w + m * R, logR);
       ++count;
       if (last)
         launch_dense(st, w + m * R, v + m * R, logR, rank, count);  // :371-381
@@ -569,15 +455,15 @@ class Engine : public EngineBase {
         if (L.F_ncols) {
           hipLaunchKernelGGL((k_spmm_epi<D>), dim3(grid_for(m, logR)), dim3(256), 0, st, m, L.F.ptr.as<int32_t>(),
                              L.F.col.as<int32_t>(), L.F.val.as<D>(), v + m * R, bin, ldb, nrhs,
-                             L.p.as<int32_t>(), L.s.as<double>(), (int64_t)0, w, logR, rs1, rs2);
+                             L.p.as<int32_t>(), L.s.as<double>(), (int64_t)0, w, logR);
         } else {
           hipLaunchKernelGGL((k_gather_scale<D>), dim3(grid_for(m, logR)), dim3(256), 0, st, bin, ldb, nrhs,
-                             L.p.as<int32_t>(), L.s.as<double>(), m, w, logR, rs1, rs2);
+                             L.p.as<int32_t>(), L.s.as<double>(), m, w, logR);
         }
         ++count;
       }
     }
-    launch_ldu(st, L, l, 1, logR, count);  // S6  :406
+    launch_ldu(st, L, logR, count);  // S6  :406
     // S7  :411
     hipLaunchKernelGGL((k_scatter_scale<D>), dim3(grid_for(n, logR)), dim3(256), 0, st, v, L.qinv.as<int32_t>(),
                        L.t.as<double>(), n, yout, ldy, nrhs, logR);
@@ -590,18 +476,10 @@ class Engine : public EngineBase {
     for (int64_t c0 = 0; c0 < nrhs; c0 += 64) {
       const int64_t nc = std::min<int64_t>(64, nrhs - c0);
       const int logR = pick_logR(nc);
-      if (syncfree) {
-        hipLaunchKernelGGL(k_zero_u32, dim3((nticket + 255) / 256), dim3(256), 0, st, tickets.as<unsigned>(), nticket);
-        ++count;
-      }
       enqueue_level(st, 0, dB + c0, ldb, dX + c0, ldx, (int)nc, logR, rank, count);
     }
     HIP_OK(hipGetLastError());
     return count;
-  }
-
-  void plan_for(int64_t nrhs) {
-    for (int64_t c0 = 0; c0 < nrhs; c0 += 64) ensure_plan(pick_logR(std::min<int64_t>(64, nrhs - c0)));
   }
 
   void check_batch(const void *B, int64_t ldb, const void *X, int64_t ldx, int64_t nrhs) const {
@@ -618,7 +496,6 @@ class Engine : public EngineBase {
   void solve_dev(const D *dB, int64_t ldb, D *dX, int64_t ldx, int64_t nrhs, int64_t rank, hipStream_t user) {
     check_batch(dB, ldb, dX, ldx, nrhs);
     HIP_OK(hipSetDevice(device));
-    plan_for(nrhs);  // uploads happen here, never inside a stream capture
     hipStream_t st = user ? user : stream;
     if (!use_graph) {
       last_launches = enqueue_apply(st, dB, ldb, dX, ldx, nrhs, rank);
@@ -850,6 +727,8 @@ class Engine : public EngineBase {
       bvec += sv * (7 * n + 4 * m);
       wfL += H.Ls.nwf();
       wfU += H.Us.nwf();
+      o[11] += (double)(H.Lp.nbands() + H.Up.nbands());
+      o[12] += (double)(H.Lp.nwg() + H.Up.nwg());
     }
     if (host.has_dense) {
       o[4] = (double)host.dense.n;

@@ -125,50 +125,251 @@ Schedule level_schedule(const Csr<T> &A, bool lower) {
   return S;
 }
 
-// Thin runs: maximal groups of >= 2 consecutive wavefronts that are each at most thin_rows wide
-// (and together at most max_rows rows: one LDS flag per row).  For every row of a run, split[slot]
-// is the position of its first nonzero whose source row belongs to the run; all earlier nonzeros
-// refer to rows finished before the run starts.  Outside runs split[slot] = end of the row.
-struct RunPlan {
-  std::vector<int32_t> wf0, wf1;   // runs as wavefront ranges [wf0, wf1)
-  std::vector<int32_t> split;      // per slot
-  std::vector<int32_t> srcslot;    // per nonzero (slot order): slot of the source row
+// ---------------------------------------------------------------------------------------------
+// band plan: how a triangle is actually executed on the GPU
+// ---------------------------------------------------------------------------------------------
+// A launch per wavefront is latency-bound (a dependent launch costs ~5 us on MI355X whatever its
+// size) and the reference's hierarchies have hundreds of wavefronts per triangle.  Instead:
+//   * consecutive wavefronts are grouped into BANDS;
+//   * inside a band, the rows split into connected COMPONENTS of the dependency graph restricted to
+//     the band (the band is a slice of the elimination forest: many small independent subtrees);
+//   * components are bin-packed onto workgroups; a workgroup owns a contiguous slot range, walks
+//     its rows in dependency order and hands results over through LDS flags -- no communication
+//     between workgroups, one launch per band.
+// A band that is essentially one component (the thin tail of a triangle) runs on one workgroup,
+// after an exact PREFIX pass on the whole chip has folded in every leading nonzero that refers to
+// rows before the band.  Accumulation order inside a row never changes.
+struct BandPlan {
+  std::vector<int32_t> order;         // slot -> row id (bands, then workgroups, then depth order)
+  std::vector<int32_t> grp_slot_ptr;  // group g (rows of one depth inside one workgroup) owns these slots
+  std::vector<int32_t> wg_grp_ptr;    // workgroup w owns groups [wg_grp_ptr[w], wg_grp_ptr[w+1])
+  std::vector<int32_t> band_wg_ptr;   // band b owns workgroups [band_wg_ptr[b], band_wg_ptr[b+1])
+  std::vector<uint8_t> band_prefix;   // band b is preceded by the exact prefix pass
+  std::vector<int32_t> srcslot;       // per nonzero (slot order): slot of the source row
+  std::vector<int32_t> split;         // per slot: where the band kernel starts in the row
+  int64_t nbands() const { return (int64_t)band_wg_ptr.size() - 1; }
+  int64_t nwg() const { return (int64_t)wg_grp_ptr.size() - 1; }
 };
 
+struct BandOptions {
+  int64_t thin_rows = 32;    // a wavefront this narrow belongs to a thin run
+  int64_t band_depth = 32;   // at most this many wavefronts per band outside thin runs
+  int64_t max_comp_weight = 1024;  // ... and a band stops growing before one component gets heavier
+                                   // than this many nonzeros (a component is served by ONE compute unit)
+  int64_t max_wg_rows = 16384;  // LDS flags per workgroup
+  int64_t max_wgs = 1024;    // workgroups per band
+};
+
+// A: strict triangle in CSR, natural row order (before any permutation); depth from level_schedule.
 template <class T>
-RunPlan plan_runs(const Csr<T> &A /* rows in slot order */, const Schedule &S, int64_t thin_rows, int64_t max_rows) {
-  RunPlan P;
+BandPlan plan_bands(const Csr<T> &A, const Schedule &S, bool lower, const BandOptions &opt) {
+  BandPlan P;
+  const int64_t m = A.nrows, nwf = S.nwf();
+  std::vector<int32_t> depth((size_t)m), pos((size_t)m);  // pos: rank of the row in level-schedule order
+  for (int64_t w = 0; w < nwf; ++w)
+    for (int64_t s = S.wf_ptr[(size_t)w]; s < S.wf_ptr[(size_t)w + 1]; ++s) {
+      depth[(size_t)S.order[(size_t)s]] = (int32_t)w;
+      pos[(size_t)S.order[(size_t)s]] = (int32_t)s;
+    }
+  P.order.reserve((size_t)m);
+  P.grp_slot_ptr.push_back(0);
+  P.wg_grp_ptr.push_back(0);
+  P.band_wg_ptr.push_back(0);
+  std::vector<int32_t> parent((size_t)m), comp_of((size_t)m);
+  auto find = [&](int32_t x) {
+    while (parent[(size_t)x] != x) {
+      parent[(size_t)x] = parent[(size_t)parent[(size_t)x]];
+      x = parent[(size_t)x];
+    }
+    return x;
+  };
+  int64_t w0 = 0;
+  while (w0 < nwf) {
+    // ---- band extent
+    const bool thin = S.wf_ptr[(size_t)w0 + 1] - S.wf_ptr[(size_t)w0] <= opt.thin_rows;
+    int64_t w1 = w0 + 1;
+    if (thin) {
+      while (w1 < nwf && S.wf_ptr[(size_t)w1 + 1] - S.wf_ptr[(size_t)w1] <= opt.thin_rows &&
+             S.wf_ptr[(size_t)w1 + 1] - S.wf_ptr[(size_t)w0] <= opt.max_wg_rows)
+        ++w1;
+    } else {
+      // grow the band one wavefront at a time (incremental union-find) until its heaviest
+      // component would exceed what one compute unit should carry
+      int64_t totw = 0, maxw = 0;
+      auto add_wave = [&](int64_t w) {
+        for (int64_t s = S.wf_ptr[(size_t)w]; s < S.wf_ptr[(size_t)w + 1]; ++s) {
+          const int32_t i = S.order[(size_t)s];
+          parent[(size_t)i] = i;
+          comp_of[(size_t)i] = (A.ptr[(size_t)i + 1] - A.ptr[(size_t)i]) + 2;  // weight, valid at roots
+          totw += comp_of[(size_t)i];
+          maxw = std::max<int64_t>(maxw, comp_of[(size_t)i]);
+        }
+        if (w == w0) return;
+        for (int64_t s = S.wf_ptr[(size_t)w]; s < S.wf_ptr[(size_t)w + 1]; ++s) {
+          const int32_t i = S.order[(size_t)s];
+          for (int32_t k = A.ptr[(size_t)i]; k < A.ptr[(size_t)i + 1]; ++k) {
+            const int32_t j = A.col[(size_t)k];
+            if (depth[(size_t)j] >= w0) {
+              const int32_t a = find(i), b = find(j);
+              if (a != b) {
+                parent[(size_t)a] = b;
+                comp_of[(size_t)b] += comp_of[(size_t)a];
+                maxw = std::max<int64_t>(maxw, comp_of[(size_t)b]);
+              }
+            }
+          }
+        }
+      };
+      add_wave(w0);
+      while (w1 < nwf && w1 - w0 < opt.band_depth && S.wf_ptr[(size_t)w1 + 1] - S.wf_ptr[(size_t)w1] > opt.thin_rows) {
+        add_wave(w1);
+        if (maxw > std::max<int64_t>(opt.max_comp_weight, totw / 512)) break;  // w1 stays out
+        ++w1;
+      }
+    }
+    std::vector<std::vector<int32_t>> wg_rows;
+    bool prefix = false;
+    for (;;) {  // (re)try with a shallower band if a component does not fit one workgroup
+      const int64_t s0 = S.wf_ptr[(size_t)w0], s1 = S.wf_ptr[(size_t)w1];
+      // ---- connected components of the dependency graph restricted to the band
+      for (int64_t s = s0; s < s1; ++s) parent[(size_t)S.order[(size_t)s]] = S.order[(size_t)s];
+      for (int64_t s = s0; s < s1; ++s) {
+        const int32_t i = S.order[(size_t)s];
+        for (int32_t k = A.ptr[(size_t)i]; k < A.ptr[(size_t)i + 1]; ++k) {
+          const int32_t j = A.col[(size_t)k];
+          if (depth[(size_t)j] >= w0) {
+            const int32_t a = find(i), b = find(j);
+            if (a != b) parent[(size_t)a] = b;
+          }
+        }
+      }
+      std::vector<int32_t> roots;
+      std::vector<int64_t> weight, crows;
+      for (int64_t s = s0; s < s1; ++s) {
+        const int32_t i = S.order[(size_t)s], r = find(i);
+        if (r == i) {
+          comp_of[(size_t)i] = (int32_t)roots.size();
+          roots.push_back(i);
+          weight.push_back(0);
+          crows.push_back(0);
+        }
+      }
+      for (int64_t s = s0; s < s1; ++s) {
+        const int32_t i = S.order[(size_t)s], c = comp_of[(size_t)find(i)];
+        comp_of[(size_t)i] = c;  // (roots keep their own id: comp_of[root] was set above)
+        weight[(size_t)c] += (A.ptr[(size_t)i + 1] - A.ptr[(size_t)i]) + 2;
+        crows[(size_t)c] += 1;
+      }
+      const int64_t ncomp = (int64_t)roots.size();
+      int64_t maxrows = 0, totw = 0, maxw = 0;
+      for (int64_t c = 0; c < ncomp; ++c) {
+        maxrows = std::max(maxrows, crows[(size_t)c]);
+        totw += weight[(size_t)c];
+        maxw = std::max(maxw, weight[(size_t)c]);
+      }
+      if (maxrows > opt.max_wg_rows && w1 - w0 > 1) {
+        w1 = w0 + std::max<int64_t>(1, (w1 - w0) / 2);
+        continue;
+      }
+      if (maxrows > opt.max_wg_rows)
+        throw Error(4, "a single wavefront component exceeds the per-workgroup row limit");
+      // ---- bin-pack components onto workgroups (largest first onto the lightest workgroup)
+      int64_t nw = std::min<int64_t>(ncomp, std::max<int64_t>(1, std::min<int64_t>(opt.max_wgs, (s1 - s0) / 16)));
+      nw = std::max(nw, (s1 - s0 + opt.max_wg_rows - 1) / opt.max_wg_rows);
+      std::vector<int64_t> idx((size_t)ncomp);
+      for (int64_t c = 0; c < ncomp; ++c) idx[(size_t)c] = c;
+      std::sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) { return weight[(size_t)x] > weight[(size_t)y]; });
+      std::vector<int64_t> lrows((size_t)nw, 0);
+      std::vector<int32_t> wg_of((size_t)ncomp);
+      // min-heap on load
+      std::vector<std::pair<int64_t, int64_t>> heap;
+      for (int64_t g = 0; g < nw; ++g) heap.push_back({0, g});
+      auto cmp = [](const std::pair<int64_t, int64_t> &x, const std::pair<int64_t, int64_t> &y) { return x > y; };
+      std::make_heap(heap.begin(), heap.end(), cmp);
+      for (int64_t q = 0; q < ncomp; ++q) {
+        const int64_t c = idx[(size_t)q];
+        // lightest workgroup that still has room for the component's rows
+        std::vector<std::pair<int64_t, int64_t>> parked;
+        for (;;) {
+          if (heap.empty()) {  // nobody has room left: open another workgroup
+            lrows.push_back(0);
+            heap.push_back({0, nw++});
+          }
+          std::pop_heap(heap.begin(), heap.end(), cmp);
+          auto top = heap.back();
+          heap.pop_back();
+          if (lrows[(size_t)top.second] + crows[(size_t)c] <= opt.max_wg_rows) {
+            wg_of[(size_t)c] = (int32_t)top.second;
+            lrows[(size_t)top.second] += crows[(size_t)c];
+            top.first += weight[(size_t)c];
+            heap.push_back(top);
+            std::push_heap(heap.begin(), heap.end(), cmp);
+            break;
+          }
+          parked.push_back(top);
+        }
+        for (auto &pk : parked) {
+          heap.push_back(pk);
+          std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+      }
+      wg_rows.assign((size_t)nw, std::vector<int32_t>());
+      for (int64_t s = s0; s < s1; ++s) {  // level-schedule order: depth-major, so each list is depth-sorted
+        const int32_t i = S.order[(size_t)s];
+        wg_rows[(size_t)wg_of[(size_t)comp_of[(size_t)i]]].push_back(i);
+      }
+      // one workgroup carrying most of a sizeable band: let the whole chip do the independent prefixes first
+      prefix = (maxw * 4 > totw) && totw > 4096;
+      break;
+    }
+    for (auto &rows : wg_rows) {
+      if (rows.empty()) continue;
+      int32_t cur = -1;
+      for (int32_t i : rows) {
+        if (depth[(size_t)i] != cur) {
+          if (cur != -1) P.grp_slot_ptr.push_back((int32_t)P.order.size());
+          cur = depth[(size_t)i];
+        }
+        P.order.push_back(i);
+      }
+      P.grp_slot_ptr.push_back((int32_t)P.order.size());
+      P.wg_grp_ptr.push_back((int32_t)P.grp_slot_ptr.size() - 1);
+    }
+    P.band_wg_ptr.push_back((int32_t)P.wg_grp_ptr.size() - 1);
+    P.band_prefix.push_back(prefix ? 1 : 0);
+    w0 = w1;
+  }
+  (void)lower;
+  (void)pos;
+  return P;
+}
+
+// After the CSR has been permuted into the band plan's slot order: source slots and split points.
+template <class T>
+void finish_band_plan(BandPlan &P, const Csr<T> &A /* rows in slot order */) {
   const int64_t m = A.nrows;
   std::vector<int32_t> slot_of((size_t)m);
   for (int64_t s = 0; s < m; ++s) slot_of[(size_t)A.rowid[(size_t)s]] = (int32_t)s;
   P.srcslot.resize(A.col.size());
   for (size_t k = 0; k < A.col.size(); ++k) P.srcslot[k] = slot_of[(size_t)A.col[k]];
   P.split.resize((size_t)m);
-  for (int64_t s = 0; s < m; ++s) P.split[(size_t)s] = A.ptr[(size_t)s + 1];
-  const int64_t nwf = S.nwf();
-  int64_t k = 0;
-  while (k < nwf) {
-    if (S.wf_ptr[(size_t)k + 1] - S.wf_ptr[(size_t)k] > thin_rows) {
-      ++k;
-      continue;
-    }
-    int64_t k2 = k + 1;
-    while (k2 < nwf && S.wf_ptr[(size_t)k2 + 1] - S.wf_ptr[(size_t)k2] <= thin_rows &&
-           S.wf_ptr[(size_t)k2 + 1] - S.wf_ptr[(size_t)k] <= max_rows)
-      ++k2;
-    if (k2 - k >= 2) {
-      P.wf0.push_back((int32_t)k);
-      P.wf1.push_back((int32_t)k2);
-      const int32_t s0 = (int32_t)S.wf_ptr[(size_t)k];
-      for (int64_t s = s0; s < S.wf_ptr[(size_t)k2]; ++s) {
+  for (int64_t b = 0; b < P.nbands(); ++b) {
+    const int32_t band0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b]]];
+    for (int32_t g = P.band_wg_ptr[(size_t)b]; g < P.band_wg_ptr[(size_t)b + 1]; ++g) {
+      const int32_t s0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]], s1 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]];
+      for (int32_t s = s0; s < s1; ++s) {
         int32_t kk = A.ptr[(size_t)s];
-        while (kk < A.ptr[(size_t)s + 1] && P.srcslot[(size_t)kk] < s0) ++kk;
+        if (P.band_prefix[(size_t)b])
+          while (kk < A.ptr[(size_t)s + 1] && P.srcslot[(size_t)kk] < s0) ++kk;
         P.split[(size_t)s] = kk;
+        for (int32_t k = A.ptr[(size_t)s]; k < A.ptr[(size_t)s + 1]; ++k) {
+          const int32_t q = P.srcslot[(size_t)k];  // either before the band, or earlier in this workgroup
+          if (!(q < band0 || (q >= s0 && q < s)))
+            throw Error(4, "internal error: band plan violates the dependency order");
+        }
       }
     }
-    k = k2;
   }
-  return P;
 }
 
 // Physically permute the CSR rows into slot order so that the matrix streams through HBM in the
@@ -207,8 +408,8 @@ struct HostLevel {
   std::vector<int32_t> p, p_inv, q, q_inv;
   // derived
   Csr<T> Lr, Ur, Er, Fr;
-  Schedule Ls, Us;
-  RunPlan Lp, Up;
+  Schedule Ls, Us;   // plain level schedules (wavefronts), kept for queries
+  BandPlan Lp, Up;   // what the device executes
 };
 
 // Dense last level: A P = Q R (GEQP3 semantics), numerical rank as QRCP::factorize decides it

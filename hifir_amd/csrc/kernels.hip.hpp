@@ -52,41 +52,6 @@ __device__ __forceinline__ cplx vdiv(cplx a, cplx b) {
   return cplx{(a.x * r + a.y) / den, (a.y * r - a.x) / den};
 }
 
-// ---- "the data is the flag" hand-off used by the sync-free triangular solves -----------------
-// A solution element is published by ONE naturally aligned 8-byte agent-scope store and polled by
-// 8-byte agent-scope loads (cdna_hip_programming.md Guideline 16, form R2: data-tagged granules;
-// no flag, no fence).  "Not yet written" is a signalling-NaN bit pattern that no arithmetic
-// instruction can produce (hardware only ever generates quiet NaNs), armed by the kernel that
-// writes the right-hand side of the solve.
-#define HIFAMD_SENTINEL_BITS 0x7FF4DEADBEEF5A5AULL
-__device__ __forceinline__ double vsentinel(double) { return __longlong_as_double((long long)HIFAMD_SENTINEL_BITS); }
-__device__ __forceinline__ cplx vsentinel(cplx) {
-  const double q = __longlong_as_double((long long)HIFAMD_SENTINEL_BITS);
-  return cplx{q, q};
-}
-__device__ __forceinline__ double ld_poll(const double *p) {
-  return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ cplx ld_poll(const cplx *p) {
-  cplx r;
-  r.x = ld_poll(&p->x);
-  r.y = ld_poll(&p->y);
-  return r;
-}
-__device__ __forceinline__ void st_publish(double *p, double v) {
-  __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_publish(cplx *p, cplx v) {
-  st_publish(&p->x, v.x);
-  st_publish(&p->y, v.y);
-}
-__device__ __forceinline__ bool is_ready(double v) {
-  return (unsigned long long)__double_as_longlong(v) != HIFAMD_SENTINEL_BITS;
-}
-__device__ __forceinline__ bool is_ready(cplx v) { return is_ready(v.x) && is_ready(v.y); }
-
 // lane decomposition
 struct LaneMap {
   int g, c, G;
@@ -107,8 +72,7 @@ template <class T>
 __global__ void __launch_bounds__(256) k_gather_scale(const T *__restrict__ bin, int64_t ldb, int nrhs,
                                                       const int32_t *__restrict__ p,
                                                       const double *__restrict__ s, int64_t cnt,
-                                                      T *__restrict__ w, int logR,
-                                                      T *__restrict__ reset1, T *__restrict__ reset2) {
+                                                      T *__restrict__ w, int logR) {
   const LaneMap lm = lane_map(logR);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -117,8 +81,6 @@ __global__ void __launch_bounds__(256) k_gather_scale(const T *__restrict__ bin,
     T val = vzero(T());
     if (lm.c < nrhs) val = vscale(s[src], bin[(int64_t)src * ldb + lm.c]);
     w[(i << logR) + lm.c] = val;
-    if (reset1) reset1[(i << logR) + lm.c] = vsentinel(T());  // arm the sync-free solves (k_trsv_sf)
-    if (reset2) reset2[(i << logR) + lm.c] = vsentinel(T());
   }
 }
 
@@ -354,263 +316,22 @@ __global__ void __launch_bounds__(256) k_trsv_wide(int64_t s0, int64_t s1, const
 }
 
 // ---------------------------------------------------------------------------------------------
-// R = 64 fast path of a triangular-solve row: the whole wave owns ONE row, so the row's slot, its
-// nonzero range and every (column, value, source-slot) triple are wave-uniform: they are fetched
-// with scalar loads, eight nonzeros at a time and one batch AHEAD of the gathers (the metadata of
-// batch n+1 is in flight while batch n waits for its dependencies), and each batch issues its
-// eight 512-byte row gathers back to back.  Accumulation stays in the reference's order.
-//   MODE 1: dependencies are polled in the data (sentinel), agent scope     (k_trsv_sf)
-//   MODE 2: dependencies inside the tail are acquired through LDS flags      (k_trsv_tail)
-// The index/value arrays are padded by 8 entries on upload so that the prefetch never leaves them.
-// ---------------------------------------------------------------------------------------------
-#define HIFAMD_NB 8
-template <class T>
-struct RowMeta {
-  int32_t j[HIFAMD_NB], ss[HIFAMD_NB];
-  T a[HIFAMD_NB];
-};
-
-template <class T, int MODE>
-__device__ __forceinline__ void load_meta(RowMeta<T> &m, int32_t k, const int32_t *__restrict__ col,
-                                          const T *__restrict__ val, const int32_t *__restrict__ srcslot) {
-#pragma unroll
-  for (int b = 0; b < HIFAMD_NB; ++b) {
-    m.j[b] = col[k + b];
-    m.a[b] = val[k + b];
-    m.ss[b] = (MODE == 2) ? srcslot[k + b] : 0;
-  }
-}
-
-template <class T, int MODE, bool LOWER>
-__device__ __forceinline__ bool trsv_row_r64(int32_t slot_u, const int32_t *__restrict__ ptr,
-                                             const int32_t *__restrict__ col, const T *__restrict__ val,
-                                             const int32_t *__restrict__ srcslot,
-                                             const int32_t *__restrict__ rowid, const T *__restrict__ d,
-                                             const T *__restrict__ rhs, T *out, T *__restrict__ out2, int lane,
-                                             const int *flag, int32_t slot0, unsigned *errflag) {
-  const int32_t slot = __builtin_amdgcn_readfirstlane(slot_u);
-  const int64_t i = __builtin_amdgcn_readfirstlane(rowid[slot]);
-  const int32_t k0 = __builtin_amdgcn_readfirstlane(ptr[slot]);
-  const int32_t k1 = __builtin_amdgcn_readfirstlane(ptr[slot + 1]);
-  T acc = rhs[(i << 6) + lane];
-  RowMeta<T> cur, nxt;
-  if (k0 < k1) load_meta<T, MODE>(cur, k0, col, val, srcslot);
-  for (int32_t k = k0; k < k1; k += HIFAMD_NB) {
-    if (k + HIFAMD_NB < k1) load_meta<T, MODE>(nxt, k + HIFAMD_NB, col, val, srcslot);
-    const int nb = min(HIFAMD_NB, k1 - k);
-    T x[HIFAMD_NB];
-    if (MODE == 2) {
-      unsigned spins = 0;
-      for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int b = 0; b < HIFAMD_NB; ++b)
-          if (b < nb && cur.ss[b] >= slot0)
-            ok = ok && (__hip_atomic_load(&flag[cur.ss[b] - slot0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0);
-        if (ok) break;  // wave-uniform
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 4095u) == 0 && spins > (1u << 24)) {
-          if (lane == 0) __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          return false;
-        }
-      }
-#pragma unroll
-      for (int b = 0; b < HIFAMD_NB; ++b)
-        if (b < nb) x[b] = out[((int64_t)cur.j[b] << 6) + lane];
-    } else {
-      unsigned spins = 0;
-      for (;;) {
-        bool ok = true;
-#pragma unroll
-        for (int b = 0; b < HIFAMD_NB; ++b)
-          if (b < nb) {
-            x[b] = ld_poll(&out[((int64_t)cur.j[b] << 6) + lane]);
-            ok = ok && is_ready(x[b]);
-          }
-        if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(4);
-        if ((++spins & 255u) == 0) {
-          if (spins > (1u << 22) || __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            if (lane == 0) __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int b = 0; b < HIFAMD_NB; ++b)
-      if (b < nb) acc = vsub(acc, vmul(cur.a[b], x[b]));
-    cur = nxt;
-  }
-  if (MODE == 2)
-    out[(i << 6) + lane] = acc;
-  else
-    st_publish(&out[(i << 6) + lane], acc);
-  if (LOWER) out2[(i << 6) + lane] = vdiv(acc, d[i]);
-  return true;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Sync-free triangular solve of the WIDE part of a triangle: ONE launch.  Rows are consumed in
-// schedule (slot) order in chunks that never cross a wavefront boundary (so the <= G rows a wave
-// works on together are independent).  Chunks are handed out by a ticket counter: a wave only ever
-// waits for rows of chunks with a SMALLER ticket, which are owned by waves that are already
-// running -- forward progress holds for every dispatch order and placement.  A dependency x[j] is
-// polled until it stops being the sentinel; to keep thousands of run-ahead waves from flooding the
-// fabric with polls, a wave first probes ONE 8-byte element of its latest-produced dependency
-// (waitcol) with back-off and only then gathers.  hint[chunk] = number of waves that can usefully
-// work near that chunk: surplus waves retire instead of spinning.  Every spin is bounded: on
-// expiry the wave raises *errflag and all waves drain.
-//   LOWER: acc = rhs[i] - sum_asc L(i,j) out[j];  out[i] = acc (published);  out2[i] = acc / d[i]
-//   UPPER: acc = rhs[i] - sum_desc U(i,j) out[j]; out[i] = acc (published)
-// ---------------------------------------------------------------------------------------------
-template <class T, bool LOWER>
-__global__ void __launch_bounds__(1024) k_trsv_sf(const int32_t *__restrict__ cptr,
-                                                  const int32_t *__restrict__ hint, unsigned nchunks,
-                                                  unsigned *ticket, const int32_t *__restrict__ ptr,
-                                                  const int32_t *__restrict__ col, const T *__restrict__ val,
-                                                  const int32_t *__restrict__ rowid,
-                                                  const int32_t *__restrict__ waitcol, const T *__restrict__ d,
-                                                  const T *__restrict__ rhs, T *out, T *__restrict__ out2,
-                                                  int logR, unsigned *errflag) {
-  __shared__ unsigned s_base;
-  const LaneMap lm = lane_map(logR);
-  const int lane = threadIdx.x & 63;
-  const unsigned wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int gwave = (int)(blockIdx.x * nw + wave);
-  if (threadIdx.x == 0) s_base = atomicAdd(ticket, nw);
-  __syncthreads();
-  unsigned chunk = s_base + wave;
-  while (chunk < nchunks) {
-    const int32_t s0 = cptr[chunk], s1 = cptr[chunk + 1];
-    if (logR == 6) {  // one wave per row: scalar metadata, prefetched batches
-      for (int32_t slot = s0; slot < s1; ++slot) {
-        const int32_t wc = __builtin_amdgcn_readfirstlane(waitcol[slot]);
-        if (wc >= 0) {  // cheap probe of the latest-produced dependency, backing off
-          unsigned spins = 0;
-          while (!is_ready(ld_poll(&out[(int64_t)wc << 6]))) {
-            if (spins < 8)
-              __builtin_amdgcn_s_sleep(2);
-            else if (spins < 64)
-              __builtin_amdgcn_s_sleep(8);
-            else
-              __builtin_amdgcn_s_sleep(32);
-            if ((++spins & 255u) == 0) {
-              if (spins > (1u << 22) || __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                if (lane == 0) __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
-              }
-            }
-          }
-        }
-        if (!trsv_row_r64<T, 1, LOWER>(slot, ptr, col, val, nullptr, rowid, d, rhs, out, out2, lane, nullptr, 0, errflag))
-          return;
-      }
-    } else
-    for (int32_t base = s0; base < s1; base += lm.G) {
-      const int32_t slot = base + lm.g;
-      const bool active = slot < s1;
-      int64_t i = 0;
-      int32_t k = 0, k1 = 0, wc = -1;
-      T acc = vzero(T());
-      if (active) {
-        i = rowid[slot];
-        k = ptr[slot];
-        k1 = ptr[slot + 1];
-        wc = waitcol[slot];
-        acc = rhs[(i << logR) + lm.c];
-      }
-      // cheap probe of the latest-produced dependency: one 8-byte poll per row group, backing off
-      {
-        const bool prober = active && wc >= 0 && lm.c == 0;
-        unsigned spins = 0;
-        for (;;) {
-          bool ok = true;
-          if (prober) ok = is_ready(ld_poll(&out[(int64_t)wc << logR]));
-          if (__all(ok)) break;
-          if (spins < 8)
-            __builtin_amdgcn_s_sleep(2);
-          else if (spins < 64)
-            __builtin_amdgcn_s_sleep(8);
-          else
-            __builtin_amdgcn_s_sleep(32);
-          if ((++spins & 255u) == 0) {
-            if (spins > (1u << 22) || __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-              if (lane == 0) __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              return;
-            }
-          }
-        }
-      }
-      while (__any(k < k1)) {
-        const int nb = min(4, k1 - k);  // <= 0 for lanes that are done
-        int32_t j[4];
-        T a[4], x[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          j[b] = 0;
-          a[b] = vzero(T());
-          if (b < nb) {
-            j[b] = col[k + b];
-            a[b] = val[k + b];
-          }
-        }
-        unsigned spins = 0;
-        for (;;) {
-          bool ok = true;
-#pragma unroll
-          for (int b = 0; b < 4; ++b)
-            if (b < nb) {
-              x[b] = ld_poll(&out[((int64_t)j[b] << logR) + lm.c]);
-              ok = ok && is_ready(x[b]);
-            }
-          if (__all(ok)) break;
-          __builtin_amdgcn_s_sleep(4);
-          if ((++spins & 255u) == 0) {
-            if (spins > (1u << 22) || __hip_atomic_load(errflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-              if (lane == 0) __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              return;
-            }
-          }
-        }
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-          if (b < nb) acc = vsub(acc, vmul(a[b], x[b]));
-        if (nb > 0) k += nb;
-      }
-      if (active) {
-        st_publish(&out[(i << logR) + lm.c], acc);
-        if (LOWER) out2[(i << logR) + lm.c] = vdiv(acc, d[i]);
-      }
-    }
-    // surplus waves retire where the schedule narrows (waves 0..31 never do: hint >= 32)
-    unsigned nx = nchunks;
-    if (lane == 0) {
-      const unsigned cur = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool stay = cur >= nchunks || gwave < hint[cur];
-      if (stay) nx = atomicAdd(ticket, 1u);
-    }
-    chunk = (unsigned)__builtin_amdgcn_readfirstlane((int)nx);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// A run of thin wavefronts [wf0, wf1) (slots [slot0, wfptr[wf1])), each only a few rows wide.
-// ONE workgroup of 16 waves owns it: dependencies on rows before slot0 were finished by earlier
-// launches (plain loads); dependencies inside the run are handed over through one LDS flag per row
-// with workgroup-scope release/acquire (all waves share this CU's L1/L2 path), i.e. a dependent
-// step costs an L2 round trip instead of a kernel boundary.  In place like k_trsv_wide.
-// A PREFIX launch of k_trsv_wide over the run's rows has already folded in, in exact order, every
-// leading nonzero whose source row lies before the run ([ptr, split)); measured on the reference's
-// 1M-row hierarchies that is ~80-95 % of a run row's nonzeros, so only the short dependent rest
-// [split, end) travels through this single compute unit.
-// srcslot[k] = slot of the row that column col[k] refers to (slot order = schedule order).
-// R = 64: rows are dealt round-robin over the waves in SLOT order (a row only waits for smaller
-// slots, so this cannot deadlock) and streamed through trsv_stream_r64's prefetch pipeline.
+// One BAND of a triangle (host.hpp BandPlan): workgroup wg0 + blockIdx.x owns the slot range of its
+// groups, i.e. a set of whole connected components of the band's dependency graph.  Dependencies on
+// rows before the band were finished by earlier launches (plain loads); dependencies inside the
+// workgroup's own range are handed over through one LDS flag per row with workgroup-scope
+// release/acquire (all waves share this CU's L1/L2 path).  No workgroup ever waits for another
+// one, so any number of them may run in any order.  In place: x[i] holds the rhs on entry and the
+// solution on exit (LOWER also writes v[i] = x[i] / d[i]).
+// R = 64: rows are dealt round-robin over the 16 waves in SLOT order (a row only waits for smaller
+// slots of the same workgroup, so this cannot deadlock) and streamed through trsv_stream_r64.
+// R < 64: a wave takes G = 64/R rows of ONE group (same depth, hence independent) at a time.
+// If the band had a PREFIX pass (k_trsv_wide<.., true>), rows start at split[slot].
 // ---------------------------------------------------------------------------------------------
 #define HIFAMD_TAIL_MAX 16384
 template <class T, bool LOWER>
-__global__ void __launch_bounds__(1024) k_trsv_tail(int32_t wf0, int32_t wf1, const int32_t *__restrict__ wfptr,
+__global__ void __launch_bounds__(1024) k_trsv_band(int32_t wg0, const int32_t *__restrict__ wg_grp_ptr,
+                                                    const int32_t *__restrict__ grp_slot_ptr,
                                                     const int32_t *__restrict__ ptr,
                                                     const int32_t *__restrict__ split,
                                                     const int32_t *__restrict__ col, const T *__restrict__ val,
@@ -621,6 +342,8 @@ __global__ void __launch_bounds__(1024) k_trsv_tail(int32_t wf0, int32_t wf1, co
   const LaneMap lm = lane_map(logR);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int32_t wf0 = wg_grp_ptr[wg0 + blockIdx.x], wf1 = wg_grp_ptr[wg0 + blockIdx.x + 1];
+  const int32_t *wfptr = grp_slot_ptr;
   const int32_t slot0 = wfptr[wf0], slot1 = wfptr[wf1];
   for (int t = threadIdx.x; t < slot1 - slot0; t += blockDim.x) flag[t] = 0;
   __syncthreads();
@@ -693,11 +416,6 @@ __global__ void __launch_bounds__(1024) k_trsv_tail(int32_t wf0, int32_t wf1, co
   }
 }
 
-__global__ void k_zero_u32(unsigned *p, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = 0u;
-}
-
 // ---------------------------------------------------------------------------------------------
 // S3 / S5:  out[i] = s[p[roff+i]] * b[p[roff+i]] - sum_asc A(i,j) x[j],  rows [0, nrows)
 // (accumulate from 0.0 in ascending column order, THEN subtract from the scaled rhs: exactly
@@ -710,8 +428,7 @@ __global__ void __launch_bounds__(256) k_spmm_epi(int64_t nrows, const int32_t *
                                                   const T *__restrict__ bin, int64_t ldb, int nrhs,
                                                   const int32_t *__restrict__ p,
                                                   const double *__restrict__ s, int64_t roff,
-                                                  T *__restrict__ out, int logR,
-                                                  T *__restrict__ reset1, T *__restrict__ reset2) {
+                                                  T *__restrict__ out, int logR) {
   const LaneMap lm = lane_map(logR);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -734,8 +451,6 @@ __global__ void __launch_bounds__(256) k_spmm_epi(int64_t nrows, const int32_t *
     T rhs = vzero(T());
     if (lm.c < nrhs) rhs = vscale(s[src], bin[(int64_t)src * ldb + lm.c]);
     out[(i << logR) + lm.c] = vsub(rhs, acc);
-    if (reset1) reset1[(i << logR) + lm.c] = vsentinel(T());
-    if (reset2) reset2[(i << logR) + lm.c] = vsentinel(T());
   }
 }
 

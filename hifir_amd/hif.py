@@ -145,7 +145,7 @@ class HIF:
         s = np.zeros(16)
         _check(lib().hifamd_stats(self._h, _p(s)))
         keys = ["sum_n", "sum_m", "nnz_LU", "nnz_EF", "dense_n", "B_mat", "B_vec", "wavefronts_L", "wavefronts_U",
-                "launches", "sparse_levels"]
+                "launches", "sparse_levels", "bands", "band_workgroups"]
         return {k: float(s[i]) for i, k in enumerate(keys)}
 
     def algorithmic_bytes(self, nrhs):

@@ -90,7 +90,8 @@ int64_t hifamd_schur_size(HifAmdHdl h);
 int64_t hifamd_schur_rank(HifAmdHdl h);
 /* stats[0..15]: 0 sum n_l, 1 sum m_l, 2 nnz(L)+nnz(U), 3 nnz(E)+nnz(F), 4 dense n, 5 B_mat bytes,
  * 6 B_vec bytes per RHS (SURVEY 8d formula), 7 #wavefronts L (all levels), 8 #wavefronts U,
- * 9 kernel launches per apply at the last captured batch width, 10 sparse levels, 11..15 reserved */
+ * 9 kernel launches per apply at the last captured batch width, 10 sparse levels, 11 bands (L+U, all
+ * levels), 12 band workgroups, 13..15 reserved */
 HifAmdStatus hifamd_stats(HifAmdHdl h, double *stats16);
 /* level schedule of one triangular factor (host-side analysis; usable without a GPU):
  * which = 0 (L_B) / 1 (U_B).  *nwf = number of wavefronts; if order != NULL it receives the m row
