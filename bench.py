@@ -241,6 +241,16 @@ def main():
                 cpu = port
             else:
                 cpu["port_value"] = port["value"]
+        # HBM traffic of one apply from the committed PMC profile of this same command (separate
+        # rocprofv3 --pmc passes, corrected as MI355X_MICROARCH.md prescribes; tests/prof_summarize.py)
+        traffic, traffic_src = None, None
+        if args.params == "default" and args.nx == 1000 and args.nrhs == 64:
+            import glob
+
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+            if cands:
+                traffic = json.load(open(cands[-1])).get("hbm_bytes_per_apply_corrected")
+                traffic_src = os.path.relpath(cands[-1], ROOT)
         line = {
             "metric": "preconditioner applies/sec + achieved HBM GB/s, 1M-row 5-pt Laplacian, nrhs=64",
             "value": r["value"], "unit": "RHS-applies/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -256,7 +266,7 @@ def main():
                        "launches_per_apply": int(st["launches"]) if st["launches"] else None,
                        "parallelism": f"rhs-sharded x{world} (hierarchy replicated)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "one whole batched apply (hipGraph of k_trsv_wide/k_trsv_tail/k_spmm_epi/...)",
                          "algorithmic_bytes": r["balg"], "apply_ms_hip_events": r["dev_ms"]},
             "cpu_baseline": cpu,
