@@ -17,8 +17,8 @@ When the compiled reference is present (oracle/_ref, the GPU box gets it as a pr
 cpu_baseline leg factorizes the matrix with the REAL reference and times the reference's own
 single-RHS solve; the hierarchy it produced is then handed to the HIP path field by field through
 the import ABI -- exactly the deployment contract of INTEGRATION.md (reference factorizes, GPU
-applies), so GPU and CPU numbers refer to the same factors.  Without the reference binary the
-hierarchy comes from the committed fixture generator's natively cached file (--hierarchy file).
+applies), so GPU and CPU numbers refer to the same factors.  For N > 1 rank 0 factorizes and the
+other ranks read the factors from a node-local file (hifir_amd/dist.py).
 """
 import argparse
 import json
@@ -50,29 +50,6 @@ PARAM_SETS = {"default": None, "tuned": dict(tau=1e-2, kappa=5.0, alpha=3.0)}
 
 def hier_cache_path(nx, pname):
     return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"hifir_amd_hier_p2d_{nx}_{pname}.npz")
-
-
-def save_levels(path, levels):
-    d = {"nlevels": len(levels)}
-    for l, lv in enumerate(levels):
-        for k, v in lv.items():
-            d[f"L{l}_{k}"] = np.asarray(v)
-    np.savez(path, **d)
-
-
-def load_levels(path):
-    from util import LEVEL_KEYS
-
-    z = np.load(path)
-    levels = []
-    for l in range(int(z["nlevels"])):
-        lv = {}
-        for k in LEVEL_KEYS:
-            if f"L{l}_{k}" in z.files:
-                v = z[f"L{l}_{k}"]
-                lv[k] = int(v) if v.ndim == 0 else v
-        levels.append(lv)
-    return levels
 
 
 def cpu_baseline_leg(A, pname, budget_s):
@@ -151,10 +128,9 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     import hifir_amd
+    from hifir_amd import dist as hd
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = hd.barrier
 
     A = poisson2d(args.nx)
     n = A.shape[0]
@@ -163,18 +139,15 @@ def main():
         """rank 0 factorizes on the host (reference) and shares the factors through a file."""
         path = hier_cache_path(args.nx, pname)
         cpu = None
+        levels = None
         if rank == 0:
             cpu, levels = cpu_baseline_leg(A, pname, args.cpu_seconds if want_cpu else 0.0)
             if levels is None:
                 if not os.path.exists(path):
                     raise SystemExit("no compiled reference (oracle/_ref) and no cached hierarchy file: "
                                      "cannot build the workload's factors on this machine")
-                levels = load_levels(path)
-            elif world > 1:
-                save_levels(path, levels)
-        barrier()
-        if rank != 0:
-            levels = load_levels(path)
+                levels = hd.load_levels(path)
+        levels = hd.share_levels(levels, path)
         return levels, cpu
 
     def run(pname, want_cpu, steps, warmup):
@@ -196,10 +169,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+        el = hd.max_over_ranks(el, device="cuda")
         # kernel-side duration of one apply: HIP events on the stream the kernels run on
         dev_ms = M.time_apply(B, X, warmup=1, reps=max(5, steps // 2))
         balg = M.algorithmic_bytes(args.nrhs)
@@ -207,13 +177,13 @@ def main():
         # one end-of-batch gather of the solution blocks (not in the per-step data path)
         gather_ms = None
         if world > 1:
-            out = [torch.empty_like(X) for _ in range(world)]
             torch.cuda.synchronize()
             barrier()
             t1 = time.perf_counter()
-            dist.all_gather(out, X)
+            Xall = hd.gather_blocks(X)
             torch.cuda.synchronize()
             gather_ms = 1e3 * (time.perf_counter() - t1)
+            del Xall
         # parity spot check of what was timed: column 0 against the oracle restatement (rank 0)
         parity = None
         if rank == 0 and want_cpu:
