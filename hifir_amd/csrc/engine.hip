@@ -164,6 +164,7 @@ class Engine : public EngineBase {
   uint64_t clock = 0;
   int64_t last_launches = 0;
   bool use_graph = true;
+  int min_logR = 6;
   BandOptions band_opt;  // how triangles are cut into bands (host.hpp)
   DevBuf errflag;        // sticky error word: a bounded spin of k_trsv_band expired
   // IR scratch
@@ -174,6 +175,7 @@ class Engine : public EngineBase {
     // Import and host-side analysis (CCS -> CSR, level schedules, dense QRCP) need no GPU; the
     // device is bound in finalize(), and every compute entry point requires a finalized handle.
     use_graph = env_int("HIFIR_AMD_NO_GRAPH", 0) == 0;
+    min_logR = std::min(6, std::max(0, env_int("HIFIR_AMD_MIN_LOGR", 6)));
     band_opt.thin_rows = env_int("HIFIR_AMD_THIN_ROWS", 32);
     band_opt.band_depth = env_int("HIFIR_AMD_BAND_DEPTH", 32);
     band_opt.max_wgs = env_int("HIFIR_AMD_BAND_WGS", 1024);
@@ -293,6 +295,7 @@ class Engine : public EngineBase {
     max_nrhs = max_nrhs_;
     Rmax = 1;
     while (Rmax < max_nrhs && Rmax < 64) Rmax <<= 1;
+    Rmax = std::max<int64_t>(Rmax, 1LL << min_logR);
     bind_device();
     for (auto &H : host.levels) {
       std::unique_ptr<DevLevel> Lp(new DevLevel());
@@ -374,10 +377,14 @@ class Engine : public EngineBase {
     while ((1LL << l) < R) ++l;
     return l;
   }
-  static int pick_logR(int64_t nrhs) {
+  // Batch width of the arena for nrhs columns.  The R = 64 kernels (one wave per row, software
+  // pipeline) are latency-optimised and measured FASTER than the narrow lane mappings even for a
+  // single right-hand side on the reference's 1M-row hierarchies (27 vs 96 ms default, 5.8 vs 7.5 ms
+  // tuned), so narrow batches are padded up to min_logR (default 6 = always 64 wide).
+  int pick_logR(int64_t nrhs) const {
     int64_t R = 1;
     while (R < nrhs && R < 64) R <<= 1;
-    return log2i(R);
+    return std::max(log2i(R), min_logR);
   }
   static unsigned grid_for(int64_t rows, int logR, int threads = 256) {
     const int64_t G = 64 >> logR, rows_per_block = (threads / 64) * G;
@@ -487,7 +494,7 @@ class Engine : public EngineBase {
     if (!B || !X) throw Error(HIFAMD_NULL_OBJ, "NULL vector");
     if (nrhs < 1) throw Error(HIFAMD_MISMATCHED_SIZES, "nrhs must be >= 1");
     if (ldb < nrhs || ldx < nrhs) throw Error(HIFAMD_MISMATCHED_SIZES, "row stride smaller than nrhs");
-    if (std::min<int64_t>(nrhs, 64) > Rmax)
+    if (std::min<int64_t>(nrhs, 64) > std::max<int64_t>(Rmax, max_nrhs))
       throw Error(HIFAMD_MISMATCHED_SIZES, "batch wider than the max_nrhs given to hifamd_finalize");
     if (B == X) throw Error(HIFAMD_BAD_PREC, "b and x must not alias");
   }

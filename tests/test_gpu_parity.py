@@ -15,9 +15,15 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-12
 
 
-@pytest.fixture(scope="module")
-def cache():
-    return {}
+@pytest.fixture(scope="module", params=[6, 0], ids=["R64", "narrowR"])
+def cache(request):
+    # the engine pads every batch to 64 columns by default; HIFIR_AMD_MIN_LOGR=0 lets the narrow
+    # lane mappings (R = 1, 2, 4, ... rows-per-wave groups) run too -- both must give the same bits
+    import os
+
+    os.environ["HIFIR_AMD_MIN_LOGR"] = str(request.param)
+    yield {}
+    os.environ.pop("HIFIR_AMD_MIN_LOGR", None)
 
 
 def _get(cache, name):
@@ -110,7 +116,9 @@ def test_spmv_bitwise(cache):
     n = len(d["b"])
     rng = np.random.default_rng(5)
     X = rng.uniform(-1, 1, size=(n, 6))
-    Y = M.spmv(torch.from_numpy(X).cuda()).cpu().numpy()
+    Yd = M.spmv(torch.from_numpy(X).cuda())
+    M.sync()  # device-pointer entry points enqueue on the handle's stream and return
+    Y = Yd.cpu().numpy()
     for k in range(6):
         assert np.array_equal(Y[:, k], orc.crs_mv(d["A_indptr"], d["A_indices"], d["A_vals"], X[:, k].copy()))
 
