@@ -194,6 +194,28 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
   T acc = x[((int64_t)i_c << 6) + lane];
   T dd = vzero(T());
   if (LOWER && !PREFIX) dd = d[i_c];
+  // head of the wave's next row: its first item, right-hand side, pivot, and the header two rows
+  // ahead.  MODE 0 issues it while the current row is consumed; MODE 2 only AFTER the current row's
+  // flag is up, because a workgroup-scope release waits for every outstanding vector-memory
+  // operation of the wave (vmcnt(0)) and these cold loads would sit on the dependency chain.
+#define HIFAMD_PREFETCH_NEXT_ROW()                          \
+  do {                                                      \
+    const int32_t kk_ = k_n + lane;                         \
+    if (kk_ < e_n) {                                        \
+      colv2 = col[kk_];                                     \
+      valv2 = val[kk_];                                     \
+      if (MODE == 2) ssv2 = srcslot[kk_];                   \
+    }                                                       \
+    acc2 = x[((int64_t)i_n << 6) + lane];                   \
+    if (LOWER && !PREFIX) dd2 = d[i_n];                     \
+    s_nn = s_n + stride;                                    \
+    has_nn = s_nn < s_end;                                  \
+    if (has_nn) {                                           \
+      i_nn = rfl(rowid[s_nn]);                              \
+      k_nn = HIFAMD_KBEG(s_nn);                             \
+      e_nn = HIFAMD_KEND(s_nn);                             \
+    }                                                       \
+  } while (0)
   for (;;) {
     const int32_t cnt = min(64, e_c - k_c);  // <= 0 for an empty row
     const bool row_done = (k_c + 64 >= e_c);
@@ -209,22 +231,8 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
         valv2 = val[kk];
         if (MODE == 2) ssv2 = srcslot[kk];
       }
-    } else if (has_n) {
-      const int32_t kk = k_n + lane;
-      if (kk < e_n) {
-        colv2 = col[kk];
-        valv2 = val[kk];
-        if (MODE == 2) ssv2 = srcslot[kk];
-      }
-      acc2 = x[((int64_t)i_n << 6) + lane];
-      if (LOWER && !PREFIX) dd2 = d[i_n];
-      s_nn = s_n + stride;
-      has_nn = s_nn < s_end;
-      if (has_nn) {
-        i_nn = rfl(rowid[s_nn]);
-        k_nn = HIFAMD_KBEG(s_nn);
-        e_nn = HIFAMD_KEND(s_nn);
-      }
+    } else if (has_n && MODE != 2) {
+      HIFAMD_PREFETCH_NEXT_ROW();
     }
     // ---- consume the current item in order.  MODE 2: the item's source slots sit one per lane, so
     // ONE LDS instruction polls the flags of all its in-run dependencies; the ready prefix of the
@@ -274,6 +282,7 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
       }
       if (LOWER && !PREFIX) out2[((int64_t)i_c << 6) + lane] = vdiv(acc, dd);
       if (!has_n) break;
+      if (MODE == 2) HIFAMD_PREFETCH_NEXT_ROW();
       s = s_n;
       i_c = i_n;
       k_c = k_n;
