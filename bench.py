@@ -115,6 +115,8 @@ def main():
                          "(examples/advanced/demo_gmreshif.cpp:63-65)")
     ap.add_argument("--secondary", type=int, default=1, help="also time the other parameter set (N=1 only)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of each CPU baseline sample")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
+                                                      "rehearse the N > 1 flow on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -123,9 +125,18 @@ def main():
     import torch
     import torch.distributed as dist
 
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a GPU: the hifir_amd apply path has no CPU fallback")
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks but only {ndev} GPU(s) visible")
+    local_rank = local_rank % ndev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
     torch.cuda.set_device(local_rank)
     import hifir_amd
     from hifir_amd import dist as hd
@@ -169,7 +180,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t0
-        el = hd.max_over_ranks(el, device="cuda")
+        el = hd.max_over_ranks(el, device="cuda" if args.backend == "nccl" else "cpu")
         # kernel-side duration of one apply: HIP events on the stream the kernels run on
         dev_ms = M.time_apply(B, X, warmup=1, reps=max(5, steps // 2))
         balg = M.algorithmic_bytes(args.nrhs)

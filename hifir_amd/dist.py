@@ -89,6 +89,11 @@ def gather_blocks(X):
         return X
     import torch
 
+    if d.get_backend() != "nccl" and X.is_cuda:  # rehearsal backends: stage through the host
+        Xh = X.cpu()
+        out = [torch.empty_like(Xh) for _ in range(d.get_world_size())]
+        d.all_gather(out, Xh.contiguous())
+        return torch.cat(out, dim=1).to(X.device)
     out = [torch.empty_like(X) for _ in range(d.get_world_size())]
     d.all_gather(out, X.contiguous())
     return torch.cat(out, dim=1)
