@@ -89,10 +89,13 @@ struct DevCsr {
   // band plan of a triangle (host.hpp BandPlan); empty for E, F, A
   DevBuf srcslot, split, wg_grp_ptr, grp_slot_ptr;
   std::vector<int32_t> band_wg_ptr, band_slot_ptr;
-  std::vector<uint8_t> band_prefix;
+  std::vector<uint8_t> band_prefix, band_dense;
+  std::vector<int32_t> band_blk_ptr, blk_slot0, blk_slot1;
+  std::vector<int64_t> blk_inv_off;
+  DevBuf tinv;  // explicit inverses of the diagonal blocks of block-dense thin bands
 
   template <class T>
-  void upload(const Csr<T> &A, const BandPlan *P) {
+  void upload(const Csr<T> &A, const BandPlan *P, const std::vector<T> *inv = nullptr) {
     nrows = A.nrows;
     ncols = A.ncols;
     nnz = (int64_t)A.col.size();
@@ -107,6 +110,12 @@ struct DevCsr {
       grp_slot_ptr.upload(P->grp_slot_ptr);
       band_wg_ptr = P->band_wg_ptr;
       band_prefix = P->band_prefix;
+      band_dense = P->band_dense;
+      band_blk_ptr = P->band_blk_ptr;
+      blk_slot0 = P->blk_slot0;
+      blk_slot1 = P->blk_slot1;
+      blk_inv_off = P->blk_inv_off;
+      if (inv) tinv.upload(*inv);
       band_slot_ptr.clear();
       for (size_t b = 0; b < band_wg_ptr.size(); ++b)
         band_slot_ptr.push_back(P->grp_slot_ptr[(size_t)P->wg_grp_ptr[(size_t)band_wg_ptr[b]]]);
@@ -167,6 +176,7 @@ class Engine : public EngineBase {
   int min_logR = 6;
   BandOptions band_opt;  // how triangles are cut into bands (host.hpp)
   DevBuf errflag;        // sticky error word: a bounded spin of k_trsv_band expired
+  DevBuf blk_tmp;        // right-hand side of one diagonal block of a block-dense thin band
   // IR scratch
   DevBuf ir_r, ir_xk, ir_part, stage_b, stage_x;
   int64_t ir_cols = 0;
@@ -181,6 +191,7 @@ class Engine : public EngineBase {
     band_opt.max_wgs = env_int("HIFIR_AMD_BAND_WGS", 1024);
     band_opt.max_comp_weight = env_int("HIFIR_AMD_BAND_WEIGHT", 1024);
     band_opt.max_wg_rows = HIFAMD_TAIL_MAX;
+    band_opt.dense_block = env_int("HIFIR_AMD_DENSE_BLOCK", 512);  // 0: exact sequential thin bands
   }
 
   void bind_device() {
@@ -272,6 +283,8 @@ class Engine : public EngineBase {
     H.Ur = permute_rows(H.Ur, H.Up.order);
     finish_band_plan(H.Lp, H.Lr);
     finish_band_plan(H.Up, H.Ur);
+    build_dense_blocks(H.Lp, H.Lr, band_opt, H.Ltinv);
+    build_dense_blocks(H.Up, H.Ur, band_opt, H.Utinv);
     host.levels.push_back(std::move(H));
   }
 
@@ -303,8 +316,10 @@ class Engine : public EngineBase {
       L.m = H.m;
       L.n = H.n;
       L.F_ncols = H.F_ncols;
-      L.L.upload(H.Lr, &H.Lp);
-      L.U.upload(H.Ur, &H.Up);
+      L.L.upload(H.Lr, &H.Lp, &H.Ltinv);
+      L.U.upload(H.Ur, &H.Up, &H.Utinv);
+      std::vector<T>().swap(H.Ltinv);
+      std::vector<T>().swap(H.Utinv);
       L.E.upload(H.Er, nullptr);
       L.F.upload(H.Fr, nullptr);
       L.d.upload(H.d);
@@ -332,6 +347,7 @@ class Engine : public EngineBase {
     }
     errflag.alloc(sizeof(unsigned));
     HIP_OK(hipMemset(errflag.p, 0, errflag.bytes));
+    if (band_opt.dense_block > 0) blk_tmp.alloc((size_t)band_opt.dense_block * Rmax * sizeof(T));
     HIP_OK(hipDeviceSynchronize());
     finalized = true;
   }
@@ -411,6 +427,11 @@ class Engine : public EngineBase {
                            M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR);
         ++count;
       }
+      if (M.band_dense[b]) {  // block by block: sparse update, then ONE dense product per block
+        for (int32_t q = M.band_blk_ptr[b]; q < M.band_blk_ptr[b + 1]; ++q)
+          launch_dense_block<LOWER>(st, L, M, q, logR, count);
+        continue;
+      }
       hipLaunchKernelGGL((k_trsv_band<D, LOWER>), dim3((unsigned)(g1 - g0)), dim3(1024), 0, st, g0,
                          M.wg_grp_ptr.as<int32_t>(), M.grp_slot_ptr.as<int32_t>(), M.ptr.as<int32_t>(),
                          M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(), M.srcslot.as<int32_t>(),
@@ -418,6 +439,9 @@ class Engine : public EngineBase {
       ++count;
     }
   }
+
+  template <bool LOWER>
+  void launch_dense_block(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t q, int logR, int64_t &count);
 
   void launch_ldu(hipStream_t st, DevLevel &L, int logR, int64_t &count) {
     if (!L.m) return;
@@ -784,14 +808,14 @@ void Engine<T>::launch_masked_add(int64_t n, int64_t nrhs, D *y, int64_t ldy, co
 template <>
 void Engine<double>::launch_dense(hipStream_t st, const double *cin, double *zout, int logR, int64_t rank, int64_t &count) {
   const int nd = (int)dn.n, rk = (int)eff_rank(rank);
-  const unsigned g = (unsigned)((((nd + 15) / 16) + 3) / 4);
+  const unsigned g = (unsigned)((nd + 15) / 16);  // one workgroup per 16-row strip (4 waves split K)
   double *tmp = dn.tmp.as<double>();
   // T1 = Q^H(1:rk, :) c   (rows >= rk come out as zeros and are never read)
   hipLaunchKernelGGL(k_dense_gemm_d, dim3(g), dim3(256), 0, st, nd, rk, nd, 0, dn.QH.as<double>(), nd, cin, logR,
-                     (const int32_t *)nullptr, tmp);
+                     (const int32_t *)nullptr, tmp, (const double *)nullptr, (double *)nullptr);
   // z[jpvt[i]] = sum_{k>=i} Rinv(i,k) T1[k], i < rk; zero rows beyond rk
   hipLaunchKernelGGL(k_dense_gemm_d, dim3(g), dim3(256), 0, st, nd, rk, rk, 1, dn.Rinv.as<double>(), nd, tmp, logR,
-                     dn.jpvt0.as<int32_t>(), zout);
+                     dn.jpvt0.as<int32_t>(), zout, (const double *)nullptr, (double *)nullptr);
   count += 2;
 }
 
@@ -800,9 +824,46 @@ void Engine<zdouble>::launch_dense(hipStream_t st, const cplx *cin, cplx *zout, 
   const int nd = (int)dn.n, rk = (int)eff_rank(rank);
   cplx *tmp = dn.tmp.as<cplx>();
   hipLaunchKernelGGL(k_dense_gemm_z, dim3(grid_for(nd, logR)), dim3(256), 0, st, nd, rk, nd, 0, dn.QH.as<cplx>(), nd, cin,
-                     logR, (const int32_t *)nullptr, tmp);
+                     logR, (const int32_t *)nullptr, tmp, (const cplx *)nullptr, (cplx *)nullptr);
   hipLaunchKernelGGL(k_dense_gemm_z, dim3(grid_for(nd, logR)), dim3(256), 0, st, nd, rk, rk, 1, dn.Rinv.as<cplx>(), nd, tmp,
-                     logR, dn.jpvt0.as<int32_t>(), zout);
+                     logR, dn.jpvt0.as<int32_t>(), zout, (const cplx *)nullptr, (cplx *)nullptr);
+  count += 2;
+}
+
+// one diagonal block of a block-dense thin band: t = rhs - (everything before the block); then
+// x[rows] = Tinv * t on the matrix cores (LOWER: also v = x / d)
+template <>
+template <bool LOWER>
+void Engine<double>::launch_dense_block(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t q, int logR,
+                                        int64_t &count) {
+  const int32_t r0 = M.blk_slot0[(size_t)q], r1 = M.blk_slot1[(size_t)q], nb = r1 - r0;
+  double *x = LOWER ? L.w.as<double>() : L.v.as<double>();
+  double *tb = blk_tmp.as<double>();
+  hipLaunchKernelGGL((k_thin_update<double>), dim3(grid_for(nb, logR)), dim3(256), 0, st, r0, r1, M.ptr.as<int32_t>(),
+                     M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<double>(), M.srcslot.as<int32_t>(),
+                     M.rowid.as<int32_t>(), (const double *)x, tb, logR);
+  const unsigned g = (unsigned)((nb + 15) / 16);
+  hipLaunchKernelGGL(k_dense_gemm_d, dim3(g), dim3(256), 0, st, nb, nb, nb, 2,
+                     M.tinv.as<double>() + M.blk_inv_off[(size_t)q], nb, (const double *)tb, logR,
+                     M.rowid.as<int32_t>() + r0, x, LOWER ? L.d.as<double>() : (const double *)nullptr,
+                     LOWER ? L.v.as<double>() : (double *)nullptr);
+  count += 2;
+}
+
+template <>
+template <bool LOWER>
+void Engine<zdouble>::launch_dense_block(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t q, int logR,
+                                         int64_t &count) {
+  const int32_t r0 = M.blk_slot0[(size_t)q], r1 = M.blk_slot1[(size_t)q], nb = r1 - r0;
+  cplx *x = LOWER ? L.w.as<cplx>() : L.v.as<cplx>();
+  cplx *tb = blk_tmp.as<cplx>();
+  hipLaunchKernelGGL((k_thin_update<cplx>), dim3(grid_for(nb, logR)), dim3(256), 0, st, r0, r1, M.ptr.as<int32_t>(),
+                     M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<cplx>(), M.srcslot.as<int32_t>(),
+                     M.rowid.as<int32_t>(), (const cplx *)x, tb, logR);
+  hipLaunchKernelGGL(k_dense_gemm_z, dim3(grid_for(nb, logR)), dim3(256), 0, st, nb, nb, nb, 2,
+                     M.tinv.as<cplx>() + M.blk_inv_off[(size_t)q], nb, (const cplx *)tb, logR,
+                     M.rowid.as<int32_t>() + r0, x, LOWER ? L.d.as<cplx>() : (const cplx *)nullptr,
+                     LOWER ? L.v.as<cplx>() : (cplx *)nullptr);
   count += 2;
 }
 

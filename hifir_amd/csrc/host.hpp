@@ -24,6 +24,9 @@ struct Error : std::runtime_error {
   Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
 };
 
+inline double abs_(double x) { return std::fabs(x); }
+inline double abs_(const zdouble &x) { return std::abs(x); }
+
 // ---------------------------------------------------------------------------------------------
 // matrices
 // ---------------------------------------------------------------------------------------------
@@ -145,6 +148,11 @@ struct BandPlan {
   std::vector<int32_t> wg_grp_ptr;    // workgroup w owns groups [wg_grp_ptr[w], wg_grp_ptr[w+1])
   std::vector<int32_t> band_wg_ptr;   // band b owns workgroups [band_wg_ptr[b], band_wg_ptr[b+1])
   std::vector<uint8_t> band_prefix;   // band b is preceded by the exact prefix pass
+  // Thin bands solved block by block with explicit inverses of the diagonal blocks (see below):
+  std::vector<uint8_t> band_dense;    // band b uses the block-dense scheme
+  std::vector<int32_t> band_blk_ptr;  // band b owns blocks [band_blk_ptr[b], band_blk_ptr[b+1])
+  std::vector<int32_t> blk_slot0, blk_slot1;  // block -> slot range
+  std::vector<int64_t> blk_inv_off;   // block -> offset of its (rows x rows, column-major) inverse
   std::vector<int32_t> srcslot;       // per nonzero (slot order): slot of the source row
   std::vector<int32_t> split;         // per slot: where the band kernel starts in the row
   int64_t nbands() const { return (int64_t)band_wg_ptr.size() - 1; }
@@ -158,6 +166,9 @@ struct BandOptions {
                                    // than this many nonzeros (a component is served by ONE compute unit)
   int64_t max_wg_rows = 16384;  // LDS flags per workgroup
   int64_t max_wgs = 1024;    // workgroups per band
+  int64_t dense_block = 512; // rows per diagonal block of a block-dense thin band (0 = scheme off)
+  int64_t dense_min_rows = 96;   // thin bands shorter than this stay on the sequential workgroup
+  double dense_max_growth = 1e4; // ... and so do bands whose block inverses grow beyond this
 };
 
 // A: strict triangle in CSR, natural row order (before any permutation); depth from level_schedule.
@@ -229,7 +240,16 @@ BandPlan plan_bands(const Csr<T> &A, const Schedule &S, bool lower, const BandOp
     }
     std::vector<std::vector<int32_t>> wg_rows;
     bool prefix = false;
-    for (;;) {  // (re)try with a shallower band if a component does not fit one workgroup
+    bool thin_single = false;
+    if (thin && w1 - w0 >= 2 && opt.dense_block > 0 &&
+        S.wf_ptr[(size_t)w1] - S.wf_ptr[(size_t)w0] >= opt.dense_min_rows) {
+      // latency-bound tail: keep it as ONE slot range in depth order (candidate for the block-dense scheme)
+      wg_rows.assign(1, std::vector<int32_t>());
+      for (int64_t s = S.wf_ptr[(size_t)w0]; s < S.wf_ptr[(size_t)w1]; ++s) wg_rows[0].push_back(S.order[(size_t)s]);
+      prefix = true;
+      thin_single = true;
+    }
+    for (; !thin_single;) {  // (re)try with a shallower band if a component does not fit one workgroup
       const int64_t s0 = S.wf_ptr[(size_t)w0], s1 = S.wf_ptr[(size_t)w1];
       // ---- connected components of the dependency graph restricted to the band
       for (int64_t s = s0; s < s1; ++s) parent[(size_t)S.order[(size_t)s]] = S.order[(size_t)s];
@@ -337,6 +357,7 @@ BandPlan plan_bands(const Csr<T> &A, const Schedule &S, bool lower, const BandOp
     }
     P.band_wg_ptr.push_back((int32_t)P.wg_grp_ptr.size() - 1);
     P.band_prefix.push_back(prefix ? 1 : 0);
+    P.band_dense.push_back(thin_single ? 1 : 0);
     w0 = w1;
   }
   (void)lower;
@@ -345,6 +366,76 @@ BandPlan plan_bands(const Csr<T> &A, const Schedule &S, bool lower, const BandOp
 }
 
 // After the CSR has been permuted into the band plan's slot order: source slots and split points.
+// Block-dense thin bands.  A thin band is a short, deep, single-component triangular system: hundreds
+// of dependent steps of a few rows each, i.e. pure latency (~2 us per step through LDS flags).  Cut
+// into diagonal blocks of <= dense_block rows it becomes, per block,
+//   (1) an UPDATE with everything outside the block (rows before the band and earlier blocks; all
+//       finished, so it is an ordinary parallel sparse kernel), and
+//   (2) ONE dense product with the explicit inverse of the block's unit triangle on the f64 matrix
+//       cores -- no dependent steps at all inside a block.
+// The inverses are formed here (forward substitution on the identity, O(rows * nnz_in_block)).
+// This changes the order of summation inside thin bands (tolerance-level differences, 1e-15 relative
+// on the hierarchies measured); a band whose inverse entries grow beyond dense_max_growth keeps the
+// sequential scheme, which is backward stable for any factor.
+template <class T>
+void build_dense_blocks(BandPlan &P, const Csr<T> &A, const BandOptions &opt, std::vector<T> &tinv) {
+  P.band_blk_ptr.assign(1, 0);
+  for (int64_t b = 0; b < P.nbands(); ++b) {
+    if (P.band_dense[(size_t)b]) {
+      const int32_t g = P.band_wg_ptr[(size_t)b];
+      const int32_t s0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]], s1 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]];
+      const size_t first_blk = P.blk_slot0.size();
+      const size_t tinv_mark = tinv.size();
+      bool ok = true;
+      for (int32_t r0 = s0; r0 < s1 && ok; r0 += (int32_t)opt.dense_block) {
+        const int32_t r1 = std::min<int32_t>(s1, r0 + (int32_t)opt.dense_block), nb = r1 - r0;
+        const size_t off = tinv.size();
+        tinv.resize(off + (size_t)nb * nb, T(0));
+        T *Y = &tinv[off];  // column-major nb x nb: column c = T_bb^{-1} e_c
+        // the block's own strict triangle, row by row (local column, value)
+        std::vector<int32_t> bp((size_t)nb + 1, 0), bq;
+        std::vector<T> bv;
+        for (int32_t r = 0; r < nb; ++r) {
+          const int32_t s = r0 + r;
+          for (int32_t k = A.ptr[(size_t)s]; k < A.ptr[(size_t)s + 1]; ++k) {
+            const int32_t q = P.srcslot[(size_t)k] - r0;
+            if (q >= 0) {
+              bq.push_back(q);
+              bv.push_back(A.val[(size_t)k]);
+            }
+          }
+          bp[(size_t)r + 1] = (int32_t)bq.size();
+        }
+        double growth = 1.0;
+#pragma omp parallel for schedule(static) reduction(max : growth)
+        for (int32_t c = 0; c < nb; ++c) {
+          T *y = Y + (size_t)c * nb;
+          y[c] = T(1);
+          for (int32_t r = c + 1; r < nb; ++r) {  // y[r] = -sum_{q in [c, r)} T(r,q) y[q]
+            T acc = T(0);
+            for (int32_t k = bp[(size_t)r]; k < bp[(size_t)r + 1]; ++k)
+              if (bq[(size_t)k] >= c) acc += bv[(size_t)k] * y[(size_t)bq[(size_t)k]];
+            y[r] = -acc;
+            growth = std::max(growth, abs_(y[r]));
+          }
+        }
+        if (!(growth <= opt.dense_max_growth)) ok = false;
+        P.blk_slot0.push_back(r0);
+        P.blk_slot1.push_back(r1);
+        P.blk_inv_off.push_back((int64_t)off);
+      }
+      if (!ok) {  // unstable to invert: fall back to the sequential workgroup for this band
+        P.blk_slot0.resize(first_blk);
+        P.blk_slot1.resize(first_blk);
+        P.blk_inv_off.resize(first_blk);
+        tinv.resize(tinv_mark);
+        P.band_dense[(size_t)b] = 0;
+      }
+    }
+    P.band_blk_ptr.push_back((int32_t)P.blk_slot0.size());
+  }
+}
+
 template <class T>
 void finish_band_plan(BandPlan &P, const Csr<T> &A /* rows in slot order */) {
   const int64_t m = A.nrows;
@@ -410,6 +501,7 @@ struct HostLevel {
   Csr<T> Lr, Ur, Er, Fr;
   Schedule Ls, Us;   // plain level schedules (wavefronts), kept for queries
   BandPlan Lp, Up;   // what the device executes
+  std::vector<T> Ltinv, Utinv;  // explicit inverses of the diagonal blocks of block-dense thin bands
 };
 
 // Dense last level: A P = Q R (GEQP3 semantics), numerical rank as QRCP::factorize decides it
@@ -425,8 +517,6 @@ struct HostDense {
   std::vector<T> QH, Rinv;     // explicit operators, column-major
 };
 
-inline double abs_(double x) { return std::fabs(x); }
-inline double abs_(const zdouble &x) { return std::abs(x); }
 inline double conj_(double x) { return x; }
 inline zdouble conj_(const zdouble &x) { return std::conj(x); }
 inline double real_(double x) { return x; }

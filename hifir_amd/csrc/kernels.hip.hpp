@@ -426,6 +426,44 @@ __global__ void __launch_bounds__(1024) k_trsv_band(int32_t wg0, const int32_t *
 }
 
 // ---------------------------------------------------------------------------------------------
+// Block-dense thin bands (host.hpp build_dense_blocks), step (1) for the block of slots [r0, r1):
+//   t[s - r0] = x[row(s)] - sum over the row's nonzeros in [split, end) whose source slot lies
+//               BEFORE the block (rows before the band or in earlier blocks: all finished).
+// Step (2) is k_dense_gemm with the block's explicit inverse.  One row per wave group.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256) k_thin_update(int32_t r0, int32_t r1, const int32_t *__restrict__ ptr,
+                                                     const int32_t *__restrict__ split,
+                                                     const int32_t *__restrict__ col, const T *__restrict__ val,
+                                                     const int32_t *__restrict__ srcslot,
+                                                     const int32_t *__restrict__ rowid, const T *__restrict__ x,
+                                                     T *__restrict__ tbuf, int logR) {
+  const LaneMap lm = lane_map(logR);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t s = r0 + wave * lm.G + lm.g; s < r1; s += nwaves * lm.G) {
+    const int64_t i = rowid[s];
+    const int32_t k0 = split[s], k1 = ptr[s + 1];
+    T acc = x[(i << logR) + lm.c];
+    int32_t k = k0;
+    for (; k + 4 <= k1; k += 4) {
+      const int32_t j0 = col[k], j1 = col[k + 1], j2 = col[k + 2], j3 = col[k + 3];
+      const int32_t q0 = srcslot[k], q1 = srcslot[k + 1], q2 = srcslot[k + 2], q3 = srcslot[k + 3];
+      const T a0 = val[k], a1 = val[k + 1], a2 = val[k + 2], a3 = val[k + 3];
+      const T x0 = x[((int64_t)j0 << logR) + lm.c], x1 = x[((int64_t)j1 << logR) + lm.c];
+      const T x2 = x[((int64_t)j2 << logR) + lm.c], x3 = x[((int64_t)j3 << logR) + lm.c];
+      if (q0 < r0) acc = vsub(acc, vmul(a0, x0));
+      if (q1 < r0) acc = vsub(acc, vmul(a1, x1));
+      if (q2 < r0) acc = vsub(acc, vmul(a2, x2));
+      if (q3 < r0) acc = vsub(acc, vmul(a3, x3));
+    }
+    for (; k < k1; ++k)
+      if (srcslot[k] < r0) acc = vsub(acc, vmul(val[k], x[((int64_t)col[k] << logR) + lm.c]));
+    tbuf[((s - r0) << logR) + lm.c] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // S3 / S5:  out[i] = s[p[roff+i]] * b[p[roff+i]] - sum_asc A(i,j) x[j],  rows [0, nrows)
 // (accumulate from 0.0 in ascending column order, THEN subtract from the scaled rhs: exactly
 //  y = E*work followed by y = s*b - y of prec_solve.hpp:366-368 / :397-399)
@@ -545,15 +583,22 @@ __global__ void __launch_bounds__(256) k_colnorm2_partial(int64_t n, int nrhs, c
 // ---------------------------------------------------------------------------------------------
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(256) k_dense_gemm_d(int mrows_total, int mrows_valid, int kend, int upper,
+// tri: 0 full, 1 upper (k >= row tile start), 2 lower (k < row tile end).  dscale/Out2 (optional):
+// Out2[orow] = result / dscale[orow]  (the fused y /= d of the L solve, prec_solve.hpp:219).
+// One 256-thread workgroup per 16-row strip: its 4 waves split the K range (interleaved blocks of
+// 32), each keeps 8 k-steps of operands in flight (the loop is latency-bound, not MFMA-bound, at
+// these sizes), and the partial tiles are summed through LDS in a fixed order.
+__global__ void __launch_bounds__(256) k_dense_gemm_d(int mrows_total, int mrows_valid, int kend, int tri,
                                                       const double *__restrict__ A, int lda,
                                                       const double *__restrict__ X, int logR,
                                                       const int32_t *__restrict__ rowmap,
-                                                      double *__restrict__ Out) {
+                                                      double *__restrict__ Out,
+                                                      const double *__restrict__ dscale,
+                                                      double *__restrict__ Out2) {
+  __shared__ double red[3][4][4][64];  // partial tiles of waves 1..3: [wave-1][col tile][reg][lane]
   const int lane = threadIdx.x & 63;
-  const int wave = (int)((((int64_t)blockIdx.x * blockDim.x) + threadIdx.x) >> 6);
-  const int i0 = wave * 16;
-  if (i0 >= mrows_total) return;
+  const int wave = threadIdx.x >> 6;
+  const int i0 = blockIdx.x * 16;
   const int R = 1 << logR;
   const int ntile = (R + 15) >> 4;
   const int arow = i0 + (lane & 15);
@@ -561,25 +606,48 @@ __global__ void __launch_bounds__(256) k_dense_gemm_d(int mrows_total, int mrows
   const bool arow_ok = arow < mrows_valid;
   v4f64 acc[4];
   for (int t = 0; t < 4; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
-  const int kbeg = upper ? i0 : 0;  // i0 is a multiple of 16, hence of 4
-  for (int k0 = kbeg; k0 < kend; k0 += 4) {
-    const int k = k0 + kq;
-    const bool kok = k < kend;
-    const double a = (arow_ok && kok) ? A[(int64_t)k * lda + arow] : 0.0;
-    for (int t = 0; t < ntile; ++t) {
-      const int colx = t * 16 + (lane & 15);
-      const double b = (kok && colx < R) ? X[((int64_t)k << logR) + colx] : 0.0;
-      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+  const int kbeg = (tri == 1) ? i0 : 0;  // i0 is a multiple of 16, hence of 4
+  if (tri == 2) kend = min(kend, i0 + 16);
+  constexpr int KU = 8;  // k-steps (of 4) whose operands are loaded before the MFMAs are issued
+  for (int kb = kbeg + wave * (4 * KU); kb < kend; kb += 4 * (4 * KU)) {
+    double a[KU], b[KU][4];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int kk = kb + 4 * u + kq;
+      const bool kok = kk < kend;
+      a[u] = (arow_ok && kok) ? A[(int64_t)kk * lda + arow] : 0.0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int colx = t * 16 + (lane & 15);
+        b[u][t] = (t < ntile && kok && colx < R) ? X[((int64_t)kk << logR) + colx] : 0.0;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < KU; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t < ntile) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u][t], acc[t], 0, 0, 0);
   }
-  for (int t = 0; t < ntile; ++t) {
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave - 1][t][r][lane] = acc[t][r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t >= ntile) continue;
     const int colx = t * 16 + (lane & 15);
-    if (colx >= R) continue;
+#pragma unroll
     for (int r = 0; r < 4; ++r) {
+      const double val = ((acc[t][r] + red[0][t][r][lane]) + red[1][t][r][lane]) + red[2][t][r][lane];
       const int row = i0 + kq + 4 * r;
-      if (row < mrows_total) {
+      if (colx < R && row < mrows_total) {
         const int orow = rowmap ? rowmap[row] : row;
-        Out[((int64_t)orow << logR) + colx] = acc[t][r];
+        Out[((int64_t)orow << logR) + colx] = val;
+        if (Out2) Out2[((int64_t)orow << logR) + colx] = val / dscale[orow];
       }
     }
   }
@@ -587,21 +655,24 @@ __global__ void __launch_bounds__(256) k_dense_gemm_d(int mrows_total, int mrows
 
 // complex dense level: plain wave-per-row-strip VALU version (no complex MFMA on gfx950);
 // one lane per (row, column) pair of a 64/R-row strip, k sequential.
-__global__ void __launch_bounds__(256) k_dense_gemm_z(int mrows_total, int mrows_valid, int kend, int upper,
+__global__ void __launch_bounds__(256) k_dense_gemm_z(int mrows_total, int mrows_valid, int kend, int tri,
                                                       const cplx *__restrict__ A, int lda,
                                                       const cplx *__restrict__ X, int logR,
                                                       const int32_t *__restrict__ rowmap,
-                                                      cplx *__restrict__ Out) {
+                                                      cplx *__restrict__ Out, const cplx *__restrict__ dscale,
+                                                      cplx *__restrict__ Out2) {
   const LaneMap lm = lane_map(logR);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t i = wave * lm.G + lm.g; i < mrows_total; i += nwaves * lm.G) {
     cplx acc{0.0, 0.0};
-    if (i < mrows_valid)
-      for (int k = upper ? (int)i : 0; k < kend; ++k)
-        acc = vadd(acc, vmul(A[(int64_t)k * lda + i], X[((int64_t)k << logR) + lm.c]));
+    if (i < mrows_valid) {
+      const int kb = (tri == 1) ? (int)i : 0, ke = (tri == 2) ? min(kend, (int)i + 1) : kend;
+      for (int k = kb; k < ke; ++k) acc = vadd(acc, vmul(A[(int64_t)k * lda + i], X[((int64_t)k << logR) + lm.c]));
+    }
     const int64_t orow = rowmap ? rowmap[i] : i;
     Out[(orow << logR) + lm.c] = acc;
+    if (Out2) Out2[(orow << logR) + lm.c] = vdiv(acc, dscale[orow]);
   }
 }
 

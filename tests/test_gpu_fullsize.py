@@ -17,13 +17,20 @@ from util import poisson2d, relerr
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref.available(), reason="compiled reference not present")]
 
 
-@pytest.fixture(scope="module")
-def big():
+@pytest.fixture(scope="module", params=["fast", "exact"])
+def big(request):
+    import os
+
+    # "fast" = the default configuration (block-dense thin bands); "exact" keeps the reference's
+    # summation order everywhere (HIFIR_AMD_DENSE_BLOCK=0) and must reproduce the oracle bit for bit
+    os.environ["HIFIR_AMD_DENSE_BLOCK"] = "0" if request.param == "exact" else "512"
     A = poisson2d(1000)
     R = ref.RefHIF(A.indptr, A.indices, A.data, ref.make_params(tau=1e-2, kappa=5.0, alpha=3.0))
     levels = R.levels()
     M = hifir_amd.HIF.from_levels(levels, max_nrhs=64)
     M.set_matrix(A.indptr, A.indices, A.data)
+    os.environ.pop("HIFIR_AMD_DENSE_BLOCK", None)
+    M.exact = request.param == "exact"
     return A, R, levels, M, orc.Oracle(levels)
 
 
@@ -35,7 +42,9 @@ def test_1m_columns_vs_oracle_and_reference(big):
     X = M.solve_mrhs(B)
     for k in (0, 31, 63):
         xo = O.solve(B[:, k].copy())
-        assert np.array_equal(X[:, k], xo)  # sparse-only hierarchy: bit-exact at full size
+        if M.exact:
+            assert np.array_equal(X[:, k], xo)  # sparse-only hierarchy: bit-exact at full size
+        assert relerr(X[:, k], xo) <= 1e-12
     assert relerr(X[:, 5], R.solve(B[:, 5].copy())) <= 1e-12  # the real reference
     # nrhs = 1 (BASELINE config 2) and an odd batch width take different lane mappings: same bits
     assert np.array_equal(M.solve(B[:, 7].copy()), X[:, 7])

@@ -15,15 +15,24 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-12
 
 
-@pytest.fixture(scope="module", params=[6, 0], ids=["R64", "narrowR"])
+MODES = {
+    # name: (HIFIR_AMD_MIN_LOGR, HIFIR_AMD_DENSE_BLOCK)
+    "R64-exact": (6, 0),    # default 64-wide arena, thin bands solved sequentially: reference summation order
+    "narrow-exact": (0, 0), # narrow lane mappings (R = 1, 2, 4, ...): must give the same bits
+    "R64-fast": (6, 512),   # the DEFAULT configuration: thin bands through explicit block inverses (1e-12)
+}
+
+
+@pytest.fixture(scope="module", params=list(MODES), ids=list(MODES))
 def cache(request):
-    # the engine pads every batch to 64 columns by default; HIFIR_AMD_MIN_LOGR=0 lets the narrow
-    # lane mappings (R = 1, 2, 4, ... rows-per-wave groups) run too -- both must give the same bits
     import os
 
-    os.environ["HIFIR_AMD_MIN_LOGR"] = str(request.param)
-    yield {}
+    logr, blk = MODES[request.param]
+    os.environ["HIFIR_AMD_MIN_LOGR"] = str(logr)
+    os.environ["HIFIR_AMD_DENSE_BLOCK"] = str(blk)
+    yield {"exact": blk == 0}
     os.environ.pop("HIFIR_AMD_MIN_LOGR", None)
+    os.environ.pop("HIFIR_AMD_DENSE_BLOCK", None)
 
 
 def _get(cache, name):
@@ -35,8 +44,8 @@ def _get(cache, name):
     return cache[name]
 
 
-def _exact(levels, d):
-    return int(levels[-1].get("dense_n", 0)) == 0 and not np.iscomplexobj(d["b"])
+def _exact(cache, levels, d):
+    return cache["exact"] and int(levels[-1].get("dense_n", 0)) == 0 and not np.iscomplexobj(d["b"])
 
 
 @pytest.mark.parametrize("name", HIER_NAMES)
@@ -45,7 +54,7 @@ def test_solve_single_rhs(cache, name):
     assert M.levels() == len(levels) + (1 if levels[-1].get("dense_n", 0) else 0)
     x = M.solve(d["b"])
     xo = O.solve(d["b"])
-    if _exact(levels, d):
+    if _exact(cache, levels, d):
         assert np.array_equal(x, xo), f"sparse-only hierarchy must be bit-identical, relerr={relerr(x, xo):.3e}"
     assert relerr(x, xo) <= TOL
     assert relerr(x, d["x"]) <= TOL  # the real reference's HIF::solve output
@@ -63,7 +72,7 @@ def test_solve_batch(cache, name, nrhs):
     B[:, 0] = d["b"]
     X = M.solve_mrhs(B)
     Xo = O.solve_batch(B, threads=4)
-    if _exact(levels, d):
+    if _exact(cache, levels, d):
         assert np.array_equal(X, Xo), f"relerr={relerr(X, Xo):.3e}"
     assert relerr(X, Xo) <= TOL
     assert relerr(X[:, 0], d["x"]) <= TOL
