@@ -337,8 +337,13 @@ class Engine : public EngineBase {
     if (host.has_dense) {
       dn.n = host.dense.n;
       dn.rank = host.dense.rank;
-      dn.QH.upload(host.dense.QH);
-      dn.Rinv.upload(host.dense.Rinv);
+      if (sizeof(T) == sizeof(double)) {  // strip-major operands for the MFMA kernel
+        dn.QH.upload(to_strip_layout(host.dense.QH.data(), dn.n, dn.n));
+        dn.Rinv.upload(to_strip_layout(host.dense.Rinv.data(), dn.n, dn.n));
+      } else {
+        dn.QH.upload(host.dense.QH);
+        dn.Rinv.upload(host.dense.Rinv);
+      }
       dn.jpvt0.upload(host.dense.jpvt0);
       dn.tmp.alloc((size_t)dn.n * Rmax * sizeof(T));
       // the explicit operators are only needed on the device from here on

@@ -585,6 +585,9 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 // tri: 0 full, 1 upper (k >= row tile start), 2 lower (k < row tile end).  dscale/Out2 (optional):
 // Out2[orow] = result / dscale[orow]  (the fused y /= d of the L solve, prec_solve.hpp:219).
+// A is stored STRIP-MAJOR (host.hpp to_strip_layout): strip s = rows [16 s, 16 s + 16), element
+// (row, k) at ((s * lda + k) * 16 + row % 16), lda = number of columns -- a strip streams through
+// HBM sequentially, 128 B per k.
 // One 256-thread workgroup per 16-row strip: its 4 waves split the K range (interleaved blocks of
 // 32), each keeps 8 k-steps of operands in flight (the loop is latency-bound, not MFMA-bound, at
 // these sizes), and the partial tiles are summed through LDS in a fixed order.
@@ -615,7 +618,7 @@ __global__ void __launch_bounds__(256) k_dense_gemm_d(int mrows_total, int mrows
     for (int u = 0; u < KU; ++u) {
       const int kk = kb + 4 * u + kq;
       const bool kok = kk < kend;
-      a[u] = (arow_ok && kok) ? A[(int64_t)kk * lda + arow] : 0.0;
+      a[u] = (arow_ok && kok) ? A[((int64_t)blockIdx.x * lda + kk) * 16 + (lane & 15)] : 0.0;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int colx = t * 16 + (lane & 15);
