@@ -611,25 +611,33 @@ __global__ void __launch_bounds__(256) k_dense_gemm_d(int mrows_total, int mrows
   for (int t = 0; t < 4; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
   const int kbeg = (tri == 1) ? i0 : 0;  // i0 is a multiple of 16, hence of 4
   if (tri == 2) kend = min(kend, i0 + 16);
-  constexpr int KU = 8;  // k-steps (of 4) whose operands are loaded before the MFMAs are issued
-  for (int kb = kbeg + wave * (4 * KU); kb < kend; kb += 4 * (4 * KU)) {
-    double a[KU], b[KU][4];
-#pragma unroll
-    for (int u = 0; u < KU; ++u) {
-      const int kk = kb + 4 * u + kq;
-      const bool kok = kk < kend;
-      a[u] = (arow_ok && kok) ? A[((int64_t)blockIdx.x * lda + kk) * 16 + (lane & 15)] : 0.0;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int colx = t * 16 + (lane & 15);
-        b[u][t] = (t < ntile && kok && colx < R) ? X[((int64_t)kk << logR) + colx] : 0.0;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < KU; ++u)
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (t < ntile) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u][t], acc[t], 0, 0, 0);
+  constexpr int KU = 8;  // k-steps (of 4) per operand set; two sets: one in flight, one being multiplied
+  const int kstride = 4 * (4 * KU);
+  double a0[KU], b0[KU][4], a1[KU], b1[KU][4];
+#define HIFAMD_LOAD_SET(aa, bb, kb_)                                                                  \
+  _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                                    \
+    const int kk = (kb_) + 4 * u + kq;                                                                \
+    const bool kok = kk < kend;                                                                       \
+    aa[u] = (arow_ok && kok) ? A[((int64_t)blockIdx.x * lda + kk) * 16 + (lane & 15)] : 0.0;         \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
+      const int colx = t * 16 + (lane & 15);                                                          \
+      bb[u][t] = (t < ntile && kok && colx < R) ? X[((int64_t)kk << logR) + colx] : 0.0;              \
+    }                                                                                                 \
+  }
+#define HIFAMD_MFMA_SET(aa, bb)                                                                       \
+  _Pragma("unroll") for (int u = 0; u < KU; ++u) _Pragma("unroll") for (int t = 0; t < 4; ++t)        \
+    if (t < ntile) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], bb[u][t], acc[t], 0, 0, 0);
+  int kb = kbeg + wave * (4 * KU);
+  if (kb < kend) { HIFAMD_LOAD_SET(a0, b0, kb) }
+  while (kb < kend) {
+    const int kb1 = kb + kstride;
+    if (kb1 < kend) { HIFAMD_LOAD_SET(a1, b1, kb1) }
+    HIFAMD_MFMA_SET(a0, b0)
+    if (kb1 >= kend) break;
+    const int kb2 = kb1 + kstride;
+    if (kb2 < kend) { HIFAMD_LOAD_SET(a0, b0, kb2) }
+    HIFAMD_MFMA_SET(a1, b1)
+    kb = kb2;
   }
   if (wave > 0) {
 #pragma unroll
