@@ -816,10 +816,10 @@ void Engine<double>::launch_dense(hipStream_t st, const double *cin, double *zou
   const unsigned g = (unsigned)((nd + 15) / 16);  // one workgroup per 16-row strip (4 waves split K)
   double *tmp = dn.tmp.as<double>();
   // T1 = Q^H(1:rk, :) c   (rows >= rk come out as zeros and are never read)
-  hipLaunchKernelGGL(k_dense_gemm_d, dim3(g), dim3(256), 0, st, nd, rk, nd, 0, dn.QH.as<double>(), nd, cin, logR,
+  hipLaunchKernelGGL(k_dense_gemm_d, dim3(g, ((1u << logR) + 15) / 16), dim3(256), 0, st, nd, rk, nd, 0, dn.QH.as<double>(), nd, cin, logR,
                      (const int32_t *)nullptr, tmp, (const double *)nullptr, (double *)nullptr);
   // z[jpvt[i]] = sum_{k>=i} Rinv(i,k) T1[k], i < rk; zero rows beyond rk
-  hipLaunchKernelGGL(k_dense_gemm_d, dim3(g), dim3(256), 0, st, nd, rk, rk, 1, dn.Rinv.as<double>(), nd, tmp, logR,
+  hipLaunchKernelGGL(k_dense_gemm_d, dim3(g, ((1u << logR) + 15) / 16), dim3(256), 0, st, nd, rk, rk, 1, dn.Rinv.as<double>(), nd, tmp, logR,
                      dn.jpvt0.as<int32_t>(), zout, (const double *)nullptr, (double *)nullptr);
   count += 2;
 }
@@ -848,7 +848,7 @@ void Engine<double>::launch_dense_block(hipStream_t st, const DevLevel &L, const
                      M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<double>(), M.srcslot.as<int32_t>(),
                      M.rowid.as<int32_t>(), (const double *)x, tb, logR);
   const unsigned g = (unsigned)((nb + 15) / 16);
-  hipLaunchKernelGGL(k_dense_gemm_d, dim3(g), dim3(256), 0, st, nb, nb, nb, 2,
+  hipLaunchKernelGGL(k_dense_gemm_d, dim3(g, ((1u << logR) + 15) / 16), dim3(256), 0, st, nb, nb, nb, 2,
                      M.tinv.as<double>() + M.blk_inv_off[(size_t)q], nb, (const double *)tb, logR,
                      M.rowid.as<int32_t>() + r0, x, LOWER ? L.d.as<double>() : (const double *)nullptr,
                      LOWER ? L.v.as<double>() : (double *)nullptr);

@@ -588,9 +588,10 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // A is stored STRIP-MAJOR (host.hpp to_strip_layout): strip s = rows [16 s, 16 s + 16), element
 // (row, k) at ((s * lda + k) * 16 + row % 16), lda = number of columns -- a strip streams through
 // HBM sequentially, 128 B per k.
-// One 256-thread workgroup per 16-row strip: its 4 waves split the K range (interleaved blocks of
-// 32), each keeps 8 k-steps of operands in flight (the loop is latency-bound, not MFMA-bound, at
-// these sizes), and the partial tiles are summed through LDS in a fixed order.
+// Grid: (16-row strips) x (16-column tiles).  One 256-thread workgroup per 16x16 output tile: its 4
+// waves split the K range (interleaved blocks of 32 k), each keeps two sets of 8 k-steps of operands
+// (one in flight, one being multiplied; the loop is latency-bound at these sizes), and the partial
+// tiles are summed through LDS in a fixed order.
 __global__ void __launch_bounds__(256) k_dense_gemm_d(int mrows_total, int mrows_valid, int kend, int tri,
                                                       const double *__restrict__ A, int lda,
                                                       const double *__restrict__ X, int logR,
@@ -598,35 +599,31 @@ __global__ void __launch_bounds__(256) k_dense_gemm_d(int mrows_total, int mrows
                                                       double *__restrict__ Out,
                                                       const double *__restrict__ dscale,
                                                       double *__restrict__ Out2) {
-  __shared__ double red[3][4][4][64];  // partial tiles of waves 1..3: [wave-1][col tile][reg][lane]
+  __shared__ double red[3][4][64];  // partial tiles of waves 1..3: [wave-1][reg][lane]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int i0 = blockIdx.x * 16;
   const int R = 1 << logR;
-  const int ntile = (R + 15) >> 4;
+  const int colx = blockIdx.y * 16 + (lane & 15);
+  const bool col_ok = colx < R;
   const int arow = i0 + (lane & 15);
   const int kq = lane >> 4;
   const bool arow_ok = arow < mrows_valid;
-  v4f64 acc[4];
-  for (int t = 0; t < 4; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
+  v4f64 acc = v4f64{0.0, 0.0, 0.0, 0.0};
   const int kbeg = (tri == 1) ? i0 : 0;  // i0 is a multiple of 16, hence of 4
   if (tri == 2) kend = min(kend, i0 + 16);
-  constexpr int KU = 8;  // k-steps (of 4) per operand set; two sets: one in flight, one being multiplied
+  constexpr int KU = 8;  // k-steps (of 4) per operand set
   const int kstride = 4 * (4 * KU);
-  double a0[KU], b0[KU][4], a1[KU], b1[KU][4];
-#define HIFAMD_LOAD_SET(aa, bb, kb_)                                                                  \
-  _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                                    \
-    const int kk = (kb_) + 4 * u + kq;                                                                \
-    const bool kok = kk < kend;                                                                       \
-    aa[u] = (arow_ok && kok) ? A[((int64_t)blockIdx.x * lda + kk) * 16 + (lane & 15)] : 0.0;         \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
-      const int colx = t * 16 + (lane & 15);                                                          \
-      bb[u][t] = (t < ntile && kok && colx < R) ? X[((int64_t)kk << logR) + colx] : 0.0;              \
-    }                                                                                                 \
+  double a0[KU], b0[KU], a1[KU], b1[KU];
+#define HIFAMD_LOAD_SET(aa, bb, kb_)                                                          \
+  _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                            \
+    const int kk = (kb_) + 4 * u + kq;                                                        \
+    const bool kok = kk < kend;                                                               \
+    aa[u] = (arow_ok && kok) ? A[((int64_t)blockIdx.x * lda + kk) * 16 + (lane & 15)] : 0.0; \
+    bb[u] = (col_ok && kok) ? X[((int64_t)kk << logR) + colx] : 0.0;                          \
   }
-#define HIFAMD_MFMA_SET(aa, bb)                                                                       \
-  _Pragma("unroll") for (int u = 0; u < KU; ++u) _Pragma("unroll") for (int t = 0; t < 4; ++t)        \
-    if (t < ntile) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], bb[u][t], acc[t], 0, 0, 0);
+#define HIFAMD_MFMA_SET(aa, bb) \
+  _Pragma("unroll") for (int u = 0; u < KU; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], bb[u], acc, 0, 0, 0);
   int kb = kbeg + wave * (4 * KU);
   if (kb < kend) { HIFAMD_LOAD_SET(a0, b0, kb) }
   while (kb < kend) {
@@ -641,25 +638,18 @@ __global__ void __launch_bounds__(256) k_dense_gemm_d(int mrows_total, int mrows
   }
   if (wave > 0) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave - 1][t][r][lane] = acc[t][r];
+    for (int r = 0; r < 4; ++r) red[wave - 1][r][lane] = acc[r];
   }
   __syncthreads();
   if (wave != 0) return;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    if (t >= ntile) continue;
-    const int colx = t * 16 + (lane & 15);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double val = ((acc[t][r] + red[0][t][r][lane]) + red[1][t][r][lane]) + red[2][t][r][lane];
-      const int row = i0 + kq + 4 * r;
-      if (colx < R && row < mrows_total) {
-        const int orow = rowmap ? rowmap[row] : row;
-        Out[((int64_t)orow << logR) + colx] = val;
-        if (Out2) Out2[((int64_t)orow << logR) + colx] = val / dscale[orow];
-      }
+  for (int r = 0; r < 4; ++r) {
+    const double val = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+    const int row = i0 + kq + 4 * r;
+    if (col_ok && row < mrows_total) {
+      const int orow = rowmap ? rowmap[row] : row;
+      Out[((int64_t)orow << logR) + colx] = val;
+      if (Out2) Out2[((int64_t)orow << logR) + colx] = val / dscale[orow];
     }
   }
 }
