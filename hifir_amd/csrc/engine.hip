@@ -186,12 +186,12 @@ class Engine : public EngineBase {
     // device is bound in finalize(), and every compute entry point requires a finalized handle.
     use_graph = env_int("HIFIR_AMD_NO_GRAPH", 0) == 0;
     min_logR = std::min(6, std::max(0, env_int("HIFIR_AMD_MIN_LOGR", 6)));
-    band_opt.thin_rows = env_int("HIFIR_AMD_THIN_ROWS", 32);
+    band_opt.thin_rows = env_int("HIFIR_AMD_THIN_ROWS", 96);
     band_opt.band_depth = env_int("HIFIR_AMD_BAND_DEPTH", 32);
     band_opt.max_wgs = env_int("HIFIR_AMD_BAND_WGS", 1024);
     band_opt.max_comp_weight = env_int("HIFIR_AMD_BAND_WEIGHT", 1024);
     band_opt.max_wg_rows = HIFAMD_TAIL_MAX;
-    band_opt.dense_block = env_int("HIFIR_AMD_DENSE_BLOCK", 512);  // 0: exact sequential thin bands
+    band_opt.dense_block = env_int("HIFIR_AMD_DENSE_BLOCK", 2048);  // 0: exact sequential thin bands
   }
 
   void bind_device() {

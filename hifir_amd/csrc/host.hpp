@@ -171,13 +171,13 @@ struct BandPlan {
 };
 
 struct BandOptions {
-  int64_t thin_rows = 32;    // a wavefront this narrow belongs to a thin run
+  int64_t thin_rows = 96;    // a wavefront this narrow belongs to a thin run
   int64_t band_depth = 32;   // at most this many wavefronts per band outside thin runs
   int64_t max_comp_weight = 1024;  // ... and a band stops growing before one component gets heavier
                                    // than this many nonzeros (a component is served by ONE compute unit)
   int64_t max_wg_rows = 16384;  // LDS flags per workgroup
   int64_t max_wgs = 1024;    // workgroups per band
-  int64_t dense_block = 512; // rows per diagonal block of a block-dense thin band (0 = scheme off)
+  int64_t dense_block = 2048; // rows per diagonal block of a block-dense thin band (0 = scheme off)
   int64_t dense_min_rows = 96;   // thin bands shorter than this stay on the sequential workgroup
   double dense_max_growth = 1e4; // ... and so do bands whose block inverses grow beyond this
 };

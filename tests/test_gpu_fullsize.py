@@ -23,7 +23,7 @@ def big(request):
 
     # "fast" = the default configuration (block-dense thin bands); "exact" keeps the reference's
     # summation order everywhere (HIFIR_AMD_DENSE_BLOCK=0) and must reproduce the oracle bit for bit
-    os.environ["HIFIR_AMD_DENSE_BLOCK"] = "0" if request.param == "exact" else "512"
+    os.environ["HIFIR_AMD_DENSE_BLOCK"] = "0" if request.param == "exact" else "2048"
     A = poisson2d(1000)
     R = ref.RefHIF(A.indptr, A.indices, A.data, ref.make_params(tau=1e-2, kappa=5.0, alpha=3.0))
     levels = R.levels()

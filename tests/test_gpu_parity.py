@@ -19,7 +19,7 @@ MODES = {
     # name: (HIFIR_AMD_MIN_LOGR, HIFIR_AMD_DENSE_BLOCK)
     "R64-exact": (6, 0),    # default 64-wide arena, thin bands solved sequentially: reference summation order
     "narrow-exact": (0, 0), # narrow lane mappings (R = 1, 2, 4, ...): must give the same bits
-    "R64-fast": (6, 512),   # the DEFAULT configuration: thin bands through explicit block inverses (1e-12)
+    "R64-fast": (6, 2048),   # the DEFAULT configuration: thin bands through explicit block inverses (1e-12)
 }
 
 
