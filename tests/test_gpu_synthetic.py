@@ -1,0 +1,112 @@
+"""GPU (-m gpu): synthetic hierarchies that no factorization would produce, to reach the corners of
+the band planner and of the apply driver: very deep chains (1 row per wavefront), a thin run whose
+block inverse blows up (must fall back to the sequential, backward-stable scheme), random
+multi-level hierarchies with random permutations/scalings, empty blocks (m = 0, m = n, F absent)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import hifir_amd
+from oracle import orc
+from util import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _ccs(A):
+    A = sp.csc_matrix(A)
+    A.sort_indices()
+    return A.indptr.astype(np.int64), A.indices.astype(np.int32), A.data.astype(np.float64)
+
+
+def _level(m, n, L, U, E, F, rng, with_F=True):
+    lv = dict(m=m, n=n)
+    for k, M in (("L", L), ("U", U), ("E", E), ("F", F)):
+        cp, ri, v = _ccs(M)
+        lv[k + "_colptr"], lv[k + "_rowind"], lv[k + "_vals"] = cp, ri, v
+    if not with_F:
+        lv["F_colptr"], lv["F_rowind"], lv["F_vals"] = np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0)
+    lv["d"] = rng.uniform(0.5, 2.0, m) * rng.choice([-1.0, 1.0], m)
+    lv["s"], lv["t"] = rng.uniform(0.5, 2.0, n), rng.uniform(0.5, 2.0, n)
+    lv["p"] = rng.permutation(n).astype(np.int32)
+    lv["q"] = rng.permutation(n).astype(np.int32)
+    lv["p_inv"] = np.argsort(lv["p"]).astype(np.int32)
+    lv["q_inv"] = np.argsort(lv["q"]).astype(np.int32)
+    return lv
+
+
+def _rand_tri(m, density, lower, rng, scale=0.3):
+    A = sp.random(m, m, density=density, random_state=np.random.RandomState(rng.integers(1 << 30)), format="csr")
+    A.data = rng.uniform(-scale, scale, A.nnz)
+    return sp.tril(A, -1) if lower else sp.triu(A, 1)
+
+
+def _check(levels, nrhs, exact_expected, tol=1e-12, seed=0):
+    M = hifir_amd.HIF.from_levels(levels, max_nrhs=min(nrhs, 64))
+    O = orc.Oracle(levels)
+    n = int(levels[0]["n"])
+    B = np.random.default_rng(seed).uniform(-1, 1, size=(n, nrhs))
+    X, Xo = M.solve_mrhs(B), O.solve_batch(B, threads=4)
+    if exact_expected:
+        assert np.array_equal(X, Xo), relerr(X, Xo)
+    assert relerr(X, Xo) <= tol
+    return M
+
+
+@pytest.mark.parametrize("coef,exact", [(-2.0, True), (-0.5, False)])
+def test_deep_chain_and_growth_fallback(coef, exact):
+    # L = I + coef * subdiagonal: 400 wavefronts of one row each.  coef = -2: the block inverse has
+    # entries up to 2^399 -> the planner must keep the sequential scheme (then bit-exact);
+    # coef = -0.5: benign -> block-dense path (tolerance).
+    m = 400
+    rng = np.random.default_rng(1)
+    L = sp.diags([np.full(m - 1, coef)], [-1], shape=(m, m))
+    # same for U (coef = -2: |x| grows to ~2^800 < 1.8e308, still finite)
+    U = sp.diags([np.full(m - 1, coef)], [1], shape=(m, m)) if coef == -2.0 else \
+        sp.diags([rng.uniform(-0.4, 0.4, m - 1)], [1], shape=(m, m))
+    lv = _level(m, m, L, U, sp.csr_matrix((0, m)), sp.csr_matrix((m, 0)), rng)
+    lv["d"] = np.ones(m)
+    _check([lv], 64, exact_expected=exact)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_two_level_hierarchy_with_dense_tail(seed):
+    rng = np.random.default_rng(seed)
+    n0, m0 = 3000, 2300
+    n1, m1 = n0 - m0, 520
+    nd = n1 - m1
+    lv0 = _level(m0, n0, _rand_tri(m0, 0.004, True, rng), _rand_tri(m0, 0.004, False, rng),
+                 sp.random(n0 - m0, m0, density=0.01, random_state=np.random.RandomState(seed), format="csr"),
+                 sp.random(m0, n0 - m0, density=0.01, random_state=np.random.RandomState(seed + 7), format="csr"), rng)
+    lv1 = _level(m1, n1, _rand_tri(m1, 0.02, True, rng), _rand_tri(m1, 0.02, False, rng),
+                 sp.random(nd, m1, density=0.05, random_state=np.random.RandomState(seed + 1), format="csr"),
+                 sp.random(m1, nd, density=0.05, random_state=np.random.RandomState(seed + 2), format="csr"), rng)
+    D = rng.normal(size=(nd, nd)) + 4.0 * np.eye(nd)
+    lv1["dense_n"], lv1["dense"] = nd, D.ravel(order="F")
+    for nrhs in (1, 7, 64):
+        _check([lv0, lv1], nrhs, exact_expected=False, tol=1e-12, seed=seed)
+
+
+def test_degenerate_shapes():
+    rng = np.random.default_rng(5)
+    # (a) m == n: last level without dense block, single LDU
+    m = 257
+    a = _level(m, m, _rand_tri(m, 0.05, True, rng), _rand_tri(m, 0.05, False, rng), sp.csr_matrix((0, m)),
+               sp.csr_matrix((m, 0)), rng)
+    _check([a], 5, exact_expected=False)
+    # (b) F absent although n > m (prec_solve.hpp:400-403), dense tail
+    n, m = 300, 200
+    b = _level(m, n, _rand_tri(m, 0.05, True, rng), _rand_tri(m, 0.05, False, rng),
+               sp.random(n - m, m, density=0.1, random_state=np.random.RandomState(3), format="csr"),
+               sp.csr_matrix((m, 0)), rng, with_F=False)
+    b["dense_n"], b["dense"] = n - m, (rng.normal(size=(n - m, n - m)) + 5 * np.eye(n - m)).ravel(order="F")
+    _check([b], 9, exact_expected=False)
+    # (c) m == 0: everything deferred to the dense block
+    n = 64
+    c = _level(0, n, sp.csr_matrix((0, 0)), sp.csr_matrix((0, 0)), sp.csr_matrix((n, 0)), sp.csr_matrix((0, n)), rng)
+    c["dense_n"], c["dense"] = n, (rng.normal(size=(n, n)) + 6 * np.eye(n)).ravel(order="F")
+    _check([c], 3, exact_expected=False)
+    # (d) empty triangles (diagonal leading block): one wavefront
+    m = 1000
+    d = _level(m, m, sp.csr_matrix((m, m)), sp.csr_matrix((m, m)), sp.csr_matrix((0, m)), sp.csr_matrix((m, 0)), rng)
+    _check([d], 64, exact_expected=True)
