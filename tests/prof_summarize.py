@@ -37,6 +37,36 @@ def pmc(path, counter):
     return napply, {k: v / napply for k, v in by.items()}
 
 
+# agreement check the bench contract asks for: kernel time of one apply from the rocprof trace of
+# the same command vs the HIP-event time bench.py reports in its JSON line
+kt = one("stats/*/*kernel_trace.csv")
+if kt and os.path.exists(bj):
+    rows = sorted(csv.DictReader(open(kt)), key=lambda r: int(r["Start_Timestamp"]))
+    # one apply = from the level-0 S1 gather (a k_gather_scale NOT preceded by the S3 k_spmm_epi of the
+    # level above) to the level-0 S7 scatter (a k_scatter_scale NOT followed by an S5 k_spmm_epi).
+    # Graph replays run the nodes back to back, so the span is the sum of the node durations.  The
+    # primary workload's applies come first in the run (bench.py order).
+    spans, cnts, start, n = [], [], None, 0
+    for i, r in enumerate(rows):
+        name = r["Kernel_Name"]
+        if "k_gather_scale" in name and (i == 0 or "k_spmm_epi" not in rows[i - 1]["Kernel_Name"]):
+            start, n = int(r["Start_Timestamp"]), 0
+        n += 1
+        if start is not None and "k_scatter_scale" in name and \
+                (i + 1 == len(rows) or "k_spmm_epi" not in rows[i + 1]["Kernel_Name"]):
+            spans.append((int(r["End_Timestamp"]) - start) / 1e6)
+            cnts.append(n)
+            start = None
+    first = [s_ for s_, c_ in zip(spans, cnts) if c_ == cnts[0]]
+    cnt = cnts
+    line = json.loads(open(bj).read().strip().splitlines()[-1])
+    agree = {"applies_in_trace_primary": len(first), "kernels_per_apply": cnt[0],
+             "sum_of_kernel_durations_per_apply_ms_median": sorted(first)[len(first) // 2],
+             "bench_apply_ms_hip_events": line["roofline"]["apply_ms_hip_events"],
+             "bench_ms_per_step_wall": line["ms_per_step"]}
+    json.dump(agree, open(dst + "_apply_time_agreement.json", "w"), indent=1)
+    print(json.dumps(agree))
+
 out = {}
 f, w = one("pmc_fetch/*/*counter_collection.csv"), one("pmc_write/*/*counter_collection.csv")
 if f and w:
