@@ -174,6 +174,7 @@ class Engine : public EngineBase {
   int64_t last_launches = 0;
   bool use_graph = true;
   int min_logR = 6;
+  int gemm_waves = 16;   // split-K width of the block-inverse GEMM
   BandOptions band_opt;  // how triangles are cut into bands (host.hpp)
   DevBuf errflag;        // sticky error word: a bounded spin of k_trsv_band expired
   DevBuf blk_tmp;        // right-hand side of one diagonal block of a block-dense thin band
@@ -186,6 +187,7 @@ class Engine : public EngineBase {
     // device is bound in finalize(), and every compute entry point requires a finalized handle.
     use_graph = env_int("HIFIR_AMD_NO_GRAPH", 0) == 0;
     min_logR = std::min(6, std::max(0, env_int("HIFIR_AMD_MIN_LOGR", 6)));
+    gemm_waves = env_int("HIFIR_AMD_GEMM_WAVES", 16);
     band_opt.thin_rows = env_int("HIFIR_AMD_THIN_ROWS", 96);
     band_opt.band_depth = env_int("HIFIR_AMD_BAND_DEPTH", 32);
     band_opt.max_wgs = env_int("HIFIR_AMD_BAND_WGS", 1024);
@@ -285,6 +287,26 @@ class Engine : public EngineBase {
     finish_band_plan(H.Up, H.Ur);
     build_dense_blocks(H.Lp, H.Lr, band_opt, H.Ltinv);
     build_dense_blocks(H.Up, H.Ur, band_opt, H.Utinv);
+    if (env_int("HIFIR_AMD_PLAN_DUMP", 0)) {  // development aid: one line per band
+      for (int tri = 0; tri < 2; ++tri) {
+        const BandPlan &P = tri ? H.Up : H.Lp;
+        const Csr<T> &A = tri ? H.Ur : H.Lr;
+        for (int64_t b = 0; b < P.nbands(); ++b) {
+          const int32_t g0 = P.band_wg_ptr[(size_t)b], g1 = P.band_wg_ptr[(size_t)b + 1];
+          const int32_t s0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g0]], s1 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g1]];
+          int64_t maxnnz = 0, maxdepth = 0, maxrows = 0;
+          for (int32_t g = g0; g < g1; ++g) {
+            const int32_t a = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]], e = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]];
+            maxnnz = std::max<int64_t>(maxnnz, A.ptr[(size_t)e] - A.ptr[(size_t)a]);
+            maxrows = std::max<int64_t>(maxrows, e - a);
+            maxdepth = std::max<int64_t>(maxdepth, P.wg_grp_ptr[(size_t)g + 1] - P.wg_grp_ptr[(size_t)g]);
+          }
+          std::fprintf(stderr, "PLAN level=%zu tri=%c band=%ld rows=%d nnz=%d wgs=%d prefix=%d dense=%d maxwg_nnz=%ld maxwg_rows=%ld maxdepth=%ld\n",
+                       host.levels.size(), tri ? 'U' : 'L', (long)b, s1 - s0, A.ptr[(size_t)s1] - A.ptr[(size_t)s0], g1 - g0,
+                       (int)P.band_prefix[(size_t)b], (int)P.band_dense[(size_t)b], (long)maxnnz, (long)maxrows, (long)maxdepth);
+        }
+      }
+    }
     host.levels.push_back(std::move(H));
   }
 
@@ -352,7 +374,14 @@ class Engine : public EngineBase {
     }
     errflag.alloc(sizeof(unsigned));
     HIP_OK(hipMemset(errflag.p, 0, errflag.bytes));
-    if (band_opt.dense_block > 0) blk_tmp.alloc((size_t)band_opt.dense_block * Rmax * sizeof(T));
+    {
+      const int remap = env_int("HIFIR_AMD_XCD", 1);
+      HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_remap), &remap, sizeof(int)));
+    }
+    if (band_opt.dense_block > 0) {  // +32 rows: the MFMA kernel reads whole 32-k operand sets (masked)
+      blk_tmp.alloc((size_t)(band_opt.dense_block + 32) * Rmax * sizeof(T));
+      HIP_OK(hipMemset(blk_tmp.p, 0, blk_tmp.bytes));
+    }
     HIP_OK(hipDeviceSynchronize());
     finalized = true;
   }
@@ -816,10 +845,10 @@ void Engine<double>::launch_dense(hipStream_t st, const double *cin, double *zou
   const unsigned g = (unsigned)((nd + 15) / 16);  // one workgroup per 16-row strip (4 waves split K)
   double *tmp = dn.tmp.as<double>();
   // T1 = Q^H(1:rk, :) c   (rows >= rk come out as zeros and are never read)
-  hipLaunchKernelGGL(k_dense_gemm_d, dim3(g, ((1u << logR) + 15) / 16), dim3(256), 0, st, nd, rk, nd, 0, dn.QH.as<double>(), nd, cin, logR,
+  hipLaunchKernelGGL(k_dense_gemm_d<4>, dim3(g, ((1u << logR) + 15) / 16), dim3(256), 0, st, nd, rk, nd, 0, dn.QH.as<double>(), nd, cin, logR,
                      (const int32_t *)nullptr, tmp, (const double *)nullptr, (double *)nullptr);
   // z[jpvt[i]] = sum_{k>=i} Rinv(i,k) T1[k], i < rk; zero rows beyond rk
-  hipLaunchKernelGGL(k_dense_gemm_d, dim3(g, ((1u << logR) + 15) / 16), dim3(256), 0, st, nd, rk, rk, 1, dn.Rinv.as<double>(), nd, tmp, logR,
+  hipLaunchKernelGGL(k_dense_gemm_d<4>, dim3(g, ((1u << logR) + 15) / 16), dim3(256), 0, st, nd, rk, rk, 1, dn.Rinv.as<double>(), nd, tmp, logR,
                      dn.jpvt0.as<int32_t>(), zout, (const double *)nullptr, (double *)nullptr);
   count += 2;
 }
@@ -848,10 +877,20 @@ void Engine<double>::launch_dense_block(hipStream_t st, const DevLevel &L, const
                      M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<double>(), M.srcslot.as<int32_t>(),
                      M.rowid.as<int32_t>(), (const double *)x, tb, logR);
   const unsigned g = (unsigned)((nb + 15) / 16);
-  hipLaunchKernelGGL(k_dense_gemm_d, dim3(g, ((1u << logR) + 15) / 16), dim3(256), 0, st, nb, nb, nb, 2,
-                     M.tinv.as<double>() + M.blk_inv_off[(size_t)q], nb, (const double *)tb, logR,
-                     M.rowid.as<int32_t>() + r0, x, LOWER ? L.d.as<double>() : (const double *)nullptr,
-                     LOWER ? L.v.as<double>() : (double *)nullptr);
+const unsigned pairs = (g + 1) / 2;
+#define HIFAMD_BLOCK_GEMM(NW)                                                                                   \
+  hipLaunchKernelGGL(k_tri_gemm_d<NW>, dim3(pairs, ((1u << logR) + 15) / 16), dim3(NW * 64), 0, st, nb,         \
+                     M.tinv.as<double>() + M.blk_inv_off[(size_t)q], (int)round_up32(nb), (const double *)tb,    \
+                     logR, M.rowid.as<int32_t>() + r0, x, LOWER ? L.d.as<double>() : (const double *)nullptr,    \
+                     LOWER ? L.v.as<double>() : (double *)nullptr)
+  if (gemm_waves >= 16) {
+    HIFAMD_BLOCK_GEMM(16);
+  } else if (gemm_waves >= 8) {
+    HIFAMD_BLOCK_GEMM(8);
+  } else {
+    HIFAMD_BLOCK_GEMM(4);
+  }
+#undef HIFAMD_BLOCK_GEMM
   count += 2;
 }
 

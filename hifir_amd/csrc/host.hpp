@@ -27,16 +27,18 @@ struct Error : std::runtime_error {
 inline double abs_(double x) { return std::fabs(x); }
 inline double abs_(const zdouble &x) { return std::abs(x); }
 
-// Column-major (ld = nrows) -> strip-major layout of k_dense_gemm_d: 16-row strips, each stored as
-// [k][16 rows] (rows beyond nrows are zero).
+// Column-major (ld = nrows) -> strip-major layout of the dense MFMA kernels: 16-row strips, each stored
+// as [k][16 rows] with ldk >= ncols columns per strip (rows beyond nrows and columns beyond ncols are zero).
 template <class T>
-std::vector<T> to_strip_layout(const T *colmajor, int64_t nrows, int64_t ncols) {
+std::vector<T> to_strip_layout(const T *colmajor, int64_t nrows, int64_t ncols, int64_t ldk = 0) {
+  if (ldk < ncols) ldk = ncols;
   const int64_t ns = (nrows + 15) / 16;
-  std::vector<T> out((size_t)(ns * ncols * 16), T(0));
+  std::vector<T> out((size_t)(ns * ldk * 16), T(0));
   for (int64_t k = 0; k < ncols; ++k)
-    for (int64_t r = 0; r < nrows; ++r) out[(size_t)(((r >> 4) * ncols + k) * 16 + (r & 15))] = colmajor[r + k * nrows];
+    for (int64_t r = 0; r < nrows; ++r) out[(size_t)(((r >> 4) * ldk + k) * 16 + (r & 15))] = colmajor[r + k * nrows];
   return out;
 }
+inline int64_t round_up32(int64_t x) { return (x + 31) & ~(int64_t)31; }
 
 // ---------------------------------------------------------------------------------------------
 // matrices
@@ -449,7 +451,7 @@ void build_dense_blocks(BandPlan &P, const Csr<T> &A, const BandOptions &opt, st
     std::vector<T> re;
     for (size_t q = 0; q < P.blk_slot0.size(); ++q) {
       const int64_t nb = P.blk_slot1[q] - P.blk_slot0[q];
-      const std::vector<T> st = to_strip_layout(&tinv[(size_t)P.blk_inv_off[q]], nb, nb);
+      const std::vector<T> st = to_strip_layout(&tinv[(size_t)P.blk_inv_off[q]], nb, nb, round_up32(nb));
       P.blk_inv_off[q] = (int64_t)re.size();
       re.insert(re.end(), st.begin(), st.end());
     }

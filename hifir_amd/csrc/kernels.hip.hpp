@@ -52,6 +52,18 @@ __device__ __forceinline__ cplx vdiv(cplx a, cplx b) {
   return cplx{(a.x * r + a.y) / den, (a.y * r - a.x) / den};
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Rows that are neighbours in
+// the matrix share most of the vector rows they gather, so the streaming kernels renumber their
+// workgroups such that every XCD walks ONE contiguous window of rows (a gathered row is then fetched
+// into one L2 instead of up to eight).
+__device__ int g_xcd_remap = 1;
+__device__ __forceinline__ unsigned xcd_block() {
+  const unsigned g = gridDim.x, b = blockIdx.x;
+  if (!g_xcd_remap) return b;
+  const unsigned q = g >> 3, r = g & 7u, x = b & 7u;
+  return x * q + (x < r ? x : r) + (b >> 3);
+}
+
 // lane decomposition
 struct LaneMap {
   int g, c, G;
@@ -74,7 +86,7 @@ __global__ void __launch_bounds__(256) k_gather_scale(const T *__restrict__ bin,
                                                       const double *__restrict__ s, int64_t cnt,
                                                       T *__restrict__ w, int logR) {
   const LaneMap lm = lane_map(logR);
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t i = wave * lm.G + lm.g; i < cnt; i += nwaves * lm.G) {
     const int32_t src = p[i];
@@ -94,7 +106,7 @@ __global__ void __launch_bounds__(256) k_scatter_scale(const T *__restrict__ v,
                                                        T *__restrict__ yout, int64_t ldy, int nrhs,
                                                        int logR) {
   const LaneMap lm = lane_map(logR);
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t i = wave * lm.G + lm.g; i < n; i += nwaves * lm.G) {
     if (lm.c < nrhs) {
@@ -313,7 +325,7 @@ __global__ void __launch_bounds__(256) k_trsv_wide(int64_t s0, int64_t s1, const
                                                    const int32_t *__restrict__ rowid,
                                                    const T *__restrict__ d, T *w, T *v, int logR) {
   const LaneMap lm = lane_map(logR);
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   if (logR == 6) {
     trsv_stream_r64<T, 0, LOWER, PREFIX>((int32_t)(s0 + wave), (int32_t)s1, (int32_t)nwaves, ptr, split, col, val,
@@ -439,7 +451,7 @@ __global__ void __launch_bounds__(256) k_thin_update(int32_t r0, int32_t r1, con
                                                      const int32_t *__restrict__ rowid, const T *__restrict__ x,
                                                      T *__restrict__ tbuf, int logR) {
   const LaneMap lm = lane_map(logR);
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t s = r0 + wave * lm.G + lm.g; s < r1; s += nwaves * lm.G) {
     const int64_t i = rowid[s];
@@ -477,7 +489,7 @@ __global__ void __launch_bounds__(256) k_spmm_epi(int64_t nrows, const int32_t *
                                                   const double *__restrict__ s, int64_t roff,
                                                   T *__restrict__ out, int logR) {
   const LaneMap lm = lane_map(logR);
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t i = wave * lm.G + lm.g; i < nrows; i += nwaves * lm.G) {
     const int32_t k0 = ptr[i], k1 = ptr[i + 1];
@@ -511,7 +523,7 @@ __global__ void __launch_bounds__(256) k_crs_spmm(int64_t nrows, const int32_t *
                                                   int64_t ldx, const T *__restrict__ b, int64_t ldb,
                                                   T *__restrict__ y, int64_t ldy, int nrhs, int logR) {
   const LaneMap lm = lane_map(logR);
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t i = wave * lm.G + lm.g; i < nrows; i += nwaves * lm.G) {
     if (lm.c >= nrhs) continue;
@@ -592,14 +604,15 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // waves split the K range (interleaved blocks of 32 k), each keeps two sets of 8 k-steps of operands
 // (one in flight, one being multiplied; the loop is latency-bound at these sizes), and the partial
 // tiles are summed through LDS in a fixed order.
-__global__ void __launch_bounds__(256) k_dense_gemm_d(int mrows_total, int mrows_valid, int kend, int tri,
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) k_dense_gemm_d(int mrows_total, int mrows_valid, int kend, int tri,
                                                       const double *__restrict__ A, int lda,
                                                       const double *__restrict__ X, int logR,
                                                       const int32_t *__restrict__ rowmap,
                                                       double *__restrict__ Out,
                                                       const double *__restrict__ dscale,
                                                       double *__restrict__ Out2) {
-  __shared__ double red[3][4][64];  // partial tiles of waves 1..3: [wave-1][reg][lane]
+  __shared__ double red[NW - 1][4][64];  // partial tiles of waves 1..NW-1: [wave-1][reg][lane]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int i0 = blockIdx.x * 16;
@@ -613,7 +626,7 @@ __global__ void __launch_bounds__(256) k_dense_gemm_d(int mrows_total, int mrows
   const int kbeg = (tri == 1) ? i0 : 0;  // i0 is a multiple of 16, hence of 4
   if (tri == 2) kend = min(kend, i0 + 16);
   constexpr int KU = 8;  // k-steps (of 4) per operand set
-  const int kstride = 4 * (4 * KU);
+  const int kstride = NW * (4 * KU);
   double a0[KU], b0[KU], a1[KU], b1[KU];
 #define HIFAMD_LOAD_SET(aa, bb, kb_)                                                          \
   _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                            \
@@ -644,12 +657,120 @@ __global__ void __launch_bounds__(256) k_dense_gemm_d(int mrows_total, int mrows
   if (wave != 0) return;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const double val = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+    double val = acc[r];
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) val += red[w][r][lane];
     const int row = i0 + kq + 4 * r;
     if (col_ok && row < mrows_total) {
       const int orow = rowmap ? rowmap[row] : row;
       Out[((int64_t)orow << logR) + colx] = val;
       if (Out2) Out2[((int64_t)orow << logR) + colx] = val / dscale[orow];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block-dense thin bands, step (2): Out[rowmap[r]] = sum_{k<=r} Tinv(r,k) X[k] for one diagonal block
+// (nb rows), Tinv = explicit inverse of the block's unit lower triangle, strip-major with
+// lda = nb rounded up to 32 (zero padded; everything right of the diagonal is zero too).
+// The product is MFMA-bound on gfx950 (v_mfma_f64_16x16x4_f64 occupies a SIMD for 64 cycles) and the
+// triangle makes strip s cost s+1 units, so workgroup p owns the PAIR of strips (p, S-1-p): every
+// workgroup then carries the same S+1 units and the grid is (pairs) x (16-column tiles) -- 256
+// workgroups for a 2048-row block at 64 columns, one per compute unit.  The NW waves deal the
+// pair's 32-k operand sets round-robin (split-K); a set is 8 A- and 8 B-fragments kept in registers,
+// one set in flight while the previous one is multiplied, two accumulators per strip so that
+// consecutive MFMAs do not wait for each other.  Partial tiles are summed through LDS in a fixed
+// order (deterministic).  X must have nb rounded up to 32 readable rows (padding rows are masked).
+// ---------------------------------------------------------------------------------------------
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) k_tri_gemm_d(int nb, const double *__restrict__ A, int lda,
+                                                        const double *__restrict__ X, int logR,
+                                                        const int32_t *__restrict__ rowmap,
+                                                        double *__restrict__ Out,
+                                                        const double *__restrict__ dscale,
+                                                        double *__restrict__ Out2) {
+  __shared__ double red[NW - 1][2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int S = (nb + 15) >> 4;
+  const int sA = blockIdx.x, sB = S - 1 - (int)blockIdx.x;
+  const bool two = sB > sA;
+  const int R = 1 << logR;
+  const int colx = blockIdx.y * 16 + (lane & 15);
+  const bool col_ok = colx < R;
+  const int colc = col_ok ? colx : 0;
+  const int kq = lane >> 4;
+  const int nsA = (min(nb, 16 * (sA + 1)) + 31) >> 5;
+  const int nsB = two ? (min(nb, 16 * (sB + 1)) + 31) >> 5 : 0;
+  const int nsets = nsA + nsB;
+  const double *Xl = X + colc;
+  const double *A_a = A + ((int64_t)sA * lda) * 16 + (lane & 15);
+  const double *A_b = A + ((int64_t)(two ? sB : sA) * lda) * 16 + (lane & 15);
+  v4f64 accA0 = v4f64{0.0, 0.0, 0.0, 0.0}, accA1 = accA0, accB0 = accA0, accB1 = accA0;
+  constexpr int KU = 8;
+  double a0[KU], b0[KU], a1[KU], b1[KU];
+#define HIFAMD_TG_LOAD(aa, bb, t_)                                                   \
+  {                                                                                  \
+    const bool isB_ = (t_) >= nsA;                                                   \
+    const int kb_ = 32 * (isB_ ? (t_) - nsA : (t_)) + kq;                            \
+    const double *ap_ = (isB_ ? A_b : A_a) + (int64_t)kb_ * 16;                      \
+    const double *xp_ = Xl + ((int64_t)kb_ << logR);                                 \
+    _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                 \
+      aa[u] = ap_[u * 64];                                                           \
+      const double xv_ = xp_[(int64_t)(4 * u) << logR];                              \
+      bb[u] = (kb_ + 4 * u < nb) ? xv_ : 0.0;                                        \
+    }                                                                                \
+  }
+#define HIFAMD_TG_MFMA(aa, bb, t_)                                                                 \
+  if ((t_) >= nsA) {                                                                               \
+    _Pragma("unroll") for (int u = 0; u < KU; u += 2) {                                            \
+      accB0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], bb[u], accB0, 0, 0, 0);                  \
+      accB1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u + 1], bb[u + 1], accB1, 0, 0, 0);          \
+    }                                                                                              \
+  } else {                                                                                         \
+    _Pragma("unroll") for (int u = 0; u < KU; u += 2) {                                            \
+      accA0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], bb[u], accA0, 0, 0, 0);                  \
+      accA1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u + 1], bb[u + 1], accA1, 0, 0, 0);          \
+    }                                                                                              \
+  }
+  int t = wave;
+  if (t < nsets) HIFAMD_TG_LOAD(a0, b0, t)
+  while (t < nsets) {
+    const int t1 = t + NW;
+    if (t1 < nsets) HIFAMD_TG_LOAD(a1, b1, t1)
+    HIFAMD_TG_MFMA(a0, b0, t)
+    if (t1 >= nsets) break;
+    const int t2 = t1 + NW;
+    if (t2 < nsets) HIFAMD_TG_LOAD(a0, b0, t2)
+    HIFAMD_TG_MFMA(a1, b1, t1)
+    t = t2;
+  }
+#undef HIFAMD_TG_LOAD
+#undef HIFAMD_TG_MFMA
+  const v4f64 accA = accA0 + accA1, accB = accB0 + accB1;
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[wave - 1][0][r][lane] = accA[r];
+      red[wave - 1][1][r][lane] = accB[r];
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h == 1 && !two) break;
+    const int i0 = 16 * (h ? sB : sA);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double val = h ? accB[r] : accA[r];
+#pragma unroll
+      for (int w = 0; w < NW - 1; ++w) val += red[w][h][r][lane];
+      const int row = i0 + kq + 4 * r;
+      if (col_ok && row < nb) {
+        const int orow = rowmap ? rowmap[row] : row;
+        Out[((int64_t)orow << logR) + colx] = val;
+        if (Out2) Out2[((int64_t)orow << logR) + colx] = val / dscale[orow];
+      }
     }
   }
 }
@@ -663,7 +784,7 @@ __global__ void __launch_bounds__(256) k_dense_gemm_z(int mrows_total, int mrows
                                                       cplx *__restrict__ Out, const cplx *__restrict__ dscale,
                                                       cplx *__restrict__ Out2) {
   const LaneMap lm = lane_map(logR);
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t i = wave * lm.G + lm.g; i < mrows_total; i += nwaves * lm.G) {
     cplx acc{0.0, 0.0};
