@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhifir_amd.so")
+LIB_PATH = os.environ.get("HIFIR_AMD_LIB") or os.path.join(_HERE, "libhifir_amd.so")  # override: development only
 
 # name -> (restype, argtypes); mirrors include/hifir_amd.h one to one
 _vp, _i64, _int, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_double
