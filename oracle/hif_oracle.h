@@ -1,7 +1,7 @@
 /* oracle/hif_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  *
  * Plain-C CPU restatement of the reference's preconditioner-apply hot path (HIFIR v0.2.0,
- * /root/reference): prec_solve + its CCS kernels + dense QRCP last level + prec_prod (round-trip
+ * /root/reference): prec_solve / prec_solve_tran + their CCS kernels + dense QRCP last level + prec_prod (round-trip
  * checker) + iterative refinement + CRS SpMV.  Every function in hif_oracle_impl.inc cites the
  * reference file:line it follows.  PARITY STATUS: PINNED -- validated (tests/test_oracle_vs_ref.py,
  * run where oracle/_ref/libhifref.so exists) bit-for-bit on all sparse stages against the real
@@ -41,19 +41,24 @@ extern "C" {
   int orc_##P##_solve(void *h, const T *b, T *x, int64_t rank);                                     \
   /* B,X row-interleaved [n][nrhs] (CompressedStorage.hpp:2127); column-by-column solve */          \
   int orc_##P##_solve_batch(void *h, const T *B, T *X, int64_t nrhs, int64_t rank, int threads);    \
+  /* x = M^{-H} b: HIF::solve(b, x, trans = true) -> prec_solve_tran (alg/prec_solve.hpp:542-612) */  \
+  int orc_##P##_solve_tran(void *h, const T *b, T *x, int64_t rank);                                \
+  int orc_##P##_solve_tran_batch(void *h, const T *B, T *X, int64_t nrhs, int64_t rank,             \
+                                 int threads);                                                      \
   int orc_##P##_mmultiply(void *h, const T *x, T *y, int64_t rank);                                 \
   int orc_##P##_hifir(void *h, int64_t n, const int64_t *ip, const int *ind, const T *v,            \
                       const T *b, int nirs, const double *betas, int64_t rank, T *x,                \
                       int *ir_status);                                                              \
   void orc_##P##_crs_mv(int64_t n, const int64_t *ip, const int *ind, const T *v, const T *x,       \
                         T *y);                                                                      \
-  /* raw CCS kernels; op 0 strict-lower solve, 1 strict-upper solve, 2 y = A x */                   \
+  /* raw CCS kernels; op 0 strict-lower solve, 1 strict-upper solve, 2 y = A x, 3 / 4 the two    */   \
+  /* solves with the conjugate transpose, 5 y = A^H x */                                            \
   void orc_##P##_ccs_kernel(int op, int64_t nrows, int64_t ncols, const int64_t *cp,                \
                             const int *ri, const T *v, const T *x, T *y);                           \
   /* the same three with nrhs interleaved right-hand sides, [n][nrhs] */                            \
   void orc_##P##_ccs_kernel_mrhs(int op, int64_t nrows, int64_t ncols, const int64_t *cp,           \
                                  const int *ri, const T *v, int64_t nrhs, const T *x, T *y);        \
-  /* dense block alone: QRCP factor + (op 0) solve / (op 1) multiply */                             \
+  /* dense block alone: QRCP factor + (op 0) solve / (op 1) multiply / (op 2) solve with A^H */     \
   int orc_##P##_qrcp(int64_t n, const T *mat, double rrqr_cond, int op, const T *b,                 \
                      int64_t rank_in, T *x, int64_t *rank_out);
 

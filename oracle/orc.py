@@ -43,6 +43,8 @@ def lib():
             g("work_size").restype = C.c_int64
             g("solve").argtypes = [vp, vp, vp, C.c_int64]
             g("solve_batch").argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_int]
+            g("solve_tran").argtypes = [vp, vp, vp, C.c_int64]
+            g("solve_tran_batch").argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_int]
             g("mmultiply").argtypes = [vp, vp, vp, C.c_int64]
             g("hifir").argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int, vp, C.c_int64, vp, vp]
             g("crs_mv").argtypes = [C.c_int64, vp, vp, vp, vp, vp]
@@ -113,17 +115,17 @@ class Oracle:
     def dense_rank(self):
         return self._f("dense_rank")(self.h)
 
-    def solve(self, b, rank=0):
+    def solve(self, b, rank=0, trans=False):
         b = np.ascontiguousarray(b, dtype=self.dtype)
         x = np.zeros_like(b)
-        assert self._f("solve")(self.h, _p(b), _p(x), rank) == 0
+        assert self._f("solve_tran" if trans else "solve")(self.h, _p(b), _p(x), rank) == 0
         return x
 
-    def solve_batch(self, B, rank=0, threads=1):
+    def solve_batch(self, B, rank=0, threads=1, trans=False):
         """B: (n, nrhs) row-interleaved (C-contiguous). Column-by-column solve."""
         B = np.ascontiguousarray(B, dtype=self.dtype)
         X = np.zeros_like(B)
-        assert self._f("solve_batch")(self.h, _p(B), _p(X), B.shape[1], rank, threads) == 0
+        assert self._f("solve_tran_batch" if trans else "solve_batch")(self.h, _p(B), _p(X), B.shape[1], rank, threads) == 0
         return X
 
     def mmultiply(self, x, rank=0):
@@ -157,7 +159,8 @@ def crs_mv(indptr, indices, vals, x):
 
 
 def ccs_kernel(op, nrows, ncols, colptr, rowind, vals, x, nrhs=None):
-    """op 0 strict-lower solve, 1 strict-upper solve, 2 y = A x; nrhs: x is (n, nrhs) interleaved."""
+    """op 0 strict-lower solve, 1 strict-upper solve, 2 y = A x, 3 / 4 the solves with the conjugate
+    transpose, 5 y = A^H x (single RHS only for 3-5); nrhs: x is (n, nrhs) interleaved."""
     k = _kind(vals, x)
     dt = np.complex128 if k == "z" else np.float64
     colptr = np.ascontiguousarray(colptr, dtype=np.int64)
@@ -165,7 +168,7 @@ def ccs_kernel(op, nrows, ncols, colptr, rowind, vals, x, nrhs=None):
     vals = np.ascontiguousarray(vals, dtype=dt)
     x = np.ascontiguousarray(x, dtype=dt)
     if nrhs is None:
-        y = np.zeros(nrows, dtype=dt) if op == 2 else x.copy()
+        y = np.zeros(nrows, dtype=dt) if op == 2 else (np.zeros(ncols, dtype=dt) if op == 5 else x.copy())
         getattr(lib(), f"orc_{k}_ccs_kernel")(op, nrows, ncols, _p(colptr), _p(rowind), _p(vals), _p(x), _p(y))
     else:
         y = np.zeros((nrows, nrhs), dtype=dt) if op == 2 else x.copy()

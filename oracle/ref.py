@@ -39,6 +39,7 @@ def lib():
             getattr(_lib, f"hifref_{k}_level_vectors").argtypes = [C.c_void_p, C.c_int] + [vp] * 7
             getattr(_lib, f"hifref_{k}_level_dense").argtypes = [C.c_void_p, C.c_int, vp]
             getattr(_lib, f"hifref_{k}_solve").argtypes = [C.c_void_p, vp, vp, C.c_int64]
+            getattr(_lib, f"hifref_{k}_solve_tran").argtypes = [C.c_void_p, vp, vp, C.c_int64]
             getattr(_lib, f"hifref_{k}_mmultiply").argtypes = [C.c_void_p, vp, vp, C.c_int64]
             getattr(_lib, f"hifref_{k}_hifir").argtypes = [C.c_void_p, vp, C.c_int, dp, vp, i32p]
             getattr(_lib, f"hifref_{k}_spmv").argtypes = [C.c_size_t, i64p, i32p, vp, vp, vp]
@@ -122,10 +123,11 @@ class RefHIF:
     def levels(self):
         return [self.level(l) for l in range(self.nlevels)]
 
-    def solve(self, b, rank=0):
+    def solve(self, b, rank=0, trans=False):
+        """HIF::solve (builder.hpp:409-423); trans=True: x = M^{-H} b (prec_solve_tran)."""
         b = np.ascontiguousarray(b, dtype=self.dtype)
         x = np.zeros_like(b)
-        if self._f("solve")(self.h, _p(b), _p(x), rank):
+        if self._f("solve_tran" if trans else "solve")(self.h, _p(b), _p(x), rank):
             raise RuntimeError(lib().hifref_error().decode())
         return x
 
@@ -159,7 +161,8 @@ def spmv(indptr, indices, vals, x):
 
 
 def ccs_kernel(op, nrows, ncols, colptr, rowind, vals, x):
-    """op 0: y=x; solve_as_strict_lower(y) | 1: strict_upper | 2: y = A x (CCS multiply_nt_low)."""
+    """op 0: y=x; solve_as_strict_lower(y) | 1: strict_upper | 2: y = A x (CCS multiply_nt_low) |
+    3: solve_as_strict_lower_tran | 4: solve_as_strict_upper_tran | 5: y = A^H x (multiply_t_low)."""
     vals = np.ascontiguousarray(vals)
     k = "z" if (np.iscomplexobj(vals) or np.iscomplexobj(x)) else "d"
     dt = np.complex128 if k == "z" else np.float64
@@ -169,6 +172,8 @@ def ccs_kernel(op, nrows, ncols, colptr, rowind, vals, x):
     x = np.ascontiguousarray(x, dtype=dt)
     if op == 2:
         y = np.zeros(nrows, dtype=dt)
+    elif op == 5:
+        y = np.zeros(ncols, dtype=dt)
     else:
         y = x.copy()
     getattr(lib(), f"hifref_{k}_ccs_kernel")(op, nrows, ncols, _p(colptr), _p(rowind), _p(vals), _p(x), _p(y))
@@ -176,7 +181,7 @@ def ccs_kernel(op, nrows, ncols, colptr, rowind, vals, x):
 
 
 def qrcp(mat_colmajor, b, op=0, rank=0, rrqr_cond=0.0):
-    """hif::QRCP on a dense n x n block (column-major flat array): op 0 solve, 1 multiply.
+    """hif::QRCP on a dense n x n block (column-major flat array): op 0 solve, 1 multiply, 2 solve with A^H.
     Returns (x, numerical_rank)."""
     mat = np.ascontiguousarray(mat_colmajor)
     k = "z" if (np.iscomplexobj(mat) or np.iscomplexobj(b)) else "d"

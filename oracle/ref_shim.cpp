@@ -148,11 +148,11 @@ void level_dense(void *h, int l, T *mat) {
 }
 
 template <class T>
-int do_solve(void *h, const T *b, T *x, int64_t rank) {
+int do_solve(void *h, const T *b, T *x, int64_t rank, bool tran = false) {
   auto *r = (Ref<T> *)h;
   try {
     hif::Array<T> bb(r->n, const_cast<T *>(b), true), xx(r->n, x, true);
-    r->M.solve(bb, xx, false, (size_t)rank);
+    r->M.solve(bb, xx, tran, (size_t)rank);  // tran: prec_solve_tran, alg/prec_solve.hpp:542-612
     return 0;
   } catch (const std::exception &e) {
     g_err = e.what();
@@ -203,7 +203,8 @@ void do_spmv(size_t n, const int64_t *indptr, const int *indices, const T *vals,
 }
 
 // raw CCS kernels on caller data (unit-level validation of the restatement)
-// op: 0 solve_as_strict_lower, 1 solve_as_strict_upper, 2 multiply_nt_low (y = A x)
+// op: 0 solve_as_strict_lower, 1 solve_as_strict_upper, 2 multiply_nt_low (y = A x),
+//     3 solve_as_strict_lower_tran, 4 solve_as_strict_upper_tran, 5 multiply_t_low (y = A^H x)
 template <class T>
 void do_ccs_kernel(int op, size_t nrows, size_t ncols, const int64_t *colptr, const int *rowind,
                    const T *vals, const T *x, T *y) {
@@ -212,12 +213,18 @@ void do_ccs_kernel(int op, size_t nrows, size_t ncols, const int64_t *colptr, co
                                       const_cast<T *>(vals), true);
   if (op == 2) {
     A.multiply_nt_low(x, y);
+  } else if (op == 5) {
+    A.multiply_t_low(x, y);
   } else {
     hif::Array<T> yy(nrows, y, true);
     if (op == 0)
       A.solve_as_strict_lower(yy);
-    else
+    else if (op == 1)
       A.solve_as_strict_upper(yy);
+    else if (op == 3)
+      A.solve_as_strict_lower_tran(yy);
+    else
+      A.solve_as_strict_upper_tran(yy);
   }
 }
 
@@ -240,6 +247,8 @@ int do_qrcp(size_t n, const T *mat, double rrqr_cond, int op, const T *b, int64_
     for (size_t i = 0; i < n; ++i) x[i] = b[i];
     if (op == 0)
       qr.solve(xx, (size_t)rank_in);
+    else if (op == 2)
+      qr.solve(xx, (size_t)rank_in, true);  // _solve_t, small_scale/QRCP.hpp:413-452
     else
       qr.multiply(xx, (size_t)rank_in);
     return 0;
@@ -294,6 +303,12 @@ int hifref_d_solve(void *h, const double *b, double *x, int64_t rank) {
 }
 int hifref_z_solve(void *h, const void *b, void *x, int64_t rank) {
   return do_solve<zt>(h, (const zt *)b, (zt *)x, rank);
+}
+int hifref_d_solve_tran(void *h, const double *b, double *x, int64_t rank) {
+  return do_solve<double>(h, b, x, rank, true);
+}
+int hifref_z_solve_tran(void *h, const void *b, void *x, int64_t rank) {
+  return do_solve<zt>(h, (const zt *)b, (zt *)x, rank, true);
 }
 int hifref_d_mmultiply(void *h, const double *x, double *y, int64_t rank) {
   return do_mmultiply<double>(h, x, y, rank);

@@ -11,7 +11,8 @@ Fixtures are DATA (inputs + expected outputs), never reference source text:
   hier_<name>.npz  a factored hierarchy exported field by field from hif::HIF<> (Prec.hpp:309-323)
                    + the matrix, rhs b, x = HIF::solve(b) (builder.hpp:410), b2 = HIF::mmultiply(x)
                    (:503), x_ir4 = HIF::hifir(A,b,4) (:459), (x_irb, status) = hifir with betas (:482),
-                   and a 4-RHS batch solved column by column.
+                   a 4-RHS batch solved column by column, and xt / XT4 = the same with
+                   trans=true (x = M^{-H} b, prec_solve_tran, alg/prec_solve.hpp:542-612).
 """
 import json
 import os
@@ -111,8 +112,10 @@ def save_hier(name, A, params=None, cplx=False):
     x_irb, st = M.hifir(b, 16, [1e-10, 1e3])
     B = np.stack([b + 0.01 * k for k in range(4)], axis=1)  # (n, 4) row-interleaved
     X = np.stack([M.solve(B[:, k].copy()) for k in range(4)], axis=1)
+    xt = M.solve(b, trans=True)  # x = M^{-H} b: HIF::solve(b, x, true) -> prec_solve_tran (prec_solve.hpp:542)
+    XT = np.stack([M.solve(B[:, k].copy(), trans=True) for k in range(4)], axis=1)
     d = dict(nlevels=M.nlevels, A_indptr=A.indptr.astype(np.int64), A_indices=A.indices.astype(np.int32), A_vals=vals,
-             b=b, x=x, b2=b2, x_ir4=x_ir4, x_irb=x_irb, irb_status=np.array(st, dtype=np.int32), B4=B, X4=X,
+             b=b, x=x, b2=b2, x_ir4=x_ir4, x_irb=x_irb, irb_status=np.array(st, dtype=np.int32), B4=B, X4=X, xt=xt, XT4=XT,
              params=np.zeros(5) if params is None else params)
     for l, lv in enumerate(M.levels()):
         for k, v in lv.items():

@@ -43,6 +43,22 @@ def test_solve_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", HIER_NAMES)
+def test_transposed_solve_matches_reference(name):
+    # x = M^{-H} b: HIF::solve(b, x, trans=true) -> prec_solve_tran (alg/prec_solve.hpp:542-612)
+    levels, d = load_hier(name)
+    O = orc.Oracle(levels)
+    xt = O.solve(d["b"], trans=True)
+    has_dense = levels[-1].get("dense_n", 0) > 0
+    if not has_dense and not np.iscomplexobj(d["b"]):
+        assert np.array_equal(xt, d["xt"]), "sparse-only hierarchy must be bit-identical"
+    assert relerr(xt, d["xt"]) <= 1e-12
+    XT = O.solve_batch(d["B4"], threads=2, trans=True)
+    assert relerr(XT, d["XT4"]) <= 1e-12
+    for k in range(4):
+        assert np.array_equal(XT[:, k], O.solve(d["B4"][:, k].copy(), trans=True))
+
+
+@pytest.mark.parametrize("name", HIER_NAMES)
 def test_batch_is_columnwise(name):
     levels, d = load_hier(name)
     O = orc.Oracle(levels)

@@ -30,12 +30,19 @@ def test_ccs_kernels_bitwise(n):
             y0 = ref.ccs_kernel(op, n, n, A.indptr, A.indices, v, x)
             y1 = orc.ccs_kernel(op, n, n, A.indptr, A.indices, v, x)
             assert np.array_equal(y0, y1)
+            # conjugate-transpose solves (CompressedStorage.hpp:2307-2324, :2399-2413)
+            y0 = ref.ccs_kernel(op + 3, n, n, A.indptr, A.indices, v, x)
+            y1 = orc.ccs_kernel(op + 3, n, n, A.indptr, A.indices, v, x)
+            assert np.array_equal(y0, y1)
         R = sp.random(n + 3, n, density=0.3, random_state=np.random.RandomState(n), format="csc")
         R.sort_indices()
         v = R.data + (1j * rng.uniform(-1, 1, R.nnz) if cplx else 0)
         x = rng.uniform(-1, 1, n) + (1j * rng.uniform(-1, 1, n) if cplx else 0)
         assert np.array_equal(ref.ccs_kernel(2, n + 3, n, R.indptr, R.indices, v, x),
                               orc.ccs_kernel(2, n + 3, n, R.indptr, R.indices, v, x))
+        xt = rng.uniform(-1, 1, n + 3) + (1j * rng.uniform(-1, 1, n + 3) if cplx else 0)
+        assert np.array_equal(ref.ccs_kernel(5, n + 3, n, R.indptr, R.indices, v, xt),  # multiply_t_low :2161
+                              orc.ccs_kernel(5, n + 3, n, R.indptr, R.indices, v, xt))
         C = R.T.tocsr()
         C.sort_indices()
         xs = rng.uniform(-1, 1, n + 3) + (1j * rng.uniform(-1, 1, n + 3) if cplx else 0)
@@ -78,6 +85,11 @@ def test_qrcp_full_and_deficient_rank(cplx):
     y0, _ = ref.qrcp(A.ravel(order="F"), b, op=1)
     y1, _ = orc.qrcp(A.ravel(order="F"), b, op=1)
     assert relerr(y1, y0) <= 1e-12
+    # A^H solves (_solve_t, QRCP.hpp:413-452): full rank, explicit rank, rank-deficient
+    for mat, rk, tol in ((A, 0, 1e-12), (A, 10, 1e-12), (A2, 0, 1e-9)):
+        z0, _ = ref.qrcp(mat.ravel(order="F"), b, op=2, rank=rk)
+        z1, _ = orc.qrcp(mat.ravel(order="F"), b, op=2, rank=rk)
+        assert relerr(z1, z0) <= tol
 
 
 @pytest.mark.parametrize("nx,params", [(40, None), (150, (1e-2, 5.0, 3.0)), (200, None)])
@@ -93,3 +105,7 @@ def test_fresh_hierarchies(nx, params):
     if M.levels()[-1]["dense_n"] == 0:
         assert np.array_equal(x0, x1)
     assert relerr(O.mmultiply(x0), M.mmultiply(x0)) <= 1e-10
+    t0, t1 = M.solve(b, trans=True), O.solve(b, trans=True)
+    assert relerr(t1, t0) <= 1e-12
+    if M.levels()[-1]["dense_n"] == 0:
+        assert np.array_equal(t0, t1)
