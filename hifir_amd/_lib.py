@@ -35,6 +35,8 @@ SIGNATURES = {
     "hifamd_spmv_batch_dev": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _vp]),
     "hifamd_hifir_batch": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _int, _vp, _i64, _vp]),
     "hifamd_hifir_batch_dev": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _int, _vp, _i64, _vp]),
+    "hifamd_apply_batch": (_int, [_vp, _int, _vp, _i64, _vp, _i64, _i64, _int, _vp, _i64, _vp]),
+    "hifamd_apply_batch_dev": (_int, [_vp, _int, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
     "hifamd_time_apply": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _int, _int, _vp]),
     "hifamd_sync": (_int, [_vp]),
 }

@@ -133,6 +133,7 @@ struct DevLevel {
 struct DevDense {
   int64_t n = 0, rank = 0;
   DevBuf QH, Rinv, jpvt0, tmp;
+  DevBuf Qm, RinvH, tmp2;  // adjoint engine only: Q, (R^{-1})^H and the permuted input
 };
 
 struct GraphKey {
@@ -162,9 +163,15 @@ class Engine : public EngineBase {
   typedef typename DevT<T>::type D;
   int device = 0;
   hipStream_t stream = nullptr;
+  bool owns_stream = true;  // the adjoint engine runs on its primary's stream
   bool finalized = false;
   int64_t Rmax = 0, max_nrhs = 0;
   HostHierarchy<T> host;
+  // x = M^{-H} b (HIF::solve(b, x, true), prec_solve_tran, alg/prec_solve.hpp:542-612) is the SAME
+  // machinery applied to the adjoint hierarchy: L' = U^H, U' = L^H, E' = F^H, F' = E^H, d' = conj(d),
+  // (s', p') = (t, q), (t', q_inv') = (s, p_inv), dense block solved with A^H.  Built on first use.
+  bool adjoint = false;
+  std::unique_ptr<Engine<T>> adj;
   std::vector<std::unique_ptr<DevLevel>> lv;
   DevDense dn;
   DevCsr A;
@@ -208,8 +215,9 @@ class Engine : public EngineBase {
 
   ~Engine() override {
     if (stream) (void)hipSetDevice(device);
+    adj.reset();
     clear_graphs();
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream && owns_stream) (void)hipStreamDestroy(stream);
   }
 
   void clear_graphs() {
@@ -277,6 +285,12 @@ class Engine : public EngineBase {
     H.Ur = ccs_to_csr(H.U, true);
     H.Er = ccs_to_csr(H.E, false);
     H.Fr = ccs_to_csr(H.F, false);
+    analyze_level(H);
+    host.levels.push_back(std::move(H));
+  }
+
+  // schedules, band plans, slot-ordered matrices and block inverses of one level (H.Lr .. H.Fr given)
+  void analyze_level(HostLevel<T> &H) {
     H.Ls = level_schedule(H.Lr, true);
     H.Us = level_schedule(H.Ur, false);
     H.Lp = plan_bands(H.Lr, H.Ls, true, band_opt);
@@ -307,7 +321,86 @@ class Engine : public EngineBase {
         }
       }
     }
+  }
+
+  // the adjoint of one imported level (see `adj` above)
+  void add_level_adjoint(const HostLevel<T> &P) {
+    if (P.q.empty() || P.p_inv.empty())
+      throw Error(HIFAMD_BAD_PREC, "the transpose apply needs the q and p_inv permutations (hifamd_add_level)");
+    HostLevel<T> H;
+    H.m = P.m;
+    H.n = P.n;
+    const int64_t nm = P.n - P.m;
+    H.F_ncols = nm;  // E^H prolongs whenever there is a Schur complement (prec_solve.hpp:602)
+    H.Lr = adjoint_rows(P.U);  // U^H: strict lower
+    H.Ur = adjoint_rows(P.L);  // L^H: strict upper
+    if (P.F_ncols) {
+      H.Er = adjoint_rows(P.F);  // F^H: nm x m
+    } else {                     // no F: y[m:n] = t[q] b[q] (:574) -- an empty restriction
+      H.Er.nrows = nm;
+      H.Er.ncols = nm ? P.m : 0;
+      H.Er.ptr.assign((size_t)nm + 1, 0);
+      H.Er.rowid.resize((size_t)nm);
+      for (int64_t i = 0; i < nm; ++i) H.Er.rowid[(size_t)i] = (int32_t)i;
+    }
+    H.Fr = adjoint_rows(P.E);  // E^H: m x nm
+    H.d.resize(P.d.size());
+    for (size_t i = 0; i < P.d.size(); ++i) H.d[i] = conj_(P.d[i]);
+    H.s = P.t;
+    H.t = P.s;
+    H.p = P.q;
+    H.q_inv = P.p_inv;
+    analyze_level(H);
     host.levels.push_back(std::move(H));
+  }
+
+  Engine<T> &adjoint_engine() {
+    if (adjoint) throw Error(HIFAMD_HIFIR_ERROR, "internal error: adjoint of the adjoint engine");
+    if (!finalized) throw Error(HIFAMD_BAD_PREC, "hierarchy not finalized (hifamd_finalize)");
+    if (!adj) {
+      std::unique_ptr<Engine<T>> E(new Engine<T>(device));
+      E->adjoint = true;
+      E->stream = stream;
+      E->owns_stream = false;
+      E->use_graph = use_graph;
+      E->min_logR = min_logR;
+      E->band_opt = band_opt;
+      E->gemm_waves = gemm_waves;
+      for (const auto &P : host.levels) E->add_level_adjoint(P);
+      if (host.has_dense) {
+        E->host.dense.n = host.dense.n;
+        E->host.dense.rank = host.dense.rank;
+        E->host.dense.qr = host.dense.qr;
+        E->host.dense.tau = host.dense.tau;
+        E->host.dense.jpvt0 = host.dense.jpvt0;
+        dense_adjoint_ops(E->host.dense);
+        E->host.has_dense = true;
+      }
+      E->finalize(max_nrhs);
+      if (has_A) E->upload_matrix(adjoint_of_csr(host.A));
+      adj = std::move(E);
+    }
+    return *adj;
+  }
+
+  // conjugate transpose of the user's CRS matrix (for iterative refinement with A^H, IterRefine.hpp:96)
+  static Csr<T> adjoint_of_csr(const Csr<T> &A) {
+    Csr<T> B;
+    B.nrows = A.ncols;
+    B.ncols = A.nrows;
+    B.ptr.assign((size_t)A.ncols + 1, 0);
+    for (size_t k = 0; k < A.col.size(); ++k) ++B.ptr[(size_t)A.col[k] + 1];
+    for (int64_t j = 0; j < A.ncols; ++j) B.ptr[(size_t)j + 1] += B.ptr[(size_t)j];
+    B.col.resize(A.col.size());
+    B.val.resize(A.val.size());
+    std::vector<int32_t> fill(B.ptr.begin(), B.ptr.end() - 1);
+    for (int64_t i = 0; i < A.nrows; ++i)
+      for (int32_t k = A.ptr[(size_t)i]; k < A.ptr[(size_t)i + 1]; ++k) {
+        const int32_t pos = fill[(size_t)A.col[(size_t)k]]++;
+        B.col[(size_t)pos] = (int32_t)i;
+        B.val[(size_t)pos] = conj_(A.val[(size_t)k]);
+      }
+    return B;
   }
 
   void set_dense(int64_t nd, const T *mat, double rrqr_cond) {
@@ -359,7 +452,9 @@ class Engine : public EngineBase {
     if (host.has_dense) {
       dn.n = host.dense.n;
       dn.rank = host.dense.rank;
-      if (sizeof(T) == sizeof(double)) {  // strip-major operands for the MFMA kernel
+      if (adjoint) {
+        // operators of the A^H solve are uploaded below
+      } else if (sizeof(T) == sizeof(double)) {  // strip-major operands for the MFMA kernel
         dn.QH.upload(to_strip_layout(host.dense.QH.data(), dn.n, dn.n));
         dn.Rinv.upload(to_strip_layout(host.dense.Rinv.data(), dn.n, dn.n));
       } else {
@@ -368,6 +463,18 @@ class Engine : public EngineBase {
       }
       dn.jpvt0.upload(host.dense.jpvt0);
       dn.tmp.alloc((size_t)dn.n * Rmax * sizeof(T));
+      if (adjoint) {
+        if (sizeof(T) == sizeof(double)) {
+          dn.Qm.upload(to_strip_layout(host.dense.Q.data(), dn.n, dn.n));
+          dn.RinvH.upload(to_strip_layout(host.dense.RinvH.data(), dn.n, dn.n));
+        } else {
+          dn.Qm.upload(host.dense.Q);
+          dn.RinvH.upload(host.dense.RinvH);
+        }
+        dn.tmp2.alloc((size_t)dn.n * Rmax * sizeof(T));
+        std::vector<T>().swap(host.dense.Q);
+        std::vector<T>().swap(host.dense.RinvH);
+      }
       // the explicit operators are only needed on the device from here on
       std::vector<T>().swap(host.dense.QH);
       std::vector<T>().swap(host.dense.Rinv);
@@ -416,6 +523,13 @@ class Engine : public EngineBase {
     }
     C.val.assign(vals, vals + nz);
     if (!finalized) throw Error(HIFAMD_BAD_PREC, "attach the matrix after hifamd_finalize");
+    if (adj) adj->upload_matrix(adjoint_of_csr(C));
+    host.A = C;  // kept for the adjoint engine (built on first use)
+    host.has_A = true;
+    upload_matrix(C);
+  }
+
+  void upload_matrix(const Csr<T> &C) {
     HIP_OK(hipSetDevice(device));
     A.upload(C, nullptr);
     has_A = true;
@@ -773,6 +887,13 @@ class Engine : public EngineBase {
     check_device_error();
   }
 
+  // operator selection of lhf?Apply (libhifir.cpp:447-472): S on this engine, SH on the adjoint one
+  Engine<T> &for_op(int op) {
+    if (op == HIFAMD_S) return *this;
+    if (op == HIFAMD_SH) return adjoint_engine();
+    throw Error(HIFAMD_HIFIR_ERROR, "LHF_M / LHF_MH (prec_prod) are not on the GPU apply path; use the host library");
+  }
+
   // ---- stats ----------------------------------------------------------------------------------
   void stats(double *o) const {
     for (int i = 0; i < 16; ++i) o[i] = 0.0;
@@ -844,6 +965,20 @@ void Engine<double>::launch_dense(hipStream_t st, const double *cin, double *zou
   const int nd = (int)dn.n, rk = (int)eff_rank(rank);
   const unsigned g = (unsigned)((nd + 15) / 16);  // one workgroup per 16-row strip (4 waves split K)
   double *tmp = dn.tmp.as<double>();
+  if (adjoint) {  // QRCP::_solve_t (QRCP.hpp:413-452): z = Q(:,1:rk) R(1:rk,1:rk)^{-H} (P^T c)(1:rk)
+    double *tmp2 = dn.tmp2.as<double>();
+    hipLaunchKernelGGL((k_row_gather<double>), dim3(grid_for(nd, logR)), dim3(256), 0, st, cin, dn.jpvt0.as<int32_t>(),
+                       (int64_t)nd, tmp2, logR);
+    // T1[i] = sum_{k<=i} conj(Rinv(k,i)) c[jpvt[k]], i < rk (rows >= rk come out as zeros)
+    hipLaunchKernelGGL(k_dense_gemm_d<4>, dim3(g, ((1u << logR) + 15) / 16), dim3(256), 0, st, nd, rk, rk, 2,
+                       dn.RinvH.as<double>(), nd, (const double *)tmp2, logR, (const int32_t *)nullptr, tmp,
+                       (const double *)nullptr, (double *)nullptr);
+    hipLaunchKernelGGL(k_dense_gemm_d<4>, dim3(g, ((1u << logR) + 15) / 16), dim3(256), 0, st, nd, nd, rk, 0,
+                       dn.Qm.as<double>(), nd, (const double *)tmp, logR, (const int32_t *)nullptr, zout,
+                       (const double *)nullptr, (double *)nullptr);
+    count += 3;
+    return;
+  }
   // T1 = Q^H(1:rk, :) c   (rows >= rk come out as zeros and are never read)
   hipLaunchKernelGGL(k_dense_gemm_d<4>, dim3(g, ((1u << logR) + 15) / 16), dim3(256), 0, st, nd, rk, nd, 0, dn.QH.as<double>(), nd, cin, logR,
                      (const int32_t *)nullptr, tmp, (const double *)nullptr, (double *)nullptr);
@@ -857,6 +992,17 @@ template <>
 void Engine<zdouble>::launch_dense(hipStream_t st, const cplx *cin, cplx *zout, int logR, int64_t rank, int64_t &count) {
   const int nd = (int)dn.n, rk = (int)eff_rank(rank);
   cplx *tmp = dn.tmp.as<cplx>();
+  if (adjoint) {
+    cplx *tmp2 = dn.tmp2.as<cplx>();
+    hipLaunchKernelGGL((k_row_gather<cplx>), dim3(grid_for(nd, logR)), dim3(256), 0, st, cin, dn.jpvt0.as<int32_t>(),
+                       (int64_t)nd, tmp2, logR);
+    hipLaunchKernelGGL(k_dense_gemm_z, dim3(grid_for(nd, logR)), dim3(256), 0, st, nd, rk, rk, 2, dn.RinvH.as<cplx>(), nd,
+                       (const cplx *)tmp2, logR, (const int32_t *)nullptr, tmp, (const cplx *)nullptr, (cplx *)nullptr);
+    hipLaunchKernelGGL(k_dense_gemm_z, dim3(grid_for(nd, logR)), dim3(256), 0, st, nd, nd, rk, 0, dn.Qm.as<cplx>(), nd,
+                       (const cplx *)tmp, logR, (const int32_t *)nullptr, zout, (const cplx *)nullptr, (cplx *)nullptr);
+    count += 3;
+    return;
+  }
   hipLaunchKernelGGL(k_dense_gemm_z, dim3(grid_for(nd, logR)), dim3(256), 0, st, nd, rk, nd, 0, dn.QH.as<cplx>(), nd, cin,
                      logR, (const int32_t *)nullptr, tmp, (const cplx *)nullptr, (cplx *)nullptr);
   hipLaunchKernelGGL(k_dense_gemm_z, dim3(grid_for(nd, logR)), dim3(256), 0, st, nd, rk, rk, 1, dn.Rinv.as<cplx>(), nd, tmp,
@@ -1005,6 +1151,7 @@ static void do_sync(E *e) {
   HIP_OK(hipSetDevice(e->device));
   HIP_OK(hipStreamSynchronize(e->stream));
   e->check_device_error();
+  if (e->adj) e->adj->check_device_error();
 }
 
 extern "C" {
@@ -1162,6 +1309,24 @@ HifAmdStatus hifamd_hifir_batch_dev(HifAmdHdl h, const void *dB, int64_t ldb, vo
   API_END
 }
 
+
+HifAmdStatus hifamd_apply_batch(HifAmdHdl h, HifAmdOp op, const void *B, int64_t ldb, void *X, int64_t ldx, int64_t nrhs,
+                                int nirs, const double *betas, int64_t rank, int *ir_status) {
+  API_BEGIN
+  if (rank == -2) rank = (nirs > 1) ? -1 : 0;  // LHF_DEFAULT_RANK, libhifir.cpp:453-455
+  DISPATCH(ENG_D->for_op(op).hifir_host((const double *)B, ldb, (double *)X, ldx, nrhs, nirs, betas, rank, ir_status),
+           ENG_Z->for_op(op).hifir_host((const zdouble *)B, ldb, (zdouble *)X, ldx, nrhs, nirs, betas, rank, ir_status))
+  API_END
+}
+
+HifAmdStatus hifamd_apply_batch_dev(HifAmdHdl h, HifAmdOp op, const void *dB, int64_t ldb, void *dX, int64_t ldx,
+                                    int64_t nrhs, int64_t rank, void *stream) {
+  API_BEGIN
+  if (rank == -2) rank = 0;
+  DISPATCH(ENG_D->for_op(op).solve_dev((const double *)dB, ldb, (double *)dX, ldx, nrhs, rank, (hipStream_t)stream),
+           ENG_Z->for_op(op).solve_dev((const cplx *)dB, ldb, (cplx *)dX, ldx, nrhs, rank, (hipStream_t)stream))
+  API_END
+}
 
 HifAmdStatus hifamd_time_apply(HifAmdHdl h, const void *dB, int64_t ldb, void *dX, int64_t ldx, int64_t nrhs,
                                int64_t rank, int warmup, int reps, double *ms_avg) {

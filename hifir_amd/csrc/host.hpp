@@ -26,6 +26,10 @@ struct Error : std::runtime_error {
 
 inline double abs_(double x) { return std::fabs(x); }
 inline double abs_(const zdouble &x) { return std::abs(x); }
+inline double conj_(double x) { return x; }
+inline zdouble conj_(const zdouble &x) { return std::conj(x); }
+inline double real_(double x) { return x; }
+inline double real_(const zdouble &x) { return x.real(); }
 
 // Column-major (ld = nrows) -> strip-major layout of the dense MFMA kernels: 16-row strips, each stored
 // as [k][16 rows] with ldk >= ncols columns per strip (rows beyond nrows and columns beyond ncols are zero).
@@ -96,6 +100,26 @@ Csr<T> ccs_to_csr(const Ccs<T> &A, bool descending_cols) {
     for (int64_t j = A.ncols - 1; j >= 0; --j) put(j);
   B.rowid.resize((size_t)A.nrows);
   for (int64_t i = 0; i < A.nrows; ++i) B.rowid[(size_t)i] = (int32_t)i;
+  return B;
+}
+
+// CSR of A^H straight from the CCS of A: column j of A IS row j of A^T, so no conversion is needed;
+// values are conjugated, per-row order is the stored (ascending row index) order, which is the order
+// in which the reference's transposed kernels accumulate (CompressedStorage.hpp:2161, :2307, :2399).
+template <class T>
+Csr<T> adjoint_rows(const Ccs<T> &A) {
+  Csr<T> B;
+  B.nrows = A.ncols;
+  B.ncols = A.nrows;
+  if (A.nnz() > (int64_t)std::numeric_limits<int32_t>::max())
+    throw Error(4, "matrix has more than 2^31-1 nonzeros: int32 device row pointers overflow");
+  B.ptr.resize((size_t)A.ncols + 1);
+  for (int64_t j = 0; j <= A.ncols; ++j) B.ptr[(size_t)j] = A.colptr.empty() ? 0 : (int32_t)A.colptr[(size_t)j];
+  B.col = A.rowind;
+  B.val.resize(A.vals.size());
+  for (size_t k = 0; k < A.vals.size(); ++k) B.val[k] = conj_(A.vals[k]);
+  B.rowid.resize((size_t)A.ncols);
+  for (int64_t i = 0; i < A.ncols; ++i) B.rowid[(size_t)i] = (int32_t)i;
   return B;
 }
 
@@ -538,12 +562,10 @@ struct HostDense {
   std::vector<T> qr, tau;      // GEQP3 layout
   std::vector<int32_t> jpvt0;  // 0-based column permutation
   std::vector<T> QH, Rinv;     // explicit operators, column-major
+  // adjoint apply (QRCP::_solve_t, QRCP.hpp:413-452): z = Q(:,1:rk) * (R(1:rk,1:rk)^{-H} * (P^T c)(1:rk))
+  std::vector<T> Q, RinvH;     // Q = (Q^H)^H, RinvH = (R^{-1})^H (lower triangular), column-major
 };
 
-inline double conj_(double x) { return x; }
-inline zdouble conj_(const zdouble &x) { return std::conj(x); }
-inline double real_(double x) { return x; }
-inline double real_(const zdouble &x) { return x.real(); }
 
 template <class T>
 double col_norm(const T *x, int64_t n) {
@@ -736,39 +758,11 @@ void laic1(int job, int64_t j, const T *x, double sest, const T *w, T gamma, dou
   }
 }
 
+// explicit Q^H and R^{-1} from the GEQP3 factors (also used to rebuild them for the adjoint operators)
 template <class T>
-void dense_factorize(HostDense<T> &D, const T *mat_colmajor, int64_t n, double rrqr_cond) {
-  D.n = n;
-  D.qr.assign(mat_colmajor, mat_colmajor + n * n);
-  qr_colpiv(n, D.qr, D.jpvt0, D.tau);
-  const double eps = std::numeric_limits<double>::epsilon();
-  const double diag_tol = std::sqrt(eps), cond_tol = 1.0 / std::pow(eps, 2.0 / 3.0);
-  const double cond_thres = rrqr_cond <= 0.0 ? cond_tol : rrqr_cond;
+void dense_explicit_ops(HostDense<T> &D) {
+  const int64_t n = D.n;
   const T *A = D.qr.data();
-  bool cond_test = false;
-  const double diag_eps = diag_tol * abs_(A[0]);
-  for (int64_t i = n; i != 0; --i)
-    if (abs_(A[(i - 1) + (i - 1) * n]) < diag_eps) {
-      cond_test = true;
-      break;
-    }
-  D.rank = n;
-  if (cond_test) {
-    std::vector<T> x((size_t)n, T(0)), y((size_t)n, T(0));
-    x[0] = y[0] = T(1);
-    double smax = abs_(A[0]), smin = smax, sminpr = 0, smaxpr = 0;
-    T s1, c1, s2, c2;
-    int64_t rk = 0;
-    for (; rk < n; ++rk) {
-      laic1(2, rk, x.data(), smin, A + rk * n, A[rk + rk * n], sminpr, s1, c1);
-      laic1(1, rk, y.data(), smax, A + rk * n, A[rk + rk * n], smaxpr, s2, c2);
-      if (!(smaxpr <= sminpr * cond_thres)) break;
-      for (int64_t i = 0; i < rk; ++i) x[(size_t)i] *= s1, y[(size_t)i] *= s2;
-      x[(size_t)rk] = c1, y[(size_t)rk] = c2;
-      smin = sminpr, smax = smaxpr;
-    }
-    D.rank = rk;
-  }
   // explicit Q^H: start from I and apply H(0)^H, H(1)^H, ... to its columns (Q^H = H(n-1)^H...H(0)^H)
   D.QH.assign((size_t)(n * n), T(0));
   for (int64_t j = 0; j < n; ++j) D.QH[(size_t)(j + j * n)] = T(1);
@@ -804,6 +798,56 @@ void dense_factorize(HostDense<T> &D, const T *mat_colmajor, int64_t n, double r
       for (int64_t i = 0; i < k; ++i) x[i] -= rk[i] * xk;
     }
   }
+}
+
+// adjoint operators: conjugate transposes of the two explicit factors
+template <class T>
+void dense_adjoint_ops(HostDense<T> &D) {
+  const int64_t n = D.n;
+  if (D.QH.empty() || D.Rinv.empty()) dense_explicit_ops(D);
+  D.Q.resize((size_t)(n * n));
+  D.RinvH.resize((size_t)(n * n));
+  for (int64_t j = 0; j < n; ++j)
+    for (int64_t i = 0; i < n; ++i) {
+      D.Q[(size_t)(i + j * n)] = conj_(D.QH[(size_t)(j + i * n)]);
+      D.RinvH[(size_t)(i + j * n)] = conj_(D.Rinv[(size_t)(j + i * n)]);
+    }
+}
+
+template <class T>
+void dense_factorize(HostDense<T> &D, const T *mat_colmajor, int64_t n, double rrqr_cond) {
+  D.n = n;
+  D.qr.assign(mat_colmajor, mat_colmajor + n * n);
+  qr_colpiv(n, D.qr, D.jpvt0, D.tau);
+  const double eps = std::numeric_limits<double>::epsilon();
+  const double diag_tol = std::sqrt(eps), cond_tol = 1.0 / std::pow(eps, 2.0 / 3.0);
+  const double cond_thres = rrqr_cond <= 0.0 ? cond_tol : rrqr_cond;
+  const T *A = D.qr.data();
+  bool cond_test = false;
+  const double diag_eps = diag_tol * abs_(A[0]);
+  for (int64_t i = n; i != 0; --i)
+    if (abs_(A[(i - 1) + (i - 1) * n]) < diag_eps) {
+      cond_test = true;
+      break;
+    }
+  D.rank = n;
+  if (cond_test) {
+    std::vector<T> x((size_t)n, T(0)), y((size_t)n, T(0));
+    x[0] = y[0] = T(1);
+    double smax = abs_(A[0]), smin = smax, sminpr = 0, smaxpr = 0;
+    T s1, c1, s2, c2;
+    int64_t rk = 0;
+    for (; rk < n; ++rk) {
+      laic1(2, rk, x.data(), smin, A + rk * n, A[rk + rk * n], sminpr, s1, c1);
+      laic1(1, rk, y.data(), smax, A + rk * n, A[rk + rk * n], smaxpr, s2, c2);
+      if (!(smaxpr <= sminpr * cond_thres)) break;
+      for (int64_t i = 0; i < rk; ++i) x[(size_t)i] *= s1, y[(size_t)i] *= s2;
+      x[(size_t)rk] = c1, y[(size_t)rk] = c2;
+      smin = sminpr, smax = smaxpr;
+    }
+    D.rank = rk;
+  }
+  dense_explicit_ops(D);
 }
 
 template <class T>

@@ -97,6 +97,20 @@ __global__ void __launch_bounds__(256) k_gather_scale(const T *__restrict__ bin,
 }
 
 // ---------------------------------------------------------------------------------------------
+// out[i] = in[map[i]], rows [0, n) of an arena block: the P^T x of the adjoint dense solve
+// (QRCP::_solve_t, QRCP.hpp:428-433)
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256) k_row_gather(const T *__restrict__ in, const int32_t *__restrict__ map,
+                                                    int64_t n, T *__restrict__ out, int logR) {
+  const LaneMap lm = lane_map(logR);
+  const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = wave * lm.G + lm.g; i < n; i += nwaves * lm.G)
+    out[(i << logR) + lm.c] = in[((int64_t)map[i] << logR) + lm.c];
+}
+
+// ---------------------------------------------------------------------------------------------
 // S7: y[i] = t[i] * v[q_inv[i]],  rows [0, n)
 // ---------------------------------------------------------------------------------------------
 template <class T>

@@ -23,6 +23,9 @@ STATUS = {0: "HIFAMD_SUCCESS", 1: "HIFAMD_NULL_OBJ", 2: "HIFAMD_MISMATCHED_SIZES
           4: "HIFAMD_HIFIR_ERROR"}
 
 
+OP_S, OP_SH, OP_M, OP_MH = 0, 1, 2, 3  # HifAmdOp == LhfOperationType (libhifir.h:159-164)
+
+
 class HifAmdError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"{STATUS.get(code, code)}: {msg}")
@@ -168,22 +171,24 @@ class HIF:
 
     # ---- apply -----------------------------------------------------------------------------------
     def solve(self, b, x=None, trans=False, rank=0):
-        """x = M^{-1} b  (HIF::solve, builder.hpp:409-423)."""
-        if trans:
-            raise HifAmdError(3, "transpose solve (LHF_SH) is not part of the GPU path yet")
+        """x = M^{-1} b, or x = M^{-H} b with trans=True (HIF::solve, builder.hpp:409-423)."""
         if _is_torch(b):
-            return self.solve_mrhs(b.reshape(-1, 1), None if x is None else x.reshape(-1, 1), rank).reshape(-1)
+            return self.solve_mrhs(b.reshape(-1, 1), None if x is None else x.reshape(-1, 1), rank, trans=trans).reshape(-1)
         b = np.ascontiguousarray(b, dtype=self.dtype)
         if b.ndim != 1 or b.shape[0] != self.nrows():
             raise HifAmdError(2, "unmatched sizes")
         if x is None:
             x = np.empty_like(b)
-        _check(lib().hifamd_solve(self._h, _p(b), _p(x), int(rank)))
+        if trans:
+            _check(lib().hifamd_apply_batch(self._h, OP_SH, _p(b), 1, _p(x), 1, 1, 1, None, int(rank), None))
+        else:
+            _check(lib().hifamd_solve(self._h, _p(b), _p(x), int(rank)))
         return x
 
-    def solve_mrhs(self, B, X=None, rank=0, stream=None):
-        """X = M^{-1} B for an [n][nrhs] row-interleaved block (the layout of
+    def solve_mrhs(self, B, X=None, rank=0, stream=None, trans=False):
+        """X = M^{-1} B (trans: M^{-H} B) for an [n][nrhs] row-interleaved block (the layout of
         Array<std::array<T,Nrhs>>, CompressedStorage.hpp:2127); nrhs is a run-time value here."""
+        op = OP_SH if trans else OP_S
         if _is_torch(B):
             import torch
 
@@ -193,7 +198,7 @@ class HIF:
                 raise HifAmdError(2, "unmatched sizes")
             if B.stride(1) != 1 or X.stride(1) != 1:
                 raise HifAmdError(2, "blocks must be row-interleaved (unit column stride)")
-            _check(lib().hifamd_solve_batch_dev(self._h, B.data_ptr(), B.stride(0), X.data_ptr(), X.stride(0),
+            _check(lib().hifamd_apply_batch_dev(self._h, op, B.data_ptr(), B.stride(0), X.data_ptr(), X.stride(0),
                                                B.shape[1], int(rank), stream))
             return X
         B = np.ascontiguousarray(B, dtype=self.dtype)
@@ -201,7 +206,11 @@ class HIF:
             raise HifAmdError(2, "unmatched sizes")
         if X is None:
             X = np.empty_like(B)
-        _check(lib().hifamd_solve_batch(self._h, _p(B), B.shape[1], _p(X), X.shape[1], B.shape[1], int(rank)))
+        if trans:
+            _check(lib().hifamd_apply_batch(self._h, op, _p(B), B.shape[1], _p(X), X.shape[1], B.shape[1], 1, None,
+                                           int(rank), None))
+        else:
+            _check(lib().hifamd_solve_batch(self._h, _p(B), B.shape[1], _p(X), X.shape[1], B.shape[1], int(rank)))
         return X
 
     def spmv(self, X, Y=None, stream=None):
@@ -216,9 +225,25 @@ class HIF:
                                           X2.shape[1], stream))
         return Y
 
-    def hifir(self, b, N, betas=None, rank=-1):
+    def hifir(self, b, N, betas=None, rank=-1, trans=False):
         """Iterative refinement (HIF::hifir, builder.hpp:459-489).  b: [n] or [n][nrhs].
-        Without betas returns x; with betas returns (x, iters, flags) per column (ints for a vector)."""
+        Without betas returns x; with betas returns (x, iters, flags) per column (ints for a vector).
+        trans=True refines A^H x = b with M^{-H} (host arrays only)."""
+        if trans:
+            if _is_torch(b):
+                raise HifAmdError(3, "hifir(trans=True) takes host arrays")
+            vec = (b.ndim == 1)
+            bt = None if betas is None else np.ascontiguousarray(betas, dtype=np.float64)
+            B = np.ascontiguousarray(b, dtype=self.dtype).reshape(b.shape[0], -1)
+            X = np.empty_like(B)
+            st = np.zeros(2 * B.shape[1], dtype=np.int32)
+            _check(lib().hifamd_apply_batch(self._h, OP_SH, _p(B), B.shape[1], _p(X), X.shape[1], B.shape[1], int(N),
+                                           _p(bt), int(rank), _p(st)))
+            x = X.reshape(-1) if vec else X
+            if betas is None:
+                return x
+            it, fl = st[0::2].copy(), st[1::2].copy()
+            return (x, int(it[0]), int(fl[0])) if vec else (x, it, fl)
         vec = (b.ndim == 1)
         bt = None if betas is None else np.ascontiguousarray(betas, dtype=np.float64)
         if _is_torch(b):

@@ -119,6 +119,46 @@ def test_iterative_refinement(cache, name):
         assert relerr(X[:, k], xo) <= 1e-11
 
 
+@pytest.mark.parametrize("name", HIER_NAMES)
+def test_transposed_solve(cache, name):
+    # LHF_SH: x = M^{-H} b through the adjoint hierarchy; bar 1e-12 vs the oracle's prec_solve_tran
+    # restatement (tolerance-level by construction: the reference accumulates dot products) and vs
+    # the real reference's golden xt / XT4
+    torch = pytest.importorskip("torch")
+    levels, d, M, O = _get(cache, name)
+    xt = M.solve(d["b"], trans=True)
+    assert relerr(xt, O.solve(d["b"], trans=True)) <= TOL
+    assert relerr(xt, d["xt"]) <= TOL
+    XT = M.solve_mrhs(d["B4"], trans=True)
+    assert relerr(XT, d["XT4"]) <= TOL
+    n = len(d["b"])
+    rng = np.random.default_rng(17)
+    for nrhs in (3, 64, 70):
+        B = rng.uniform(-1, 1, size=(n, nrhs)).astype(d["b"].dtype)
+        if np.iscomplexobj(B):
+            B = B + 1j * rng.uniform(-1, 1, size=(n, nrhs))
+        Xo = O.solve_batch(B, threads=4, trans=True)
+        assert relerr(M.solve_mrhs(B, trans=True), Xo) <= TOL
+        Xd = M.solve_mrhs(torch.from_numpy(B).cuda(), trans=True)  # device pointers, enqueued
+        M.sync()
+        torch.cuda.synchronize()
+        assert relerr(Xd.cpu().numpy(), Xo) <= TOL
+    # the forward operator is untouched by the adjoint engine
+    assert relerr(M.solve(d["b"]), d["x"]) <= TOL
+    # refinement with A^H and M^{-H} (IterRefine.hpp:77-105 with tran=true): same recurrence on the host
+    # with the oracle's transposed solve and scipy's A^H
+    import scipy.sparse as sp
+
+    A = sp.csr_matrix((d["A_vals"], d["A_indices"], d["A_indptr"]), shape=(n, n))
+    AH = A.conj().T.tocsr()
+    assert relerr(M.hifir(d["b"], 1, trans=True), d["xt"]) <= TOL
+    x = np.zeros_like(d["b"])
+    for i in range(4):
+        r = d["b"] - AH @ x if i else d["b"].copy()
+        x = O.solve(r, trans=True) + x
+    assert relerr(M.hifir(d["b"], 4, trans=True), x) <= 1e-10
+
+
 def test_spmv_bitwise(cache):
     torch = pytest.importorskip("torch")
     levels, d, M, O = _get(cache, "cd2d_48")
@@ -143,9 +183,13 @@ def test_error_paths(cache):
     with pytest.raises(hifir_amd.HifAmdError) as e:
         M.solve(np.zeros(7))
     assert e.value.code == 2
-    with pytest.raises(hifir_amd.HifAmdError):
-        M.solve(d["b"], trans=True)
     import ctypes as C
+    x = np.empty_like(d["b"])
+    bb = np.ascontiguousarray(d["b"])
+    for op in (2, 3):  # LHF_M / LHF_MH stay on the host library
+        rc = hifir_amd.lib().hifamd_apply_batch(M._h, op, bb.ctypes.data_as(C.c_void_p), 1, x.ctypes.data_as(C.c_void_p),
+                                                1, 1, 1, None, 0, None)
+        assert rc == 4 and b"LHF_M" in hifir_amd.lib().hifamd_last_error()
     b = np.ascontiguousarray(d["b"])
     rc = hifir_amd.lib().hifamd_solve(M._h, b.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), 0)
     assert rc == 3  # aliasing b and x is refused (libhifir Ownership: b and x must not alias)
