@@ -5,6 +5,7 @@ Checked through size-independent properties plus a few columns against the oracl
   * linearity  M^-1(a b1 + c b2) = a M^-1 b1 + c M^-1 b2  to rounding,
   * round trip M (M^-1 b) = b with the oracle's prec_prod (libhifir/tests/test_real.c:110-146, 1e-10),
   * iterative refinement (both variants) and the outer SpMV against the real reference,
+  * the conjugate-transpose apply (LHF_SH) against the real reference and the oracle,
   * 3-D 7-pt Poisson and a complex (Helmholtz-like) system at moderate size vs the oracle."""
 import numpy as np
 import pytest
@@ -50,6 +51,20 @@ def test_1m_columns_vs_oracle_and_reference(big):
     assert np.array_equal(M.solve(B[:, 7].copy()), X[:, 7])
     X3 = M.solve_mrhs(np.ascontiguousarray(B[:, :3]))
     assert np.array_equal(X3, X[:, :3])
+
+
+def test_1m_transposed_apply(big):
+    # LHF_SH at full size: M^{-H} through the adjoint hierarchy vs the real reference's
+    # HIF::solve(b, x, true) and the oracle's prec_solve_tran
+    A, R, levels, M, O = big
+    n = A.shape[0]
+    rng = np.random.default_rng(6)
+    B = rng.uniform(-1, 1, size=(n, 64))
+    X = M.solve_mrhs(B, trans=True)
+    for k in (0, 63):
+        assert relerr(X[:, k], O.solve(B[:, k].copy(), trans=True)) <= 1e-12
+    assert relerr(X[:, 9], R.solve(B[:, 9].copy(), trans=True)) <= 1e-12
+    assert np.array_equal(M.solve(B[:, 7].copy(), trans=True), X[:, 7])
 
 
 def test_1m_linearity_and_roundtrip(big):
@@ -118,3 +133,7 @@ def test_complex_helmholtz_like_vs_oracle():
     X = M.solve_mrhs(B)
     assert relerr(X, O.solve_batch(B, threads=4)) <= 1e-12
     assert relerr(X[:, 3], R.solve(B[:, 3].copy())) <= 1e-12
+    XH = M.solve_mrhs(B, trans=True)  # conjugation matters here: A is complex symmetric, not Hermitian
+    assert relerr(XH, O.solve_batch(B, threads=4, trans=True)) <= 1e-12
+    assert relerr(XH[:, 3], R.solve(B[:, 3].copy(), trans=True)) <= 1e-12
+    assert relerr(XH, X) > 1e-3
