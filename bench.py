@@ -184,6 +184,7 @@ def main():
         # kernel-side duration of one apply: HIP events on the stream the kernels run on
         dev_ms = M.time_apply(B, X, warmup=1, reps=max(5, steps // 2))
         balg = M.algorithmic_bytes(args.nrhs)
+        stage_bytes = M.stage_bytes(args.nrhs)
         st = M.stats()
         # one end-of-batch gather of the solution blocks (not in the per-step data path)
         gather_ms = None
@@ -203,7 +204,7 @@ def main():
             xo = orc.Oracle(levels).solve(B[:, 0].cpu().numpy())
             xg = X[:, 0].cpu().numpy()
             parity = float(np.abs(xg - xo).max() / np.abs(xo).max())
-        res = dict(ms_per_step=1e3 * el / steps, value=world * args.nrhs * steps / el, dev_ms=dev_ms, balg=balg,
+        res = dict(ms_per_step=1e3 * el / steps, value=world * args.nrhs * steps / el, dev_ms=dev_ms, balg=balg, stage_bytes=stage_bytes,
                    stats=st, cpu=cpu, gather_ms=gather_ms, parity=parity, levels=levels)
         M.close()
         del B, X
@@ -232,6 +233,13 @@ def main():
             if cands:
                 traffic = json.load(open(cands[-1])).get("hbm_bytes_per_apply_corrected")
                 traffic_src = os.path.relpath(cands[-1], ROOT)
+        # per-stage rooflines: algorithmic bytes of a stage group / its kernels' time in the committed
+        # rocprofv3 kernel trace of this same command (tests/prof_summarize.py)
+        stages = None
+        if traffic_src:
+            sp_ = os.path.join(ROOT, traffic_src.replace("_pmc_summary.json", "_stage_roofline.json"))
+            if os.path.exists(sp_):
+                stages = json.load(open(sp_))
         line = {
             "metric": "preconditioner applies/sec + achieved HBM GB/s, 1M-row 5-pt Laplacian, nrhs=64",
             "value": r["value"], "unit": "RHS-applies/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -248,8 +256,9 @@ def main():
                        "parallelism": f"rhs-sharded x{world} (hierarchy replicated)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "one whole batched apply (hipGraph of k_trsv_wide/k_trsv_tail/k_spmm_epi/...)",
-                         "algorithmic_bytes": r["balg"], "apply_ms_hip_events": r["dev_ms"]},
+                         "kernel": "one whole batched apply (hipGraph of k_trsv_band/k_trsv_wide/k_thin_update/k_tri_gemm_d/k_spmm_epi/k_gather_scale/k_scatter_scale)",
+                         "algorithmic_bytes": r["balg"], "apply_ms_hip_events": r["dev_ms"],
+                         "algorithmic_bytes_by_stage": r["stage_bytes"], "stages_from_profile": stages},
             "cpu_baseline": cpu,
             "parity_relerr_col0_vs_oracle": r["parity"],
         }

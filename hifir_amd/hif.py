@@ -156,6 +156,24 @@ class HIF:
         st = self.stats()
         return st["B_mat"] + nrhs * st["B_vec"]
 
+    def stage_bytes(self, nrhs):
+        """The same B_alg split by stage group (SURVEY 8(d) terms): which kernels stream which bytes.
+        permute = S1 + S7 (k_gather_scale / k_scatter_scale), ldu = S2 + S6 (k_trsv_* / k_thin_update /
+        k_tri_gemm_d), schur = S3 + S5 (k_spmm_epi), dense = last-level operators."""
+        st = self.stats()
+        sv = np.dtype(self.dtype).itemsize
+        si, sp, ss = 4, 8, 8
+        n, m, L = st["sum_n"], st["sum_m"], st["sparse_levels"]
+        nm = n - m
+        out = {
+            "permute": 4 * n * sv * nrhs + n * (2 * si + 2 * ss),
+            "ldu": 4 * m * sv * nrhs + 2 * st["nnz_LU"] * (sv + si) + 2 * m * sv + 4 * (m + L) * sp,
+            "schur": (3 * m + 3 * nm) * sv * nrhs + st["nnz_EF"] * (sv + si) + (n + 2 * L) * sp,
+            "dense": st["dense_n"] ** 2 * sv,
+        }
+        assert abs(sum(out.values()) - self.algorithmic_bytes(nrhs)) <= 1e-9 * self.algorithmic_bytes(nrhs)
+        return out
+
     def level_schedule(self, level, which):
         """(order, wf_ptr) of the L (which=0) or U (which=1) factor of a level."""
         nwf = C.c_int64()

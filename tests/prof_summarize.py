@@ -66,6 +66,41 @@ if kt and os.path.exists(bj):
              "bench_ms_per_step_wall": line["ms_per_step"]}
     json.dump(agree, open(dst + "_apply_time_agreement.json", "w"), indent=1)
     print(json.dumps(agree))
+    # per-stage rooflines of the primary workload: kernel time per apply (same segmentation) against the
+    # stage group's share of B_alg (bench.py "algorithmic_bytes_by_stage", SURVEY 8(d) terms)
+    sb = line["roofline"].get("algorithmic_bytes_by_stage")
+    if sb:
+        group = {"k_gather_scale": "permute", "k_scatter_scale": "permute", "k_spmm_epi": "schur", "k_trsv_band": "ldu",
+                 "k_trsv_wide": "ldu", "k_thin_update": "ldu", "k_tri_gemm_d": "ldu", "k_dense_gemm": "dense",
+                 "k_row_gather": "dense"}
+        tms = {g: 0.0 for g in sb}
+        per_kernel = {}
+        napp = 0
+        start = None
+        for i, r in enumerate(rows):
+            name = r["Kernel_Name"]
+            if "k_gather_scale" in name and (i == 0 or "k_spmm_epi" not in rows[i - 1]["Kernel_Name"]):
+                start = i
+            if start is not None and "k_scatter_scale" in name and \
+                    (i + 1 == len(rows) or "k_spmm_epi" not in rows[i + 1]["Kernel_Name"]):
+                if i - start + 1 == cnts[0]:
+                    napp += 1
+                    for q in rows[start:i + 1]:
+                        d_ = (int(q["End_Timestamp"]) - int(q["Start_Timestamp"])) / 1e6
+                        for k_, g_ in group.items():
+                            if k_ in q["Kernel_Name"]:
+                                tms[g_] += d_
+                                e = per_kernel.setdefault(k_, [0, 0.0])
+                                e[0] += 1
+                                e[1] += d_
+                                break
+                start = None
+        stages = {g: {"algorithmic_bytes": sb[g], "ms_per_apply": tms[g] / napp,
+                      "achieved_GBs": sb[g] / (tms[g] / napp * 1e-3) / 1e9 if tms[g] else None,
+                      "frac_of_8TBs": sb[g] / (tms[g] / napp * 1e-3) / 8e12 if tms[g] else None} for g in sb}
+        stages["kernels"] = {k_: {"launches_per_apply": v[0] / napp, "ms_per_apply": v[1] / napp} for k_, v in per_kernel.items()}
+        json.dump(stages, open(dst + "_stage_roofline.json", "w"), indent=1)
+        print(json.dumps(stages))
 
 out = {}
 f, w = one("pmc_fetch/*/*counter_collection.csv"), one("pmc_write/*/*counter_collection.csv")
