@@ -187,6 +187,7 @@ class Engine : public EngineBase {
   DevBuf blk_tmp;        // right-hand side of one diagonal block of a block-dense thin band
   // IR scratch
   DevBuf ir_r, ir_xk, ir_part, stage_b, stage_x;
+  DevBuf gm_v, gm_w, gm_Q, gm_alpha;  // GMRES: work vectors, Krylov basis, per-column coefficients
   int64_t ir_cols = 0;
 
   explicit Engine(int dev) : device(dev) {
@@ -887,6 +888,194 @@ class Engine : public EngineBase {
     check_device_error();
   }
 
+  // ---- right-preconditioned restarted GMRES, batched over columns ----------------------------------
+  // The reference's driver (examples/advanced/gmres.hpp:19-123: MGS Arnoldi, Givens rotations, relative
+  // residual |y_{j+1}| / ||b||, flags 0 converged / 1 stagnated / 2 reached maxit) run for up to 64
+  // columns in lock step: the vectors stay in HBM, one apply + one SpMM + j+1 fused column-dots per
+  // inner step serve every column, and only the per-column scalars (Hessenberg column, rotations,
+  // residuals) live on the host.  A column that leaves the inner loop keeps a zero basis vector.
+  void col_dots(const double *x, int64_t ldx, const double *y, int64_t ldy, int64_t n, int nc, double *out) {
+    const int nblk = 512;
+    if (ir_part.bytes < (size_t)nblk * 64 * sizeof(double)) ir_part.alloc((size_t)nblk * 64 * sizeof(double));
+    std::vector<double> part((size_t)nblk * nc);
+    hipLaunchKernelGGL(k_coldot_partial, dim3(nblk), dim3(256), 0, stream, n, nc, x, ldx, y, ldy, ir_part.as<double>());
+    HIP_OK(hipMemcpyAsync(part.data(), ir_part.p, (size_t)nblk * nc * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    for (int c = 0; c < nc; ++c) {
+      double tot = 0.0;
+      for (int b = 0; b < nblk; ++b) tot += part[(size_t)b * nc + c];
+      out[c] = tot;
+    }
+  }
+  void col_op(int op, int64_t n, int nc, double *y, int64_t ldy, const double *x, int64_t ldx, const double *alpha_host) {
+    // coefficients travel through a small ring of device slots so that consecutive launches never race
+    const size_t slots = 256;
+    if (gm_alpha.bytes < slots * 64 * sizeof(double)) gm_alpha.alloc(slots * 64 * sizeof(double));
+    double *dst = gm_alpha.as<double>() + (size_t)(gm_slot++ % slots) * 64;
+    HIP_OK(hipMemcpyAsync(dst, alpha_host, (size_t)nc * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_OK(hipStreamSynchronize(stream));  // alpha_host is pageable and reused by the caller
+    int64_t g = (n * nc + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_col_op, dim3((unsigned)g), dim3(256), 0, stream, op, n, nc, y, ldy, x, ldx, (const double *)dst);
+  }
+  uint64_t gm_slot = 0;
+
+  void gmres_tile(const double *dB, int64_t ldb, double *dX, int64_t ldx, int nc, int restart, double rtol, int maxit,
+                  int64_t rank, int *flags, int *iters) {
+    const int64_t n = lv[0]->n;
+    const size_t vec = (size_t)n * nc * sizeof(double);
+    if (gm_v.bytes < vec) gm_v.alloc(vec);
+    if (gm_w.bytes < vec) gm_w.alloc(vec);
+    if (gm_Q.bytes < vec * (size_t)restart) gm_Q.alloc(vec * (size_t)restart);
+    double *v = gm_v.as<double>(), *w = gm_w.as<double>(), *Q = gm_Q.as<double>();
+    auto Qk = [&](int k) { return Q + (size_t)k * (size_t)n * nc; };
+    std::vector<double> beta0, beta, tmp((size_t)nc), alpha((size_t)nc);
+    std::vector<double> y((size_t)nc * (restart + 1)), w2((size_t)nc * restart), R((size_t)nc * restart * restart),
+        J((size_t)nc * restart * 2), resid((size_t)nc, 1.0);
+    std::vector<int> iter((size_t)nc, 0), flag((size_t)nc, 0), jfin((size_t)nc);
+    std::vector<char> done((size_t)nc, 0), active((size_t)nc);
+    col_norms((const D *)dB, ldb, n, nc, beta0);
+    vec_op(0, n, nc, (D *)dX, ldx, nullptr, 0, nullptr, 0);  // x = 0  (:33-34)
+    for (int c = 0; c < nc; ++c) done[(size_t)c] = (beta0[(size_t)c] == 0.0);  // quick return (:36)
+    const int max_outer = (maxit + restart - 1) / restart;  // :43
+    for (int outer = 0; outer < max_outer; ++outer) {
+      bool any = false;
+      for (int c = 0; c < nc; ++c) any = any || !done[(size_t)c];
+      if (!any) break;
+      if (outer)
+        resid_dev((const D *)dB, ldb, (const D *)dX, ldx, (D *)v, nc, nc);  // v = b - A x  (:48-50)
+      else
+        vec_op(1, n, nc, (D *)v, nc, (const D *)dB, ldb, nullptr, 0);
+      col_norms((const D *)v, nc, n, nc, beta);
+      for (int c = 0; c < nc; ++c) {
+        if (!done[(size_t)c] && beta[(size_t)c] == 0.0) done[(size_t)c] = 1;  // exact solution reached
+        y[(size_t)c * (restart + 1)] = beta[(size_t)c];                        // :54
+        alpha[(size_t)c] = done[(size_t)c] ? 0.0 : beta[(size_t)c];
+        active[(size_t)c] = !done[(size_t)c];
+        jfin[(size_t)c] = -1;
+      }
+      col_op(1, n, nc, Qk(0), nc, v, nc, alpha.data());  // Q(:,0) = v / beta  (:55)
+      int j = 0;
+      for (;;) {
+        vec_op(1, n, nc, (D *)v, nc, (const D *)Qk(j), nc, nullptr, 0);  // :58
+        solve_dev((const D *)v, nc, (D *)w, nc, nc, rank, nullptr);      // w = M^{-1} v  (:59)
+        spmv_dev((const D *)w, nc, (D *)v, nc, nc, nullptr);            // v = A w       (:60)
+        for (int k = 0; k <= j; ++k) {                                   // modified Gram-Schmidt (:63-66)
+          col_dots(v, nc, Qk(k), nc, n, nc, tmp.data());
+          for (int c = 0; c < nc; ++c) {
+            w2[(size_t)c * restart + k] = tmp[(size_t)c];
+            alpha[(size_t)c] = -tmp[(size_t)c];
+          }
+          col_op(0, n, nc, v, nc, Qk(k), nc, alpha.data());
+        }
+        col_dots(v, nc, v, nc, n, nc, tmp.data());  // v_norm2  (:67)
+        if (j + 1 < restart) {
+          for (int c = 0; c < nc; ++c) alpha[(size_t)c] = active[(size_t)c] ? std::sqrt(tmp[(size_t)c]) : 0.0;
+          col_op(1, n, nc, Qk(j + 1), nc, v, nc, alpha.data());  // :69-70
+        }
+        bool any_active = false;
+        for (int c = 0; c < nc; ++c) {
+          if (!active[(size_t)c]) continue;
+          double *yc = &y[(size_t)c * (restart + 1)], *wc = &w2[(size_t)c * restart];
+          double *Rc = &R[(size_t)c * restart * restart], *Jc = &J[(size_t)c * restart * 2];
+          const double v_norm2 = tmp[(size_t)c], v_norm = std::sqrt(v_norm2);
+          for (int cj = 0; cj + 1 <= j; ++cj) {  // Givens rotations on the new column (:73-78)
+            const double t0 = wc[cj];
+            wc[cj] = Jc[cj] * t0 + Jc[restart + cj] * wc[cj + 1];
+            wc[cj + 1] = -Jc[restart + cj] * t0 + Jc[cj] * wc[cj + 1];
+          }
+          const double rho = std::sqrt(wc[j] * wc[j] + v_norm2);  // :79
+          Jc[j] = wc[j] / rho;
+          Jc[restart + j] = v_norm / rho;
+          yc[j + 1] = -Jc[restart + j] * yc[j];
+          yc[j] = Jc[j] * yc[j];
+          wc[j] = rho;
+          for (int i = 0; i <= j; ++i) Rc[(size_t)j * restart + i] = wc[i];  // R(:,j)  (:85)
+          const double resid_prev = resid[(size_t)c];
+          resid[(size_t)c] = std::fabs(yc[j + 1]) / beta0[(size_t)c];  // :89
+          bool brk = false;
+          if (resid[(size_t)c] >= resid_prev * (1.0 - 1e-8)) {  // :90-93
+            flag[(size_t)c] = 1;
+            brk = true;
+          } else if (iter[(size_t)c] >= maxit) {  // :94-97
+            flag[(size_t)c] = 2;
+            brk = true;
+          } else {
+            ++iter[(size_t)c];
+            if (resid[(size_t)c] <= rtol || j + 1 >= restart) brk = true;  // :102
+          }
+          if (brk) {
+            jfin[(size_t)c] = j;
+            active[(size_t)c] = 0;
+          } else {
+            any_active = true;
+          }
+        }
+        if (!any_active) break;
+        ++j;
+      }
+      int jmax = -1;
+      for (int c = 0; c < nc; ++c) {  // back substitution R y = g  (:106-110)
+        const int jf = jfin[(size_t)c];
+        if (jf < 0) continue;
+        jmax = std::max(jmax, jf);
+        double *yc = &y[(size_t)c * (restart + 1)];
+        const double *Rc = &R[(size_t)c * restart * restart];
+        for (int k = jf; k > -1; --k) {
+          yc[k] /= Rc[(size_t)k * restart + k];
+          const double t0 = yc[k];
+          for (int i = k - 1; i > -1; --i) yc[i] -= t0 * Rc[(size_t)k * restart + i];
+        }
+      }
+      vec_op(0, n, nc, (D *)v, nc, nullptr, 0, nullptr, 0);  // v = Q y  (:112-116)
+      for (int i = 0; i <= jmax; ++i) {
+        for (int c = 0; c < nc; ++c)
+          alpha[(size_t)c] = (jfin[(size_t)c] >= i) ? y[(size_t)c * (restart + 1) + i] : 0.0;
+        col_op(0, n, nc, v, nc, Qk(i), nc, alpha.data());
+      }
+      solve_dev((const D *)v, nc, (D *)w, nc, nc, rank, nullptr);  // :118
+      for (int c = 0; c < nc; ++c) alpha[(size_t)c] = (jfin[(size_t)c] >= 0) ? 1.0 : 0.0;
+      col_op(0, n, nc, dX, ldx, w, nc, alpha.data());  // x += w  (:119)
+      for (int c = 0; c < nc; ++c)
+        if (jfin[(size_t)c] >= 0 && (resid[(size_t)c] <= rtol || flag[(size_t)c] != 0)) done[(size_t)c] = 1;  // :120
+    }
+    HIP_OK(hipStreamSynchronize(stream));
+    check_device_error();
+    for (int c = 0; c < nc; ++c) {
+      if (flags) flags[c] = flag[(size_t)c];
+      if (iters) iters[c] = iter[(size_t)c];
+    }
+  }
+
+  void gmres_dev(const double *dB, int64_t ldb, double *dX, int64_t ldx, int64_t nrhs, int restart, double rtol,
+                 int maxit, int64_t rank, int *flags, int *iters) {
+    check_batch(dB, ldb, dX, ldx, nrhs);
+    if (!has_A) throw Error(HIFAMD_BAD_PREC, "GMRES needs the matrix (hifamd_set_matrix)");
+    if (restart < 1 || maxit < 1 || !(rtol > 0.0)) throw Error(HIFAMD_MISMATCHED_SIZES, "need restart >= 1, maxit >= 1, rtol > 0");
+    HIP_OK(hipSetDevice(device));
+    for (int64_t c0 = 0; c0 < nrhs; c0 += 64) {
+      const int nc = (int)std::min<int64_t>(64, nrhs - c0);
+      gmres_tile(dB + c0, ldb, dX + c0, ldx, nc, restart, rtol, maxit, rank, flags ? flags + c0 : nullptr,
+                 iters ? iters + c0 : nullptr);
+    }
+  }
+
+  void gmres_host(const double *B, int64_t ldb, double *X, int64_t ldx, int64_t nrhs, int restart, double rtol,
+                  int maxit, int64_t rank, int *flags, int *iters) {
+    check_batch(B, ldb, X, ldx, nrhs);
+    HIP_OK(hipSetDevice(device));
+    const int64_t n = lv[0]->n;
+    const size_t need = (size_t)n * nrhs * sizeof(double);
+    if (stage_b.bytes < need) stage_b.alloc(need);
+    if (stage_x.bytes < need) stage_x.alloc(need);
+    HIP_OK(hipMemcpy2DAsync(stage_b.p, nrhs * sizeof(double), B, ldb * sizeof(double), nrhs * sizeof(double), n,
+                            hipMemcpyHostToDevice, stream));
+    gmres_dev(stage_b.as<double>(), nrhs, stage_x.as<double>(), nrhs, nrhs, restart, rtol, maxit, rank, flags, iters);
+    HIP_OK(hipMemcpy2DAsync(X, ldx * sizeof(double), stage_x.p, nrhs * sizeof(double), nrhs * sizeof(double), n,
+                            hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+  }
+
   // operator selection of lhf?Apply (libhifir.cpp:447-472): S on this engine, SH on the adjoint one
   Engine<T> &for_op(int op) {
     if (op == HIFAMD_S) return *this;
@@ -1325,6 +1514,22 @@ HifAmdStatus hifamd_apply_batch_dev(HifAmdHdl h, HifAmdOp op, const void *dB, in
   if (rank == -2) rank = 0;
   DISPATCH(ENG_D->for_op(op).solve_dev((const double *)dB, ldb, (double *)dX, ldx, nrhs, rank, (hipStream_t)stream),
            ENG_Z->for_op(op).solve_dev((const cplx *)dB, ldb, (cplx *)dX, ldx, nrhs, rank, (hipStream_t)stream))
+  API_END
+}
+
+HifAmdStatus hifamd_gmres_batch(HifAmdHdl h, const void *B, int64_t ldb, void *X, int64_t ldx, int64_t nrhs, int restart,
+                                double rtol, int maxit, int64_t rank, int *flags, int *iters) {
+  API_BEGIN
+  if (h->vt != HIFAMD_D) throw Error(HIFAMD_HIFIR_ERROR, "the GMRES driver is real-valued (the reference example's inner product is not Hermitian)");
+  ENG_D->gmres_host((const double *)B, ldb, (double *)X, ldx, nrhs, restart, rtol, maxit, rank, flags, iters);
+  API_END
+}
+
+HifAmdStatus hifamd_gmres_batch_dev(HifAmdHdl h, const void *dB, int64_t ldb, void *dX, int64_t ldx, int64_t nrhs,
+                                    int restart, double rtol, int maxit, int64_t rank, int *flags, int *iters) {
+  API_BEGIN
+  if (h->vt != HIFAMD_D) throw Error(HIFAMD_HIFIR_ERROR, "the GMRES driver is real-valued (the reference example's inner product is not Hermitian)");
+  ENG_D->gmres_dev((const double *)dB, ldb, (double *)dX, ldx, nrhs, restart, rtol, maxit, rank, flags, iters);
   API_END
 }
 

@@ -600,6 +600,47 @@ __global__ void __launch_bounds__(256) k_colnorm2_partial(int64_t n, int nrhs, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// BLAS-1 helpers of the batched GMRES driver (the reference's examples/advanced/gmres.hpp:19-123,
+// real arithmetic): per-column dot products, axpy and scaling with one coefficient per column.
+// ---------------------------------------------------------------------------------------------
+// partial[block][c] = sum over the block's rows of x[i][c] * y[i][c]   (hif::inner, utils/math.hpp:83)
+__global__ void __launch_bounds__(256) k_coldot_partial(int64_t n, int nrhs, const double *x, int64_t ldx,
+                                                        const double *y, int64_t ldy, double *partial) {
+  __shared__ double sm[256];
+  const int cpad = nrhs;  // nrhs <= 64 here
+  const int rows_per_pass = 256 / cpad;
+  const int c = threadIdx.x % cpad, rloc = threadIdx.x / cpad;
+  double acc = 0.0;
+  if (rloc < rows_per_pass)
+    for (int64_t i = (int64_t)blockIdx.x * rows_per_pass + rloc; i < n; i += (int64_t)gridDim.x * rows_per_pass)
+      acc += x[i * ldx + c] * y[i * ldy + c];
+  sm[threadIdx.x] = (rloc < rows_per_pass) ? acc : 0.0;
+  __syncthreads();
+  if (threadIdx.x < cpad) {
+    double tot = 0.0;
+    for (int r = 0; r < rows_per_pass; ++r) tot += sm[r * cpad + threadIdx.x];
+    partial[(int64_t)blockIdx.x * nrhs + threadIdx.x] = tot;
+  }
+}
+
+// op 0: y[:,c] += alpha[c] * x[:,c] | 1: y[:,c] = x[:,c] / alpha[c] (0 where alpha[c] == 0: a column
+// that has left the iteration keeps a zero basis vector)
+__global__ void __launch_bounds__(256) k_col_op(int op, int64_t n, int nrhs, double *y, int64_t ldy, const double *x,
+                                                int64_t ldx, const double *__restrict__ alpha) {
+  const int64_t total = n * nrhs;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / nrhs;
+    const int c = (int)(e - i * nrhs);
+    const double a = alpha[c];
+    if (op == 0)
+      y[i * ldy + c] = y[i * ldy + c] + a * x[i * ldx + c];
+    else
+      y[i * ldy + c] = (a == 0.0) ? 0.0 : x[i * ldx + c] / a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // dense last level on the f64 matrix cores: Out[rowmap(i)] = sum_{k=kbeg(i)}^{kend-1} A(i,k) X[k]
 //   A column-major (lda), rows >= mrows_valid are treated as zero rows (rank truncation);
 //   upper != 0: A is upper triangular, k starts at the row tile's first row;

@@ -284,6 +284,32 @@ class HIF:
         it, fl = st[0::2].copy(), st[1::2].copy()
         return (x, int(it[0]), int(fl[0])) if vec else (x, it, fl)
 
+    def gmres(self, b, restart=30, rtol=1e-6, maxit=500, full_rank=False):
+        """Right-preconditioned restarted GMRES (the reference's examples/advanced/gmres.hpp:19-123),
+        all columns of b ([n] or [n][nrhs], host array or CUDA tensor) in lock step on the device.
+        Returns (x, flags, iters); ints for a vector."""
+        vec = (b.ndim == 1)
+        rank = -1 if full_rank else 0
+        if _is_torch(b):
+            import torch
+
+            B = b.reshape(b.shape[0], -1)
+            X = torch.empty_like(B)
+            fl = np.zeros(B.shape[1], dtype=np.int32)
+            it = np.zeros(B.shape[1], dtype=np.int32)
+            _check(lib().hifamd_gmres_batch_dev(self._h, B.data_ptr(), B.stride(0), X.data_ptr(), X.stride(0), B.shape[1],
+                                               int(restart), float(rtol), int(maxit), rank, _p(fl), _p(it)))
+        else:
+            B = np.ascontiguousarray(b, dtype=self.dtype).reshape(b.shape[0], -1)
+            X = np.empty_like(B)
+            fl = np.zeros(B.shape[1], dtype=np.int32)
+            it = np.zeros(B.shape[1], dtype=np.int32)
+            _check(lib().hifamd_gmres_batch(self._h, _p(B), B.shape[1], _p(X), X.shape[1], B.shape[1], int(restart),
+                                           float(rtol), int(maxit), rank, _p(fl), _p(it)))
+        if vec:
+            return X.reshape(-1), int(fl[0]), int(it[0])
+        return X, fl, it
+
     def time_apply(self, B, X, rank=0, warmup=2, reps=10):
         """Average device milliseconds of one batched apply, HIP events on the handle's stream."""
         ms = C.c_double()

@@ -153,6 +153,18 @@ HifAmdStatus hifamd_apply_batch(HifAmdHdl h, HifAmdOp op, const void *B, int64_t
 HifAmdStatus hifamd_apply_batch_dev(HifAmdHdl h, HifAmdOp op, const void *dB, int64_t ldb, void *dX, int64_t ldx,
                                     int64_t nrhs, int64_t rank, void *stream);
 
+/* ---- right-preconditioned restarted GMRES, batched (the caller of the hot path) ------------- */
+/* The reference's driver gmres_hif (examples/advanced/gmres.hpp:19-123: x0 = 0, modified Gram-Schmidt,
+ * Givens rotations, stop on |y_{j+1}| / ||b|| <= rtol) for nrhs columns in lock step; all vectors
+ * stay in HBM, one batched apply and one SpMM per inner step serve every column.  Needs
+ * hifamd_set_matrix; real-valued handles only.  rank: 0 numerical rank (the example's default),
+ * -1 full.  Per column: flags[c] = 0 converged / 1 stagnated / 2 reached maxit, iters[c] = inner
+ * iterations (either may be NULL).  Host pointers; the _dev variant takes device pointers for B, X. */
+HifAmdStatus hifamd_gmres_batch(HifAmdHdl h, const void *B, int64_t ldb, void *X, int64_t ldx, int64_t nrhs,
+                                int restart, double rtol, int maxit, int64_t rank, int *flags, int *iters);
+HifAmdStatus hifamd_gmres_batch_dev(HifAmdHdl h, const void *dB, int64_t ldb, void *dX, int64_t ldx, int64_t nrhs,
+                                    int restart, double rtol, int maxit, int64_t rank, int *flags, int *iters);
+
 /* ---- instrumentation ---------------------------------------------------------------------- */
 /* Average device time (ms) of the last `hifamd_solve_batch_dev`-shaped graph over `reps` replays,
  * measured with HIP events on the handle's stream (the stream the kernels run on). */

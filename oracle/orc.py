@@ -185,3 +185,74 @@ def qrcp(mat_colmajor, b, op=0, rank=0, rrqr_cond=0.0):
     rk = np.zeros(1, dtype=np.int64)
     getattr(lib(), f"orc_{k}_qrcp")(len(b), _p(mat), rrqr_cond, op, _p(b), rank, _p(x), _p(rk))
     return x, int(rk[0])
+
+
+def gmres(O, indptr, indices, vals, b, restart=30, rtol=1e-6, maxit=500, full_rank=False):
+    """numpy restatement of the reference's right-preconditioned GMRES driver gmres_hif
+    (examples/advanced/gmres.hpp:19-123; real arithmetic) around the oracle's apply `O.solve`:
+    x0 = 0, modified Gram-Schmidt, Givens rotations, relative residual |y_{j+1}| / ||b||.
+    Returns (x, flag, iterations); flag 0 converged / 1 stagnated / 2 reached maxit."""
+    import scipy.sparse as sp
+
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    n = len(b)
+    A = sp.csr_matrix((np.asarray(vals, dtype=np.float64), indices, indptr), shape=(n, n))
+    rr = -1 if full_rank else 0                                     # :26
+    it, flag = 0, 0
+    beta0 = np.linalg.norm(b)                                        # :30
+    x = np.zeros(n)
+    if beta0 == 0.0:                                                 # :36
+        return x, 0, 0
+    Q = np.zeros((n, restart))
+    R = np.zeros((restart, restart))
+    J = np.zeros((restart, 2))
+    y = np.zeros(restart + 1)
+    w2 = np.zeros(restart)
+    resid = 1.0
+    for outer in range(int(np.ceil(maxit / restart))):               # :43-45
+        v = b - A @ x if it else b.copy()                            # :48-52
+        beta = np.linalg.norm(v)
+        y[0] = beta
+        Q[:, 0] = v / beta
+        j = 0
+        while True:
+            w = O.solve(Q[:, j].copy(), rank=rr)                     # :59
+            v = A @ w                                                # :60
+            for k in range(j + 1):                                   # :63-66
+                w2[k] = v @ Q[:, k]
+                v = v - w2[k] * Q[:, k]
+            v_norm2 = v @ v
+            v_norm = np.sqrt(v_norm2)
+            if j + 1 < restart:
+                Q[:, j + 1] = v / v_norm
+            for cj in range(j):                                      # :73-78
+                t0 = w2[cj]
+                w2[cj] = J[cj, 0] * t0 + J[cj, 1] * w2[cj + 1]
+                w2[cj + 1] = -J[cj, 1] * t0 + J[cj, 0] * w2[cj + 1]
+            rho = np.sqrt(w2[j] * w2[j] + v_norm2)                   # :79
+            J[j, 0] = w2[j] / rho
+            J[j, 1] = v_norm / rho
+            y[j + 1] = -J[j, 1] * y[j]
+            y[j] = J[j, 0] * y[j]
+            w2[j] = rho
+            R[:j + 1, j] = w2[:j + 1]
+            resid_prev = resid
+            resid = abs(y[j + 1]) / beta0                            # :89
+            if resid >= resid_prev * (1.0 - 1e-8):                   # :90-93
+                flag = 1
+                break
+            elif it >= maxit:                                        # :94-97
+                flag = 2
+                break
+            it += 1
+            if resid <= rtol or j + 1 >= restart:                    # :102
+                break
+            j += 1
+        for k in range(j, -1, -1):                                   # :106-110
+            y[k] /= R[k, k]
+            y[:k] -= y[k] * R[:k, k]
+        v = Q[:, :j + 1] @ y[:j + 1]                                 # :112-116
+        x = x + O.solve(v, rank=rr)                                  # :118-119
+        if resid <= rtol or flag != 0:                               # :120
+            break
+    return x, flag, it

@@ -42,6 +42,8 @@ def lib():
             getattr(_lib, f"hifref_{k}_solve_tran").argtypes = [C.c_void_p, vp, vp, C.c_int64]
             getattr(_lib, f"hifref_{k}_mmultiply").argtypes = [C.c_void_p, vp, vp, C.c_int64]
             getattr(_lib, f"hifref_{k}_hifir").argtypes = [C.c_void_p, vp, C.c_int, dp, vp, i32p]
+            if k == "d":
+                _lib.hifref_d_gmres.argtypes = [C.c_void_p, vp, C.c_int, C.c_double, C.c_int, C.c_int, vp, i32p]
             getattr(_lib, f"hifref_{k}_spmv").argtypes = [C.c_size_t, i64p, i32p, vp, vp, vp]
             getattr(_lib, f"hifref_{k}_qrcp").argtypes = [C.c_size_t, vp, C.c_double, C.c_int, vp, C.c_int64, vp, i64p]
             getattr(_lib, f"hifref_{k}_ccs_kernel").argtypes = [C.c_int, C.c_size_t, C.c_size_t, i64p, i32p, vp, vp, vp]
@@ -146,6 +148,20 @@ class RefHIF:
         if self._f("hifir")(self.h, _p(b), nirs, _p(bt), _p(x), _p(st)):
             raise RuntimeError(lib().hifref_error().decode())
         return x, (int(st[0]), int(st[1]))
+
+
+def _gmres(self, b, restart=30, rtol=1e-6, maxit=500, full_rank=False):
+    """gmres_hif of the reference's examples/advanced/gmres.hpp:19-123 (real only) on the factorized
+    matrix: returns (x, flag, iterations); flag 0 converged / 1 stagnated / 2 reached maxit."""
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros_like(b)
+    out = np.zeros(2, dtype=np.int32)
+    if lib().hifref_d_gmres(self.h, _p(b), restart, rtol, maxit, int(full_rank), _p(x), _p(out)):
+        raise RuntimeError(lib().hifref_error().decode())
+    return x, int(out[0]), int(out[1])
+
+
+RefHIF.gmres = _gmres
 
 
 def spmv(indptr, indices, vals, x):

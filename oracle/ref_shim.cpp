@@ -27,6 +27,9 @@
 
 #define HIF_THROW 1
 #include <hifir.hpp>
+// the reference's right-preconditioned GMRES driver (an example header, not library code):
+// gmres_hif(A, b, M, restart, rtol, maxit, verbose, full_rank)   examples/advanced/gmres.hpp:19-123
+#include <gmres.hpp>
 
 namespace {
 
@@ -193,6 +196,26 @@ int do_hifir(void *h, const T *b, int nirs, const double *betas, T *x, int *ir_s
   }
 }
 
+// gmres_hif (examples/advanced/gmres.hpp:19-123) on the handle's own matrix; out[0] = flag
+// (0 converged / 1 stagnated / 2 reached maxit), out[1] = iterations
+template <class T>
+int do_gmres(void *h, const T *b, int restart, double rtol, int maxit, int full_rank, T *x, int *out) {
+  auto *r = (Ref<T> *)h;
+  try {
+    typename Ref<T>::crs_t A(r->n, r->n, r->ip.data(), r->ind.data(), r->val.data(), true);
+    hif::Array<T> bb(r->n, const_cast<T *>(b), true);
+    auto res = gmres_hif(A, bb, r->M, restart, rtol, maxit, 0, full_rank != 0);
+    const hif::Array<T> &xs = std::get<0>(res);
+    for (size_t i = 0; i < r->n; ++i) x[i] = xs[i];
+    out[0] = std::get<1>(res);
+    out[1] = std::get<2>(res);
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+
 // y = A x with the reference CRS kernel (serial multiply_nt; mt_mv.hpp partitions rows only)
 template <class T>
 void do_spmv(size_t n, const int64_t *indptr, const int *indices, const T *vals, const T *x, T *y) {
@@ -321,6 +344,10 @@ int hifref_d_hifir(void *h, const double *b, int nirs, const double *betas, doub
 }
 int hifref_z_hifir(void *h, const void *b, int nirs, const double *betas, void *x, int *st) {
   return do_hifir<zt>(h, (const zt *)b, nirs, betas, (zt *)x, st);
+}
+int hifref_d_gmres(void *h, const double *b, int restart, double rtol, int maxit, int full_rank, double *x,
+                   int *out) {
+  return do_gmres<double>(h, b, restart, rtol, maxit, full_rank, x, out);
 }
 void hifref_d_spmv(size_t n, const int64_t *ip, const int *ind, const double *v, const double *x,
                    double *y) {

@@ -109,3 +109,19 @@ def test_fresh_hierarchies(nx, params):
     assert relerr(t1, t0) <= 1e-12
     if M.levels()[-1]["dense_n"] == 0:
         assert np.array_equal(t0, t1)
+
+
+@pytest.mark.parametrize("nx,params,rtol,maxit,restart", [(40, None, 1e-10, 200, 30), (100, (1e-2, 5.0, 3.0), 1e-8, 200, 10),
+                                                         (100, (1e-2, 5.0, 3.0), 1e-12, 7, 30)])
+def test_gmres_restatement(nx, params, rtol, maxit, restart):
+    # the numpy restatement of examples/advanced/gmres.hpp:19-123 around the oracle's apply vs the real driver
+    A = poisson2d(nx)
+    P = None if params is None else ref.make_params(tau=params[0], kappa=params[1], alpha=params[2], dense_thres=100)
+    M = ref.RefHIF(A.indptr, A.indices, A.data, P)
+    O = orc.Oracle(M.levels())
+    rng = np.random.default_rng(nx)
+    b = rng.uniform(-1, 1, A.shape[0])
+    x0, f0, i0 = M.gmres(b, restart=restart, rtol=rtol, maxit=maxit)
+    x1, f1, i1 = orc.gmres(O, A.indptr, A.indices, A.data, b, restart=restart, rtol=rtol, maxit=maxit)
+    assert (f0, i0) == (f1, i1)
+    assert relerr(x1, x0) <= 1e-8
