@@ -46,6 +46,8 @@ extern "C" {
   int orc_##P##_solve_tran_batch(void *h, const T *B, T *X, int64_t nrhs, int64_t rank,             \
                                  int threads);                                                      \
   int orc_##P##_mmultiply(void *h, const T *x, T *y, int64_t rank);                                 \
+  /* y = M^H x: HIF::mmultiply(x, y, trans = true) -> prec_prod_tran (alg/prec_prod.hpp:148-235) */   \
+  int orc_##P##_mmultiply_tran(void *h, const T *x, T *y, int64_t rank);                            \
   int orc_##P##_hifir(void *h, int64_t n, const int64_t *ip, const int *ind, const T *v,            \
                       const T *b, int nirs, const double *betas, int64_t rank, T *x,                \
                       int *ir_status);                                                              \
@@ -58,7 +60,8 @@ extern "C" {
   /* the same three with nrhs interleaved right-hand sides, [n][nrhs] */                            \
   void orc_##P##_ccs_kernel_mrhs(int op, int64_t nrows, int64_t ncols, const int64_t *cp,           \
                                  const int *ri, const T *v, int64_t nrhs, const T *x, T *y);        \
-  /* dense block alone: QRCP factor + (op 0) solve / (op 1) multiply / (op 2) solve with A^H */     \
+  /* dense block alone: QRCP factor + (op 0) solve / (op 1) multiply / (op 2) solve with A^H /   */  \
+  /* (op 3) multiply with A^H */                                                                    \
   int orc_##P##_qrcp(int64_t n, const T *mat, double rrqr_cond, int op, const T *b,                 \
                      int64_t rank_in, T *x, int64_t *rank_out);
 

@@ -46,6 +46,7 @@ def lib():
             g("solve_tran").argtypes = [vp, vp, vp, C.c_int64]
             g("solve_tran_batch").argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.c_int]
             g("mmultiply").argtypes = [vp, vp, vp, C.c_int64]
+            g("mmultiply_tran").argtypes = [vp, vp, vp, C.c_int64]
             g("hifir").argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int, vp, C.c_int64, vp, vp]
             g("crs_mv").argtypes = [C.c_int64, vp, vp, vp, vp, vp]
             g("ccs_kernel").argtypes = [C.c_int, C.c_int64, C.c_int64, vp, vp, vp, vp, vp]
@@ -128,10 +129,10 @@ class Oracle:
         assert self._f("solve_tran_batch" if trans else "solve_batch")(self.h, _p(B), _p(X), B.shape[1], rank, threads) == 0
         return X
 
-    def mmultiply(self, x, rank=0):
+    def mmultiply(self, x, rank=0, trans=False):
         x = np.ascontiguousarray(x, dtype=self.dtype)
         y = np.zeros_like(x)
-        assert self._f("mmultiply")(self.h, _p(x), _p(y), rank) == 0
+        assert self._f("mmultiply_tran" if trans else "mmultiply")(self.h, _p(x), _p(y), rank) == 0
         return y
 
     def hifir(self, indptr, indices, vals, b, nirs, betas=None, rank=-1):

@@ -41,6 +41,7 @@ def lib():
             getattr(_lib, f"hifref_{k}_solve").argtypes = [C.c_void_p, vp, vp, C.c_int64]
             getattr(_lib, f"hifref_{k}_solve_tran").argtypes = [C.c_void_p, vp, vp, C.c_int64]
             getattr(_lib, f"hifref_{k}_mmultiply").argtypes = [C.c_void_p, vp, vp, C.c_int64]
+            getattr(_lib, f"hifref_{k}_mmultiply_tran").argtypes = [C.c_void_p, vp, vp, C.c_int64]
             getattr(_lib, f"hifref_{k}_hifir").argtypes = [C.c_void_p, vp, C.c_int, dp, vp, i32p]
             if k == "d":
                 _lib.hifref_d_gmres.argtypes = [C.c_void_p, vp, C.c_int, C.c_double, C.c_int, C.c_int, vp, i32p]
@@ -133,10 +134,11 @@ class RefHIF:
             raise RuntimeError(lib().hifref_error().decode())
         return x
 
-    def mmultiply(self, x, rank=0):
+    def mmultiply(self, x, rank=0, trans=False):
+        """HIF::mmultiply (builder.hpp:503-513): y = M x, or M^H x with trans=True."""
         x = np.ascontiguousarray(x, dtype=self.dtype)
         y = np.zeros_like(x)
-        if self._f("mmultiply")(self.h, _p(x), _p(y), rank):
+        if self._f("mmultiply_tran" if trans else "mmultiply")(self.h, _p(x), _p(y), rank):
             raise RuntimeError(lib().hifref_error().decode())
         return y
 
@@ -197,7 +199,7 @@ def ccs_kernel(op, nrows, ncols, colptr, rowind, vals, x):
 
 
 def qrcp(mat_colmajor, b, op=0, rank=0, rrqr_cond=0.0):
-    """hif::QRCP on a dense n x n block (column-major flat array): op 0 solve, 1 multiply, 2 solve with A^H.
+    """hif::QRCP on a dense n x n block (column-major flat array): op 0 solve, 1 multiply, 2 solve with A^H, 3 multiply with A^H.
     Returns (x, numerical_rank)."""
     mat = np.ascontiguousarray(mat_colmajor)
     k = "z" if (np.iscomplexobj(mat) or np.iscomplexobj(b)) else "d"

@@ -164,11 +164,11 @@ int do_solve(void *h, const T *b, T *x, int64_t rank, bool tran = false) {
 }
 
 template <class T>
-int do_mmultiply(void *h, const T *x, T *y, int64_t rank) {
+int do_mmultiply(void *h, const T *x, T *y, int64_t rank, bool tran = false) {
   auto *r = (Ref<T> *)h;
   try {
     hif::Array<T> xx(r->n, const_cast<T *>(x), true), yy(r->n, y, true);
-    r->M.mmultiply(xx, yy, false, (size_t)rank);
+    r->M.mmultiply(xx, yy, tran, (size_t)rank);  // tran: prec_prod_tran, alg/prec_prod.hpp:148-235
     return 0;
   } catch (const std::exception &e) {
     g_err = e.what();
@@ -272,6 +272,8 @@ int do_qrcp(size_t n, const T *mat, double rrqr_cond, int op, const T *b, int64_
       qr.solve(xx, (size_t)rank_in);
     else if (op == 2)
       qr.solve(xx, (size_t)rank_in, true);  // _solve_t, small_scale/QRCP.hpp:413-452
+    else if (op == 3)
+      qr.multiply(xx, (size_t)rank_in, true);  // _multiply_t, small_scale/QRCP.hpp:502-541
     else
       qr.multiply(xx, (size_t)rank_in);
     return 0;
@@ -338,6 +340,12 @@ int hifref_d_mmultiply(void *h, const double *x, double *y, int64_t rank) {
 }
 int hifref_z_mmultiply(void *h, const void *x, void *y, int64_t rank) {
   return do_mmultiply<zt>(h, (const zt *)x, (zt *)y, rank);
+}
+int hifref_d_mmultiply_tran(void *h, const double *x, double *y, int64_t rank) {
+  return do_mmultiply<double>(h, x, y, rank, true);
+}
+int hifref_z_mmultiply_tran(void *h, const void *x, void *y, int64_t rank) {
+  return do_mmultiply<zt>(h, (const zt *)x, (zt *)y, rank, true);
 }
 int hifref_d_hifir(void *h, const double *b, int nirs, const double *betas, double *x, int *st) {
   return do_hifir<double>(h, b, nirs, betas, x, st);

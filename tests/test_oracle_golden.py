@@ -76,6 +76,9 @@ def test_mmultiply_and_roundtrip(name):
     assert relerr(b2, d["b2"]) <= 1e-10
     # libhifir/tests/test_real.c:110-146 invariant
     assert np.linalg.norm(b2 - d["b"]) / np.linalg.norm(d["b"]) <= 1e-10
+    # the same round trip with the conjugate transposes: M^H (M^{-H} b) = b (prec_prod_tran, prec_prod.hpp:148-235)
+    bt = O.mmultiply(d["xt"], trans=True)
+    assert np.linalg.norm(bt - d["b"]) / np.linalg.norm(d["b"]) <= 1e-10
 
 
 @pytest.mark.parametrize("name", HIER_NAMES)

@@ -85,6 +85,11 @@ def test_qrcp_full_and_deficient_rank(cplx):
     y0, _ = ref.qrcp(A.ravel(order="F"), b, op=1)
     y1, _ = orc.qrcp(A.ravel(order="F"), b, op=1)
     assert relerr(y1, y0) <= 1e-12
+    # A^H products (_multiply_t, QRCP.hpp:502-541)
+    for rk in (0, 10):
+        z0, _ = ref.qrcp(A.ravel(order="F"), b, op=3, rank=rk)
+        z1, _ = orc.qrcp(A.ravel(order="F"), b, op=3, rank=rk)
+        assert relerr(z1, z0) <= 1e-12
     # A^H solves (_solve_t, QRCP.hpp:413-452): full rank, explicit rank, rank-deficient
     for mat, rk, tol in ((A, 0, 1e-12), (A, 10, 1e-12), (A2, 0, 1e-9)):
         z0, _ = ref.qrcp(mat.ravel(order="F"), b, op=2, rank=rk)
@@ -105,6 +110,7 @@ def test_fresh_hierarchies(nx, params):
     if M.levels()[-1]["dense_n"] == 0:
         assert np.array_equal(x0, x1)
     assert relerr(O.mmultiply(x0), M.mmultiply(x0)) <= 1e-10
+    assert relerr(O.mmultiply(x0, trans=True), M.mmultiply(x0, trans=True)) <= 1e-10
     t0, t1 = M.solve(b, trans=True), O.solve(b, trans=True)
     assert relerr(t1, t0) <= 1e-12
     if M.levels()[-1]["dense_n"] == 0:
