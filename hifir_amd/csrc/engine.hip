@@ -128,19 +128,23 @@ struct DevLevel {
   DevCsr L, U, E, F;
   DevBuf d, s, t, p, qinv;
   DevBuf w, v;  // arena: n * Rmax each
+  DevBuf q, pinv;        // product only (prec_prod.hpp:76,132), uploaded with the product buffers
+  DevBuf pg, pc, pr;     // product only: permuted input, child product / D(U+I)g, result rows
 };
 
 struct DevDense {
   int64_t n = 0, rank = 0;
   DevBuf QH, Rinv, jpvt0, tmp;
   DevBuf Qm, RinvH, tmp2;  // adjoint engine only: Q, (R^{-1})^H and the permuted input
+  DevBuf Rm;               // product only: R (primary engine, upper) or R^H (adjoint engine, lower)
 };
 
 struct GraphKey {
   const void *B, *X;
   int64_t ldb, ldx, nrhs, rank;
+  int kind;  // 0: apply (prec_solve), 1: product (prec_prod)
   bool operator<(const GraphKey &o) const {
-    return std::tie(B, X, ldb, ldx, nrhs, rank) < std::tie(o.B, o.X, o.ldb, o.ldx, o.nrhs, o.rank);
+    return std::tie(B, X, ldb, ldx, nrhs, rank, kind) < std::tie(o.B, o.X, o.ldb, o.ldx, o.nrhs, o.rank, o.kind);
   }
 };
 
@@ -351,6 +355,8 @@ class Engine : public EngineBase {
     H.t = P.s;
     H.p = P.q;
     H.q_inv = P.p_inv;
+    H.q = P.p;          // product on the adjoint hierarchy = prec_prod_tran: (s, p) in, (t, q_inv) out
+    H.p_inv = P.q_inv;
     analyze_level(H);
     host.levels.push_back(std::move(H));
   }
@@ -650,13 +656,139 @@ class Engine : public EngineBase {
     ++count;
   }
 
+  // ---- y = M b: prec_prod (alg/prec_prod.hpp:55-147), the inverse direction of the apply ------------
+  // On the adjoint engine the same code is prec_prod_tran (:148-235): the adjoint hierarchy swaps the
+  // roles exactly as that function does.
+  bool prod_ready = false;
+  void ensure_prod_buffers() {
+    if (prod_ready) return;
+    for (size_t l = 0; l < lv.size(); ++l) {
+      DevLevel &L = *lv[l];
+      const HostLevel<T> &H = host.levels[l];
+      if (H.q.empty() || H.p_inv.empty())
+        throw Error(HIFAMD_BAD_PREC, "the product operators need the q and p_inv permutations (hifamd_add_level)");
+      L.q.upload(H.q);
+      L.pinv.upload(H.p_inv);
+      const size_t bytes = (size_t)H.n * Rmax * sizeof(T);
+      L.pg.alloc(bytes);
+      L.pc.alloc(bytes);
+      L.pr.alloc(bytes);
+    }
+    if (host.has_dense) {
+      HostDense<T> &Dn = host.dense;
+      const int64_t n = Dn.n;
+      std::vector<T> Rm((size_t)(n * n), T(0));  // R (upper incl. diagonal) or, on the adjoint engine, R^H
+      for (int64_t j = 0; j < n; ++j)
+        for (int64_t i = 0; i <= j; ++i) {
+          if (adjoint)
+            Rm[(size_t)(j + i * n)] = conj_(Dn.qr[(size_t)(i + j * n)]);
+          else
+            Rm[(size_t)(i + j * n)] = Dn.qr[(size_t)(i + j * n)];
+        }
+      dense_explicit_ops(Dn);  // Q^H (and R^{-1}, unused here)
+      const bool real = sizeof(T) == sizeof(double);
+      if (adjoint) {  // _multiply_t needs Q^H and R^H
+        if (real) {
+          dn.QH.upload(to_strip_layout(Dn.QH.data(), n, n));
+          dn.Rm.upload(to_strip_layout(Rm.data(), n, n));
+        } else {
+          dn.QH.upload(Dn.QH);
+          dn.Rm.upload(Rm);
+        }
+      } else {  // _multiply_nt needs R and Q
+        dense_adjoint_ops(Dn);
+        if (real) {
+          dn.Qm.upload(to_strip_layout(Dn.Q.data(), n, n));
+          dn.Rm.upload(to_strip_layout(Rm.data(), n, n));
+        } else {
+          dn.Qm.upload(Dn.Q);
+          dn.Rm.upload(Rm);
+        }
+        if (!dn.tmp2.p) dn.tmp2.alloc((size_t)n * Rmax * sizeof(T));
+      }
+      std::vector<T>().swap(Dn.QH);
+      std::vector<T>().swap(Dn.Rinv);
+      std::vector<T>().swap(Dn.Q);
+      std::vector<T>().swap(Dn.RinvH);
+    }
+    HIP_OK(hipDeviceSynchronize());
+    prod_ready = true;
+  }
+
+  void launch_dense_mul(hipStream_t st, const D *cin, D *zout, int logR, int64_t rank, int64_t &count);
+
+  void enqueue_prod_level(hipStream_t st, size_t l, const D *bin, int64_t ldb, D *yout, int64_t ldy, int nrhs,
+                          int logR, int64_t rank, int64_t &count) {
+    DevLevel &L = *lv[l];
+    const int64_t m = L.m, n = L.n, nm = n - m;
+    const int64_t R = 1LL << logR;
+    D *w = L.w.as<D>(), *v = L.v.as<D>(), *g = L.pg.as<D>(), *cy = L.pc.as<D>(), *r = L.pr.as<D>();
+    const bool last = (l + 1 == lv.size());
+    // g = b[q] / t[q], all n rows  (:76, :97)
+    hipLaunchKernelGGL((k_gather_div<D>), dim3(grid_for(n, logR)), dim3(256), 0, st, bin, ldb, nrhs, L.q.as<int32_t>(),
+                       L.t.as<double>(), n, g, logR);
+    ++count;
+    if (nm) {  // the Schur complement's product -> cy[m:n]  (:80-93)
+      if (last)
+        launch_dense_mul(st, g + m * R, cy + m * R, logR, rank, count);
+      else
+        enqueue_prod_level(st, l + 1, g + m * R, R, cy + m * R, R, (int)R, logR, rank, count);
+    }
+    if (m) {
+      // cy[0:m] = D (U + I) g   (:101-103);  r[0:m] = (L + I) cy   (:106-108)
+      hipLaunchKernelGGL((k_prod_rows<D, true>), dim3(grid_for(m, logR)), dim3(256), 0, st, m, L.U.ptr.as<int32_t>(),
+                         L.U.col.as<int32_t>(), L.U.val.as<D>(), L.U.rowid.as<int32_t>(), (const D *)g, L.d.as<D>(), cy,
+                         logR);
+      hipLaunchKernelGGL((k_prod_rows<D, false>), dim3(grid_for(m, logR)), dim3(256), 0, st, m, L.L.ptr.as<int32_t>(),
+                         L.L.col.as<int32_t>(), L.L.val.as<D>(), L.L.rowid.as<int32_t>(), (const D *)cy,
+                         (const D *)nullptr, r, logR);
+      count += 2;
+      if (L.F_ncols) {  // w = F g[m:n]; r += w   (:112-115)
+        hipLaunchKernelGGL((k_spmm_prod<D, 0>), dim3(grid_for(m, logR)), dim3(256), 0, st, m, L.F.ptr.as<int32_t>(),
+                           L.F.col.as<int32_t>(), L.F.val.as<D>(), (const D *)(g + m * R), w, r, (const D *)nullptr, logR);
+        ++count;
+      } else if (nm) {  // no F: the reference's y(1:m) still holds D(U+I)g when the solve below reads it (:121)
+        hipLaunchKernelGGL((k_vec_op<D>), dim3(vec_grid(m * R)), dim3(256), 0, st, 1, m, (int)R, w, R, (const D *)cy, R,
+                           (const D *)nullptr, (int64_t)0);
+        ++count;
+      }
+    }
+    if (nm) {
+      if (m) {
+        launch_ldu(st, L, logR, count);  // v = (LDU)^{-1} w   (:121)
+        hipLaunchKernelGGL((k_vec_op<D>), dim3(vec_grid(m * R)), dim3(256), 0, st, 2, m, (int)R, v, R, (const D *)g, R,
+                           (const D *)nullptr, (int64_t)0);  // v += g   (:123)
+        ++count;
+      }
+      // r[m:n] = E v + cy[m:n]   (:125-127)
+      hipLaunchKernelGGL((k_spmm_prod<D, 1>), dim3(grid_for(nm, logR)), dim3(256), 0, st, nm, L.E.ptr.as<int32_t>(),
+                         L.E.col.as<int32_t>(), L.E.val.as<D>(), (const D *)v, r + m * R, (D *)nullptr,
+                         (const D *)(cy + m * R), logR);
+      ++count;
+    }
+    // y = r[p_inv] / s   (:132)
+    hipLaunchKernelGGL((k_scatter_div<D>), dim3(grid_for(n, logR)), dim3(256), 0, st, (const D *)r, L.pinv.as<int32_t>(),
+                       L.s.as<double>(), n, yout, ldy, nrhs, logR);
+    ++count;
+  }
+  static unsigned vec_grid(int64_t elems) {
+    int64_t g = (elems + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+  }
+
   // all kernels of one batched apply, nrhs tiled by 64 columns
-  int64_t enqueue_apply(hipStream_t st, const D *dB, int64_t ldb, D *dX, int64_t ldx, int64_t nrhs, int64_t rank) {
+  int64_t enqueue_apply(hipStream_t st, const D *dB, int64_t ldb, D *dX, int64_t ldx, int64_t nrhs, int64_t rank,
+                        int kind = 0) {
     int64_t count = 0;
     for (int64_t c0 = 0; c0 < nrhs; c0 += 64) {
       const int64_t nc = std::min<int64_t>(64, nrhs - c0);
       const int logR = pick_logR(nc);
-      enqueue_level(st, 0, dB + c0, ldb, dX + c0, ldx, (int)nc, logR, rank, count);
+      if (kind == 0)
+        enqueue_level(st, 0, dB + c0, ldb, dX + c0, ldx, (int)nc, logR, rank, count);
+      else
+        enqueue_prod_level(st, 0, dB + c0, ldb, dX + c0, ldx, (int)nc, logR, rank, count);
     }
     HIP_OK(hipGetLastError());
     return count;
@@ -673,15 +805,17 @@ class Engine : public EngineBase {
   }
 
   // graph-cached batched apply on device pointers
-  void solve_dev(const D *dB, int64_t ldb, D *dX, int64_t ldx, int64_t nrhs, int64_t rank, hipStream_t user) {
+  void solve_dev(const D *dB, int64_t ldb, D *dX, int64_t ldx, int64_t nrhs, int64_t rank, hipStream_t user,
+                 int kind = 0) {
     check_batch(dB, ldb, dX, ldx, nrhs);
     HIP_OK(hipSetDevice(device));
+    if (kind == 1) ensure_prod_buffers();
     hipStream_t st = user ? user : stream;
     if (!use_graph) {
-      last_launches = enqueue_apply(st, dB, ldb, dX, ldx, nrhs, rank);
+      last_launches = enqueue_apply(st, dB, ldb, dX, ldx, nrhs, rank, kind);
       return;
     }
-    GraphKey key{dB, dX, ldb, ldx, nrhs, host.has_dense ? eff_rank(rank) : 0};
+    GraphKey key{dB, dX, ldb, ldx, nrhs, host.has_dense ? eff_rank(rank) : 0, kind};
     auto it = graphs.find(key);
     if (it == graphs.end()) {
       if (graphs.size() >= 8) {  // evict the least recently used
@@ -695,7 +829,7 @@ class Engine : public EngineBase {
       GraphEntry ge;
       HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
       try {
-        ge.launches = enqueue_apply(stream, dB, ldb, dX, ldx, nrhs, rank);
+        ge.launches = enqueue_apply(stream, dB, ldb, dX, ldx, nrhs, rank, kind);
       } catch (...) {
         hipGraph_t g = nullptr;
         (void)hipStreamEndCapture(stream, &g);
@@ -1078,9 +1212,27 @@ class Engine : public EngineBase {
 
   // operator selection of lhf?Apply (libhifir.cpp:447-472): S on this engine, SH on the adjoint one
   Engine<T> &for_op(int op) {
-    if (op == HIFAMD_S) return *this;
-    if (op == HIFAMD_SH) return adjoint_engine();
-    throw Error(HIFAMD_HIFIR_ERROR, "LHF_M / LHF_MH (prec_prod) are not on the GPU apply path; use the host library");
+    if (op == HIFAMD_S || op == HIFAMD_M) return *this;
+    if (op == HIFAMD_SH || op == HIFAMD_MH) return adjoint_engine();
+    throw Error(HIFAMD_MISMATCHED_SIZES, "unknown operator tag");
+  }
+  static int kind_of(int op) { return (op == HIFAMD_M || op == HIFAMD_MH) ? 1 : 0; }
+
+  // host-pointer product (lhf?Apply with LHF_M / LHF_MH: direct, no refinement, libhifir.cpp:457-460)
+  void prod_host(const T *B, int64_t ldb, T *X, int64_t ldx, int64_t nrhs, int64_t rank) {
+    check_batch(B, ldb, X, ldx, nrhs);
+    HIP_OK(hipSetDevice(device));
+    const int64_t n = lv[0]->n;
+    const size_t need = (size_t)n * nrhs * sizeof(T);
+    if (stage_b.bytes < need) stage_b.alloc(need);
+    if (stage_x.bytes < need) stage_x.alloc(need);
+    HIP_OK(hipMemcpy2DAsync(stage_b.p, nrhs * sizeof(T), B, ldb * sizeof(T), nrhs * sizeof(T), n,
+                            hipMemcpyHostToDevice, stream));
+    solve_dev(stage_b.as<D>(), nrhs, stage_x.as<D>(), nrhs, nrhs, rank, nullptr, 1);
+    HIP_OK(hipMemcpy2DAsync(X, ldx * sizeof(T), stage_x.p, nrhs * sizeof(T), nrhs * sizeof(T), n,
+                            hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    check_device_error();
   }
 
   // ---- stats ----------------------------------------------------------------------------------
@@ -1197,6 +1349,55 @@ void Engine<zdouble>::launch_dense(hipStream_t st, const cplx *cin, cplx *zout, 
   hipLaunchKernelGGL(k_dense_gemm_z, dim3(grid_for(nd, logR)), dim3(256), 0, st, nd, rk, rk, 1, dn.Rinv.as<cplx>(), nd, tmp,
                      logR, dn.jpvt0.as<int32_t>(), zout, (const cplx *)nullptr, (cplx *)nullptr);
   count += 2;
+}
+
+// dense last level of the product: QRCP::_multiply_nt (QRCP.hpp:460-495) z = Q(:,1:rk) R(1:rk,1:rk) (P^T c)(1:rk);
+// on the adjoint engine QRCP::_multiply_t (:502-541) z[jpvt] = R^H (Q^H c)(1:rk)
+template <>
+void Engine<double>::launch_dense_mul(hipStream_t st, const double *cin, double *zout, int logR, int64_t rank, int64_t &count) {
+  const int nd = (int)dn.n, rk = (int)eff_rank(rank);
+  const unsigned g = (unsigned)((nd + 15) / 16);
+  const dim3 grid(g, ((1u << logR) + 15) / 16);
+  double *tmp = dn.tmp.as<double>();
+  if (adjoint) {
+    hipLaunchKernelGGL(k_dense_gemm_d<4>, grid, dim3(256), 0, st, nd, rk, nd, 0, dn.QH.as<double>(), nd, cin, logR,
+                       (const int32_t *)nullptr, tmp, (const double *)nullptr, (double *)nullptr);
+    hipLaunchKernelGGL(k_dense_gemm_d<4>, grid, dim3(256), 0, st, nd, rk, rk, 2, dn.Rm.as<double>(), nd, (const double *)tmp,
+                       logR, dn.jpvt0.as<int32_t>(), zout, (const double *)nullptr, (double *)nullptr);
+    count += 2;
+    return;
+  }
+  double *tmp2 = dn.tmp2.as<double>();
+  hipLaunchKernelGGL((k_row_gather<double>), dim3(grid_for(nd, logR)), dim3(256), 0, st, cin, dn.jpvt0.as<int32_t>(),
+                     (int64_t)nd, tmp2, logR);
+  hipLaunchKernelGGL(k_dense_gemm_d<4>, grid, dim3(256), 0, st, nd, rk, rk, 1, dn.Rm.as<double>(), nd, (const double *)tmp2,
+                     logR, (const int32_t *)nullptr, tmp, (const double *)nullptr, (double *)nullptr);
+  hipLaunchKernelGGL(k_dense_gemm_d<4>, grid, dim3(256), 0, st, nd, nd, rk, 0, dn.Qm.as<double>(), nd, (const double *)tmp,
+                     logR, (const int32_t *)nullptr, zout, (const double *)nullptr, (double *)nullptr);
+  count += 3;
+}
+
+template <>
+void Engine<zdouble>::launch_dense_mul(hipStream_t st, const cplx *cin, cplx *zout, int logR, int64_t rank, int64_t &count) {
+  const int nd = (int)dn.n, rk = (int)eff_rank(rank);
+  const dim3 grid(grid_for(nd, logR));
+  cplx *tmp = dn.tmp.as<cplx>();
+  if (adjoint) {
+    hipLaunchKernelGGL(k_dense_gemm_z, grid, dim3(256), 0, st, nd, rk, nd, 0, dn.QH.as<cplx>(), nd, cin, logR,
+                       (const int32_t *)nullptr, tmp, (const cplx *)nullptr, (cplx *)nullptr);
+    hipLaunchKernelGGL(k_dense_gemm_z, grid, dim3(256), 0, st, nd, rk, rk, 2, dn.Rm.as<cplx>(), nd, (const cplx *)tmp, logR,
+                       dn.jpvt0.as<int32_t>(), zout, (const cplx *)nullptr, (cplx *)nullptr);
+    count += 2;
+    return;
+  }
+  cplx *tmp2 = dn.tmp2.as<cplx>();
+  hipLaunchKernelGGL((k_row_gather<cplx>), dim3(grid_for(nd, logR)), dim3(256), 0, st, cin, dn.jpvt0.as<int32_t>(),
+                     (int64_t)nd, tmp2, logR);
+  hipLaunchKernelGGL(k_dense_gemm_z, grid, dim3(256), 0, st, nd, rk, rk, 1, dn.Rm.as<cplx>(), nd, (const cplx *)tmp2, logR,
+                     (const int32_t *)nullptr, tmp, (const cplx *)nullptr, (cplx *)nullptr);
+  hipLaunchKernelGGL(k_dense_gemm_z, grid, dim3(256), 0, st, nd, nd, rk, 0, dn.Qm.as<cplx>(), nd, (const cplx *)tmp, logR,
+                     (const int32_t *)nullptr, zout, (const cplx *)nullptr, (cplx *)nullptr);
+  count += 3;
 }
 
 // one diagonal block of a block-dense thin band: t = rhs - (everything before the block); then
@@ -1502,18 +1703,27 @@ HifAmdStatus hifamd_hifir_batch_dev(HifAmdHdl h, const void *dB, int64_t ldb, vo
 HifAmdStatus hifamd_apply_batch(HifAmdHdl h, HifAmdOp op, const void *B, int64_t ldb, void *X, int64_t ldx, int64_t nrhs,
                                 int nirs, const double *betas, int64_t rank, int *ir_status) {
   API_BEGIN
-  if (rank == -2) rank = (nirs > 1) ? -1 : 0;  // LHF_DEFAULT_RANK, libhifir.cpp:453-455
-  DISPATCH(ENG_D->for_op(op).hifir_host((const double *)B, ldb, (double *)X, ldx, nrhs, nirs, betas, rank, ir_status),
-           ENG_Z->for_op(op).hifir_host((const zdouble *)B, ldb, (zdouble *)X, ldx, nrhs, nirs, betas, rank, ir_status))
+  const bool prod = (op == HIFAMD_M || op == HIFAMD_MH);
+  if (rank == -2) rank = (prod || nirs > 1) ? -1 : 0;  // LHF_DEFAULT_RANK, libhifir.cpp:453-455
+  if (prod) {
+    DISPATCH(ENG_D->for_op(op).prod_host((const double *)B, ldb, (double *)X, ldx, nrhs, rank),
+             ENG_Z->for_op(op).prod_host((const zdouble *)B, ldb, (zdouble *)X, ldx, nrhs, rank))
+    if (ir_status)
+      for (int64_t c = 0; c < nrhs; ++c) ir_status[2 * c] = 1, ir_status[2 * c + 1] = -1;
+  } else {
+    DISPATCH(ENG_D->for_op(op).hifir_host((const double *)B, ldb, (double *)X, ldx, nrhs, nirs, betas, rank, ir_status),
+             ENG_Z->for_op(op).hifir_host((const zdouble *)B, ldb, (zdouble *)X, ldx, nrhs, nirs, betas, rank, ir_status))
+  }
   API_END
 }
 
 HifAmdStatus hifamd_apply_batch_dev(HifAmdHdl h, HifAmdOp op, const void *dB, int64_t ldb, void *dX, int64_t ldx,
                                     int64_t nrhs, int64_t rank, void *stream) {
   API_BEGIN
-  if (rank == -2) rank = 0;
-  DISPATCH(ENG_D->for_op(op).solve_dev((const double *)dB, ldb, (double *)dX, ldx, nrhs, rank, (hipStream_t)stream),
-           ENG_Z->for_op(op).solve_dev((const cplx *)dB, ldb, (cplx *)dX, ldx, nrhs, rank, (hipStream_t)stream))
+  const int kind = (op == HIFAMD_M || op == HIFAMD_MH) ? 1 : 0;
+  if (rank == -2) rank = kind ? -1 : 0;
+  DISPATCH(ENG_D->for_op(op).solve_dev((const double *)dB, ldb, (double *)dX, ldx, nrhs, rank, (hipStream_t)stream, kind),
+           ENG_Z->for_op(op).solve_dev((const cplx *)dB, ldb, (cplx *)dX, ldx, nrhs, rank, (hipStream_t)stream, kind))
   API_END
 }
 

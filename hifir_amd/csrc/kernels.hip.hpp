@@ -550,6 +550,83 @@ __global__ void __launch_bounds__(256) k_crs_spmm(int64_t nrows, const int32_t *
 }
 
 // ---------------------------------------------------------------------------------------------
+// prec_prod (y = M b, alg/prec_prod.hpp:55-147): the inverse direction of the apply.  No dependent steps
+// except the one LDU solve of the Schur coupling term, so these are plain row-gather kernels.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double vdivr(double a, double r) { return a / r; }
+__device__ __forceinline__ cplx vdivr(cplx a, double r) { return cplx{a.x / r, a.y / r}; }
+
+// g[i] = b[q[i]] / t[q[i]], rows [0, cnt)   (:76, :97; with (p, s) for the transposed product)
+template <class T>
+__global__ void __launch_bounds__(256) k_gather_div(const T *__restrict__ bin, int64_t ldb, int nrhs,
+                                                    const int32_t *__restrict__ q, const double *__restrict__ t,
+                                                    int64_t cnt, T *__restrict__ g, int logR) {
+  const LaneMap lm = lane_map(logR);
+  const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = wave * lm.G + lm.g; i < cnt; i += nwaves * lm.G) {
+    const int32_t src = q[i];
+    T val = vzero(T());
+    if (lm.c < nrhs) val = vdivr(bin[(int64_t)src * ldb + lm.c], t[src]);
+    g[(i << logR) + lm.c] = val;
+  }
+}
+
+// y[i] = r[p_inv[i]] / s[i], rows [0, n)   (:132)
+template <class T>
+__global__ void __launch_bounds__(256) k_scatter_div(const T *__restrict__ r, const int32_t *__restrict__ pinv,
+                                                     const double *__restrict__ s, int64_t n, T *__restrict__ yout,
+                                                     int64_t ldy, int nrhs, int logR) {
+  const LaneMap lm = lane_map(logR);
+  const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = wave * lm.G + lm.g; i < n; i += nwaves * lm.G)
+    if (lm.c < nrhs) yout[i * ldy + lm.c] = vdivr(r[((int64_t)pinv[i] << logR) + lm.c], s[i]);
+}
+
+// rows of a unit triangle times a vector, slot-ordered CSR (rowid): out[i] = (sum_k A(i,k) x[k] + x[i]) [* d[i]]
+// (:101-103 with d, :106-108 without)
+template <class T, bool SCALE>
+__global__ void __launch_bounds__(256) k_prod_rows(int64_t nrows, const int32_t *__restrict__ ptr,
+                                                   const int32_t *__restrict__ col, const T *__restrict__ val,
+                                                   const int32_t *__restrict__ rowid, const T *__restrict__ x,
+                                                   const T *__restrict__ d, T *__restrict__ out, int logR) {
+  const LaneMap lm = lane_map(logR);
+  const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t sidx = wave * lm.G + lm.g; sidx < nrows; sidx += nwaves * lm.G) {
+    const int64_t i = rowid[sidx];
+    T acc = vzero(T());
+    for (int32_t k = ptr[sidx]; k < ptr[sidx + 1]; ++k) acc = vadd(acc, vmul(x[((int64_t)col[k] << logR) + lm.c], val[k]));
+    acc = vadd(acc, x[(i << logR) + lm.c]);
+    if (SCALE) acc = vmul(acc, d[i]);
+    out[(i << logR) + lm.c] = acc;
+  }
+}
+
+// t = sum_k A(i,k) x[k];  MODE 0: out[i] = t, acc[i] += t  (F term, :113-114)
+//                         MODE 1: out[i] = t + add[i]      (E term + child product, :125-127)
+template <class T, int MODE>
+__global__ void __launch_bounds__(256) k_spmm_prod(int64_t nrows, const int32_t *__restrict__ ptr,
+                                                   const int32_t *__restrict__ col, const T *__restrict__ val,
+                                                   const T *__restrict__ x, T *__restrict__ out, T *accio,
+                                                   const T *__restrict__ add, int logR) {
+  const LaneMap lm = lane_map(logR);
+  const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = wave * lm.G + lm.g; i < nrows; i += nwaves * lm.G) {
+    T t = vzero(T());
+    for (int32_t k = ptr[i]; k < ptr[i + 1]; ++k) t = vadd(t, vmul(x[((int64_t)col[k] << logR) + lm.c], val[k]));
+    if (MODE == 0) {
+      out[(i << logR) + lm.c] = t;
+      accio[(i << logR) + lm.c] = vadd(accio[(i << logR) + lm.c], t);
+    } else {
+      out[(i << logR) + lm.c] = vadd(t, add[(i << logR) + lm.c]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // BLAS-1 helpers of iterative refinement (alg/IterRefine.hpp:99,103,147,156-157), [n][nrhs] blocks
 // ---------------------------------------------------------------------------------------------
 // op 0: y = 0 | 1: y = x | 2: y += x | 3: y = x + z

@@ -231,6 +231,25 @@ class HIF:
             _check(lib().hifamd_solve_batch(self._h, _p(B), B.shape[1], _p(X), X.shape[1], B.shape[1], int(rank)))
         return X
 
+    def mmultiply(self, x, trans=False, rank=-1):
+        """y = M x (trans: M^H x), the multilevel product HIF::mmultiply (builder.hpp:503-513) -- the inverse
+        direction of solve().  x: [n] or [n][nrhs], host array or CUDA tensor."""
+        op = OP_MH if trans else OP_M
+        vec = (x.ndim == 1)
+        if _is_torch(x):
+            import torch
+
+            X = x.reshape(x.shape[0], -1)
+            Y = torch.empty_like(X)
+            _check(lib().hifamd_apply_batch_dev(self._h, op, X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0),
+                                               X.shape[1], int(rank), None))
+        else:
+            X = np.ascontiguousarray(x, dtype=self.dtype).reshape(x.shape[0], -1)
+            Y = np.empty_like(X)
+            _check(lib().hifamd_apply_batch(self._h, op, _p(X), X.shape[1], _p(Y), Y.shape[1], X.shape[1], 1, None,
+                                           int(rank), None))
+        return Y.reshape(-1) if vec else Y
+
     def spmv(self, X, Y=None, stream=None):
         """Y = A X on the device (torch CUDA tensors, [n][nrhs] or [n])."""
         import torch

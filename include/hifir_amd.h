@@ -46,8 +46,8 @@ typedef enum HifAmdValueType { HIFAMD_D = 0, HIFAMD_Z = 1 } HifAmdValueType;
 typedef enum HifAmdOp {
   HIFAMD_S = 0, /* x = M^{-1} b   (prec_solve,      alg/prec_solve.hpp:332-412) */
   HIFAMD_SH,    /* x = M^{-H} b   (prec_solve_tran, alg/prec_solve.hpp:542-612) */
-  HIFAMD_M,     /* x = M b    -- not on the GPU path: HIFAMD_HIFIR_ERROR */
-  HIFAMD_MH     /* x = M^H b  -- not on the GPU path: HIFAMD_HIFIR_ERROR */
+  HIFAMD_M,     /* x = M b        (prec_prod,       alg/prec_prod.hpp:55-147)  */
+  HIFAMD_MH     /* x = M^H b      (prec_prod_tran,  alg/prec_prod.hpp:148-235) */
 } HifAmdOp;
 
 typedef struct HifAmdPrec *HifAmdHdl; /* opaque: one multilevel preconditioner resident in HBM */
@@ -70,7 +70,7 @@ HifAmdStatus hifamd_destroy(HifAmdHdl h); /* NULL-safe, frees HBM (cf. lhf?Destr
  *   L_B, U_B : m x m strict triangles, implicit unit diagonal, sorted row indices
  *   E        : (n-m) x m,   F : m x F_ncols (F_ncols == n-m, or 0 when absent; prec_solve.hpp:395)
  * d: m values; s,t: n REAL scalings (Prec.hpp:96-99); p, q_inv: n 0-based permutations.
- * p_inv and q are only needed by the transpose operator (HIFAMD_SH) and may be NULL otherwise. */
+ * p_inv and q are only needed by HIFAMD_SH / HIFAMD_M / HIFAMD_MH and may be NULL otherwise. */
 HifAmdStatus hifamd_add_level(HifAmdHdl h, int64_t m, int64_t n,
                               const int64_t *L_colptr, const int32_t *L_rowind, const void *L_vals,
                               const int64_t *U_colptr, const int32_t *U_rowind, const void *U_vals,
@@ -141,12 +141,14 @@ HifAmdStatus hifamd_hifir_batch_dev(HifAmdHdl h, const void *dB, int64_t ldb, vo
                                     int *ir_status);
 
 /* ---- lhf?Apply with an operator tag (libhifir.h:685, libhifir.cpp:447-472), batched ----------- */
-/* op = HIFAMD_S / HIFAMD_SH.  nirs <= 1: direct apply (ir_status, if given, gets {1, -1} per column);
+/* op = HIFAMD_S / HIFAMD_SH: nirs <= 1 direct apply (ir_status, if given, gets {1, -1} per column);
  * nirs > 1: iterative refinement with A (HIFAMD_S) or A^H (HIFAMD_SH, IterRefine.hpp:93-96).
- * rank = -2 (LHF_DEFAULT_RANK) -> full rank when refining, numerical rank otherwise (libhifir.cpp:453-455).
+ * op = HIFAMD_M / HIFAMD_MH: the multilevel product (HIF::mmultiply, builder.hpp:503-513), always direct.
+ * rank = -2 (LHF_DEFAULT_RANK) -> full rank for products and when refining, numerical rank otherwise
+ * (libhifir.cpp:453-455).
  * The adjoint hierarchy (U^H, L^H, F^H, E^H, conj(d), (t,q) in, (s,p_inv) out, A^H solve on the dense
  * block) is analysed and shipped to HBM on the first HIFAMD_SH call; it needs the q and p_inv arrays
- * in hifamd_add_level.  Host pointers. */
+ * in hifamd_add_level (so do the product operators).  Host pointers. */
 HifAmdStatus hifamd_apply_batch(HifAmdHdl h, HifAmdOp op, const void *B, int64_t ldb, void *X, int64_t ldx,
                                 int64_t nrhs, int nirs, const double *betas, int64_t rank, int *ir_status);
 /* direct apply with device pointers, enqueued on `stream` and not synchronized */

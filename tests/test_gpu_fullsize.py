@@ -98,6 +98,15 @@ def test_1m_linearity_and_roundtrip(big):
     assert relerr(X[:, 2], lin) <= 1e-12
     b_back = O.mmultiply(X[:, 0].copy())
     assert np.linalg.norm(b_back - b1) / np.linalg.norm(b1) <= 1e-10
+    # the same round trip entirely on the device (LHF_M / LHF_MH), both directions, vs oracle and reference
+    Y = M.mmultiply(X)
+    assert (np.linalg.norm(Y - B, axis=0) / np.linalg.norm(B, axis=0)).max() <= 1e-10
+    assert relerr(Y[:, 0], b_back) <= 1e-10
+    assert relerr(Y[:, 1], R.mmultiply(X[:, 1].copy())) <= 1e-10
+    XH = M.solve_mrhs(B, trans=True)
+    YH = M.mmultiply(XH, trans=True)
+    assert (np.linalg.norm(YH - B, axis=0) / np.linalg.norm(B, axis=0)).max() <= 1e-10
+    assert relerr(YH[:, 2], R.mmultiply(XH[:, 2].copy(), trans=True)) <= 1e-10
 
 
 def test_1m_iterative_refinement_matches_reference(big):

@@ -159,6 +159,41 @@ def test_transposed_solve(cache, name):
     assert relerr(M.hifir(d["b"], 4, trans=True), x) <= 1e-10
 
 
+@pytest.mark.parametrize("name", HIER_NAMES)
+def test_multilevel_product(cache, name):
+    # LHF_M / LHF_MH: y = M x and M^H x (prec_prod / prec_prod_tran) vs the oracle restatements, the real
+    # reference's golden b2, and the round trips M (M^{-1} b) = b of libhifir/tests/test_real.c:110-146
+    torch = pytest.importorskip("torch")
+    levels, d, M, O = _get(cache, name)
+    nrm = np.linalg.norm(d["b"])
+    b2 = M.mmultiply(d["x"])
+    assert relerr(b2, O.mmultiply(d["x"])) <= 1e-10
+    assert relerr(b2, d["b2"]) <= 1e-10
+    assert np.linalg.norm(b2 - d["b"]) / nrm <= 1e-10
+    bt = M.mmultiply(d["xt"], trans=True)
+    assert relerr(bt, O.mmultiply(d["xt"], trans=True)) <= 1e-10
+    assert np.linalg.norm(bt - d["b"]) / nrm <= 1e-10
+    # batched, wider than one tile, entirely on the device: M (M^{-1} B) = B and M^H (M^{-H} B) = B
+    n = len(d["b"])
+    rng = np.random.default_rng(29)
+    B = rng.uniform(-1, 1, size=(n, 70)).astype(d["b"].dtype)
+    if np.iscomplexobj(B):
+        B = B + 1j * rng.uniform(-1, 1, size=(n, 70))
+    Bd = torch.from_numpy(B).cuda()
+    for tr in (False, True):
+        Xd = M.solve_mrhs(Bd, trans=tr, rank=-1)
+        Yd = M.mmultiply(Xd, trans=tr)
+        M.sync()
+        torch.cuda.synchronize()
+        Y = Yd.cpu().numpy()
+        assert (np.linalg.norm(Y - B, axis=0) / np.linalg.norm(B, axis=0)).max() <= 1e-9
+        k = 33
+        assert relerr(Y[:, k], O.mmultiply(Xd[:, k].cpu().numpy().copy(), trans=tr, rank=-1)) <= 1e-10
+    # an explicit rank goes to the dense block's product like in the reference (QRCP.hpp:466-467)
+    if levels[-1].get("dense_n", 0) > 8:
+        assert relerr(M.mmultiply(d["x"], rank=5), O.mmultiply(d["x"], rank=5)) <= 1e-10
+
+
 def test_spmv_bitwise(cache):
     torch = pytest.importorskip("torch")
     levels, d, M, O = _get(cache, "cd2d_48")
@@ -186,10 +221,9 @@ def test_error_paths(cache):
     import ctypes as C
     x = np.empty_like(d["b"])
     bb = np.ascontiguousarray(d["b"])
-    for op in (2, 3):  # LHF_M / LHF_MH stay on the host library
-        rc = hifir_amd.lib().hifamd_apply_batch(M._h, op, bb.ctypes.data_as(C.c_void_p), 1, x.ctypes.data_as(C.c_void_p),
-                                                1, 1, 1, None, 0, None)
-        assert rc == 4 and b"LHF_M" in hifir_amd.lib().hifamd_last_error()
+    rc = hifir_amd.lib().hifamd_apply_batch(M._h, 7, bb.ctypes.data_as(C.c_void_p), 1, x.ctypes.data_as(C.c_void_p),
+                                            1, 1, 1, None, 0, None)
+    assert rc == 2 and b"operator" in hifir_amd.lib().hifamd_last_error()
     b = np.ascontiguousarray(d["b"])
     rc = hifir_amd.lib().hifamd_solve(M._h, b.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), 0)
     assert rc == 3  # aliasing b and x is refused (libhifir Ownership: b and x must not alias)
