@@ -95,7 +95,7 @@ struct DevCsr {
   DevBuf tinv;  // explicit inverses of the diagonal blocks of block-dense thin bands
 
   template <class T>
-  void upload(const Csr<T> &A, const BandPlan *P, const std::vector<T> *inv = nullptr) {
+  void upload(const Csr<T> &A, const BandPlan *P, const std::vector<double> *inv = nullptr) {
     nrows = A.nrows;
     ncols = A.ncols;
     nnz = (int64_t)A.col.size();
@@ -189,6 +189,7 @@ class Engine : public EngineBase {
   BandOptions band_opt;  // how triangles are cut into bands (host.hpp)
   DevBuf errflag;        // sticky error word: a bounded spin of k_trsv_band expired
   DevBuf blk_tmp;        // right-hand side of one diagonal block of a block-dense thin band
+  DevBuf zt1, zt2;       // complex handles: the two real partial products A_re X, A_im X (k_zcombine)
   // IR scratch
   DevBuf ir_r, ir_xk, ir_part, stage_b, stage_x;
   DevBuf gm_v, gm_w, gm_Q, gm_alpha;  // GMRES: work vectors, Krylov basis, per-column coefficients
@@ -440,8 +441,8 @@ class Engine : public EngineBase {
       L.F_ncols = H.F_ncols;
       L.L.upload(H.Lr, &H.Lp, &H.Ltinv);
       L.U.upload(H.Ur, &H.Up, &H.Utinv);
-      std::vector<T>().swap(H.Ltinv);
-      std::vector<T>().swap(H.Utinv);
+      std::vector<double>().swap(H.Ltinv);
+      std::vector<double>().swap(H.Utinv);
       L.E.upload(H.Er, nullptr);
       L.F.upload(H.Fr, nullptr);
       L.d.upload(H.d);
@@ -459,25 +460,15 @@ class Engine : public EngineBase {
     if (host.has_dense) {
       dn.n = host.dense.n;
       dn.rank = host.dense.rank;
-      if (adjoint) {
-        // operators of the A^H solve are uploaded below
-      } else if (sizeof(T) == sizeof(double)) {  // strip-major operands for the MFMA kernel
-        dn.QH.upload(to_strip_layout(host.dense.QH.data(), dn.n, dn.n));
-        dn.Rinv.upload(to_strip_layout(host.dense.Rinv.data(), dn.n, dn.n));
-      } else {
-        dn.QH.upload(host.dense.QH);
-        dn.Rinv.upload(host.dense.Rinv);
+      if (!adjoint) {  // MFMA operands (complex: two real planes each)
+        dn.QH.upload(mfma_operand(host.dense.QH.data(), dn.n, dn.n));
+        dn.Rinv.upload(mfma_operand(host.dense.Rinv.data(), dn.n, dn.n));
       }
       dn.jpvt0.upload(host.dense.jpvt0);
       dn.tmp.alloc((size_t)dn.n * Rmax * sizeof(T));
       if (adjoint) {
-        if (sizeof(T) == sizeof(double)) {
-          dn.Qm.upload(to_strip_layout(host.dense.Q.data(), dn.n, dn.n));
-          dn.RinvH.upload(to_strip_layout(host.dense.RinvH.data(), dn.n, dn.n));
-        } else {
-          dn.Qm.upload(host.dense.Q);
-          dn.RinvH.upload(host.dense.RinvH);
-        }
+        dn.Qm.upload(mfma_operand(host.dense.Q.data(), dn.n, dn.n));
+        dn.RinvH.upload(mfma_operand(host.dense.RinvH.data(), dn.n, dn.n));
         dn.tmp2.alloc((size_t)dn.n * Rmax * sizeof(T));
         std::vector<T>().swap(host.dense.Q);
         std::vector<T>().swap(host.dense.RinvH);
@@ -488,6 +479,11 @@ class Engine : public EngineBase {
     }
     errflag.alloc(sizeof(unsigned));
     HIP_OK(hipMemset(errflag.p, 0, errflag.bytes));
+    if (sizeof(T) != sizeof(double)) {
+      const size_t rows = (size_t)std::max<int64_t>(band_opt.dense_block + 32, host.has_dense ? host.dense.n + 32 : 0);
+      zt1.alloc(rows * (size_t)Rmax * 2 * sizeof(double));
+      zt2.alloc(rows * (size_t)Rmax * 2 * sizeof(double));
+    }
     {
       const int remap = env_int("HIFIR_AMD_XCD", 1);
       HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_remap), &remap, sizeof(int)));
@@ -604,6 +600,36 @@ class Engine : public EngineBase {
     launch_trsv<false>(st, L, logR, count);
   }
 
+  // complex products on the real matrix cores (operands: two real planes, see host.hpp mfma_operand)
+  void zgemm(hipStream_t st, int rows_total, int rows_valid, int kend, int tri, const DevBuf &A, int lda, const cplx *X,
+             int logR, const int32_t *rowmap, cplx *Out, const cplx *dscale, cplx *Out2, int64_t &count) {
+    const double *Are = A.as<double>(), *Aim = Are + plane_elems(rows_total, lda);
+    const dim3 grid((unsigned)((rows_total + 15) / 16), ((2u << logR) + 15) / 16);
+    double *t1 = zt1.as<double>(), *t2 = zt2.as<double>();
+    hipLaunchKernelGGL(k_dense_gemm_d<4>, grid, dim3(256), 0, st, rows_total, rows_valid, kend, tri, Are, lda,
+                       (const double *)X, logR + 1, (const int32_t *)nullptr, t1, (const double *)nullptr, (double *)nullptr);
+    hipLaunchKernelGGL(k_dense_gemm_d<4>, grid, dim3(256), 0, st, rows_total, rows_valid, kend, tri, Aim, lda,
+                       (const double *)X, logR + 1, (const int32_t *)nullptr, t2, (const double *)nullptr, (double *)nullptr);
+    hipLaunchKernelGGL(k_zcombine, dim3(grid_for(rows_total, logR)), dim3(256), 0, st, (int64_t)rows_total,
+                       (const double *)t1, (const double *)t2, logR, rowmap, Out, dscale, Out2);
+    count += 3;
+  }
+  void zgemm_tri(hipStream_t st, int nb, const double *Aops, const cplx *X, int logR, const int32_t *rowmap, cplx *Out,
+                 const cplx *dscale, cplx *Out2, int64_t &count) {
+    const int lda = (int)round_up32(nb);
+    const double *Are = Aops, *Aim = Aops + plane_elems(nb, lda);
+    const unsigned pairs = (unsigned)(((nb + 15) / 16 + 1) / 2);
+    const dim3 grid(pairs, ((2u << logR) + 15) / 16);
+    double *t1 = zt1.as<double>(), *t2 = zt2.as<double>();
+    hipLaunchKernelGGL(k_tri_gemm_d<16>, grid, dim3(1024), 0, st, nb, Are, lda, (const double *)X, logR + 1,
+                       (const int32_t *)nullptr, t1, (const double *)nullptr, (double *)nullptr);
+    hipLaunchKernelGGL(k_tri_gemm_d<16>, grid, dim3(1024), 0, st, nb, Aim, lda, (const double *)X, logR + 1,
+                       (const int32_t *)nullptr, t2, (const double *)nullptr, (double *)nullptr);
+    hipLaunchKernelGGL(k_zcombine, dim3(grid_for(nb, logR)), dim3(256), 0, st, (int64_t)nb, (const double *)t1,
+                       (const double *)t2, logR, rowmap, Out, dscale, Out2);
+    count += 3;
+  }
+
   void launch_dense(hipStream_t st, const D *cin, D *zout, int logR, int64_t rank, int64_t &count);
 
   int64_t eff_rank(int64_t rank) const {
@@ -686,24 +712,13 @@ class Engine : public EngineBase {
             Rm[(size_t)(i + j * n)] = Dn.qr[(size_t)(i + j * n)];
         }
       dense_explicit_ops(Dn);  // Q^H (and R^{-1}, unused here)
-      const bool real = sizeof(T) == sizeof(double);
       if (adjoint) {  // _multiply_t needs Q^H and R^H
-        if (real) {
-          dn.QH.upload(to_strip_layout(Dn.QH.data(), n, n));
-          dn.Rm.upload(to_strip_layout(Rm.data(), n, n));
-        } else {
-          dn.QH.upload(Dn.QH);
-          dn.Rm.upload(Rm);
-        }
+        dn.QH.upload(mfma_operand(Dn.QH.data(), n, n));
+        dn.Rm.upload(mfma_operand(Rm.data(), n, n));
       } else {  // _multiply_nt needs R and Q
         dense_adjoint_ops(Dn);
-        if (real) {
-          dn.Qm.upload(to_strip_layout(Dn.Q.data(), n, n));
-          dn.Rm.upload(to_strip_layout(Rm.data(), n, n));
-        } else {
-          dn.Qm.upload(Dn.Q);
-          dn.Rm.upload(Rm);
-        }
+        dn.Qm.upload(mfma_operand(Dn.Q.data(), n, n));
+        dn.Rm.upload(mfma_operand(Rm.data(), n, n));
         if (!dn.tmp2.p) dn.tmp2.alloc((size_t)n * Rmax * sizeof(T));
       }
       std::vector<T>().swap(Dn.QH);
@@ -1337,18 +1352,13 @@ void Engine<zdouble>::launch_dense(hipStream_t st, const cplx *cin, cplx *zout, 
     cplx *tmp2 = dn.tmp2.as<cplx>();
     hipLaunchKernelGGL((k_row_gather<cplx>), dim3(grid_for(nd, logR)), dim3(256), 0, st, cin, dn.jpvt0.as<int32_t>(),
                        (int64_t)nd, tmp2, logR);
-    hipLaunchKernelGGL(k_dense_gemm_z, dim3(grid_for(nd, logR)), dim3(256), 0, st, nd, rk, rk, 2, dn.RinvH.as<cplx>(), nd,
-                       (const cplx *)tmp2, logR, (const int32_t *)nullptr, tmp, (const cplx *)nullptr, (cplx *)nullptr);
-    hipLaunchKernelGGL(k_dense_gemm_z, dim3(grid_for(nd, logR)), dim3(256), 0, st, nd, nd, rk, 0, dn.Qm.as<cplx>(), nd,
-                       (const cplx *)tmp, logR, (const int32_t *)nullptr, zout, (const cplx *)nullptr, (cplx *)nullptr);
-    count += 3;
+    ++count;
+    zgemm(st, nd, rk, rk, 2, dn.RinvH, nd, tmp2, logR, nullptr, tmp, nullptr, nullptr, count);
+    zgemm(st, nd, nd, rk, 0, dn.Qm, nd, tmp, logR, nullptr, zout, nullptr, nullptr, count);
     return;
   }
-  hipLaunchKernelGGL(k_dense_gemm_z, dim3(grid_for(nd, logR)), dim3(256), 0, st, nd, rk, nd, 0, dn.QH.as<cplx>(), nd, cin,
-                     logR, (const int32_t *)nullptr, tmp, (const cplx *)nullptr, (cplx *)nullptr);
-  hipLaunchKernelGGL(k_dense_gemm_z, dim3(grid_for(nd, logR)), dim3(256), 0, st, nd, rk, rk, 1, dn.Rinv.as<cplx>(), nd, tmp,
-                     logR, dn.jpvt0.as<int32_t>(), zout, (const cplx *)nullptr, (cplx *)nullptr);
-  count += 2;
+  zgemm(st, nd, rk, nd, 0, dn.QH, nd, cin, logR, nullptr, tmp, nullptr, nullptr, count);
+  zgemm(st, nd, rk, rk, 1, dn.Rinv, nd, tmp, logR, dn.jpvt0.as<int32_t>(), zout, nullptr, nullptr, count);
 }
 
 // dense last level of the product: QRCP::_multiply_nt (QRCP.hpp:460-495) z = Q(:,1:rk) R(1:rk,1:rk) (P^T c)(1:rk);
@@ -1380,24 +1390,18 @@ void Engine<double>::launch_dense_mul(hipStream_t st, const double *cin, double 
 template <>
 void Engine<zdouble>::launch_dense_mul(hipStream_t st, const cplx *cin, cplx *zout, int logR, int64_t rank, int64_t &count) {
   const int nd = (int)dn.n, rk = (int)eff_rank(rank);
-  const dim3 grid(grid_for(nd, logR));
   cplx *tmp = dn.tmp.as<cplx>();
   if (adjoint) {
-    hipLaunchKernelGGL(k_dense_gemm_z, grid, dim3(256), 0, st, nd, rk, nd, 0, dn.QH.as<cplx>(), nd, cin, logR,
-                       (const int32_t *)nullptr, tmp, (const cplx *)nullptr, (cplx *)nullptr);
-    hipLaunchKernelGGL(k_dense_gemm_z, grid, dim3(256), 0, st, nd, rk, rk, 2, dn.Rm.as<cplx>(), nd, (const cplx *)tmp, logR,
-                       dn.jpvt0.as<int32_t>(), zout, (const cplx *)nullptr, (cplx *)nullptr);
-    count += 2;
+    zgemm(st, nd, rk, nd, 0, dn.QH, nd, cin, logR, nullptr, tmp, nullptr, nullptr, count);
+    zgemm(st, nd, rk, rk, 2, dn.Rm, nd, tmp, logR, dn.jpvt0.as<int32_t>(), zout, nullptr, nullptr, count);
     return;
   }
   cplx *tmp2 = dn.tmp2.as<cplx>();
   hipLaunchKernelGGL((k_row_gather<cplx>), dim3(grid_for(nd, logR)), dim3(256), 0, st, cin, dn.jpvt0.as<int32_t>(),
                      (int64_t)nd, tmp2, logR);
-  hipLaunchKernelGGL(k_dense_gemm_z, grid, dim3(256), 0, st, nd, rk, rk, 1, dn.Rm.as<cplx>(), nd, (const cplx *)tmp2, logR,
-                     (const int32_t *)nullptr, tmp, (const cplx *)nullptr, (cplx *)nullptr);
-  hipLaunchKernelGGL(k_dense_gemm_z, grid, dim3(256), 0, st, nd, nd, rk, 0, dn.Qm.as<cplx>(), nd, (const cplx *)tmp, logR,
-                     (const int32_t *)nullptr, zout, (const cplx *)nullptr, (cplx *)nullptr);
-  count += 3;
+  ++count;
+  zgemm(st, nd, rk, rk, 1, dn.Rm, nd, tmp2, logR, nullptr, tmp, nullptr, nullptr, count);
+  zgemm(st, nd, nd, rk, 0, dn.Qm, nd, tmp, logR, nullptr, zout, nullptr, nullptr, count);
 }
 
 // one diagonal block of a block-dense thin band: t = rhs - (everything before the block); then
@@ -1440,11 +1444,9 @@ void Engine<zdouble>::launch_dense_block(hipStream_t st, const DevLevel &L, cons
   hipLaunchKernelGGL((k_thin_update<cplx>), dim3(grid_for(nb, logR)), dim3(256), 0, st, r0, r1, M.ptr.as<int32_t>(),
                      M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<cplx>(), M.srcslot.as<int32_t>(),
                      M.rowid.as<int32_t>(), (const cplx *)x, tb, logR);
-  hipLaunchKernelGGL(k_dense_gemm_z, dim3(grid_for(nb, logR)), dim3(256), 0, st, nb, nb, nb, 2,
-                     M.tinv.as<cplx>() + M.blk_inv_off[(size_t)q], nb, (const cplx *)tb, logR,
-                     M.rowid.as<int32_t>() + r0, x, LOWER ? L.d.as<cplx>() : (const cplx *)nullptr,
-                     LOWER ? L.v.as<cplx>() : (cplx *)nullptr);
-  count += 2;
+  ++count;
+  zgemm_tri(st, nb, M.tinv.as<double>() + M.blk_inv_off[(size_t)q], (const cplx *)tb, logR, M.rowid.as<int32_t>() + r0, x,
+            LOWER ? L.d.as<cplx>() : (const cplx *)nullptr, LOWER ? L.v.as<cplx>() : (cplx *)nullptr, count);
 }
 
 }  // namespace hifamd

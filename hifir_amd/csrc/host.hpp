@@ -44,6 +44,26 @@ std::vector<T> to_strip_layout(const T *colmajor, int64_t nrows, int64_t ncols, 
 }
 inline int64_t round_up32(int64_t x) { return (x + 31) & ~(int64_t)31; }
 
+// Operand of the f64 MFMA kernels from a column-major matrix: real -> one strip-major plane; complex ->
+// TWO real strip-major planes [re | im] (gfx950 has no complex MFMA: a complex product runs as the two
+// real products A_re * X and A_im * X on the interleaved real view of X, recombined by k_zcombine).
+inline int64_t plane_elems(int64_t nrows, int64_t ldk) { return ((nrows + 15) / 16) * 16 * ldk; }
+inline std::vector<double> mfma_operand(const double *colmajor, int64_t nrows, int64_t ncols, int64_t ldk = 0) {
+  return to_strip_layout(colmajor, nrows, ncols, ldk);
+}
+inline std::vector<double> mfma_operand(const zdouble *colmajor, int64_t nrows, int64_t ncols, int64_t ldk = 0) {
+  if (ldk < ncols) ldk = ncols;
+  std::vector<double> re((size_t)(nrows * ncols)), im((size_t)(nrows * ncols));
+  for (int64_t k = 0; k < nrows * ncols; ++k) {
+    re[(size_t)k] = colmajor[k].real();
+    im[(size_t)k] = colmajor[k].imag();
+  }
+  std::vector<double> out = to_strip_layout(re.data(), nrows, ncols, ldk);
+  const std::vector<double> pi = to_strip_layout(im.data(), nrows, ncols, ldk);
+  out.insert(out.end(), pi.begin(), pi.end());
+  return out;
+}
+
 // ---------------------------------------------------------------------------------------------
 // matrices
 // ---------------------------------------------------------------------------------------------
@@ -415,7 +435,8 @@ BandPlan plan_bands(const Csr<T> &A, const Schedule &S, bool lower, const BandOp
 // on the hierarchies measured); a band whose inverse entries grow beyond dense_max_growth keeps the
 // sequential scheme, which is backward stable for any factor.
 template <class T>
-void build_dense_blocks(BandPlan &P, const Csr<T> &A, const BandOptions &opt, std::vector<T> &tinv) {
+void build_dense_blocks(BandPlan &P, const Csr<T> &A, const BandOptions &opt, std::vector<double> &tinv_ops) {
+  std::vector<T> tinv;  // column-major inverses, block after block; converted to MFMA operands at the end
   P.band_blk_ptr.assign(1, 0);
   for (int64_t b = 0; b < P.nbands(); ++b) {
     if (P.band_dense[(size_t)b]) {
@@ -471,15 +492,13 @@ void build_dense_blocks(BandPlan &P, const Csr<T> &A, const BandOptions &opt, st
     }
     P.band_blk_ptr.push_back((int32_t)P.blk_slot0.size());
   }
-  if (sizeof(T) == sizeof(double)) {  // the MFMA kernel reads strip-major operands (complex stays column-major)
-    std::vector<T> re;
-    for (size_t q = 0; q < P.blk_slot0.size(); ++q) {
-      const int64_t nb = P.blk_slot1[q] - P.blk_slot0[q];
-      const std::vector<T> st = to_strip_layout(&tinv[(size_t)P.blk_inv_off[q]], nb, nb, round_up32(nb));
-      P.blk_inv_off[q] = (int64_t)re.size();
-      re.insert(re.end(), st.begin(), st.end());
-    }
-    tinv.swap(re);
+  // MFMA operands: strip-major, zero-padded to a multiple of 32 columns (complex: two real planes)
+  tinv_ops.clear();
+  for (size_t q = 0; q < P.blk_slot0.size(); ++q) {
+    const int64_t nb = P.blk_slot1[q] - P.blk_slot0[q];
+    const std::vector<double> st = mfma_operand(&tinv[(size_t)P.blk_inv_off[q]], nb, nb, round_up32(nb));
+    P.blk_inv_off[q] = (int64_t)tinv_ops.size();
+    tinv_ops.insert(tinv_ops.end(), st.begin(), st.end());
   }
 }
 
@@ -548,7 +567,7 @@ struct HostLevel {
   Csr<T> Lr, Ur, Er, Fr;
   Schedule Ls, Us;   // plain level schedules (wavefronts), kept for queries
   BandPlan Lp, Up;   // what the device executes
-  std::vector<T> Ltinv, Utinv;  // explicit inverses of the diagonal blocks of block-dense thin bands
+  std::vector<double> Ltinv, Utinv;  // explicit inverses of the diagonal blocks of block-dense thin bands (MFMA operands)
 };
 
 // Dense last level: A P = Q R (GEQP3 semantics), numerical rank as QRCP::factorize decides it

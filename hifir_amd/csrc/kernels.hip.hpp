@@ -907,26 +907,23 @@ __global__ void __launch_bounds__(NW * 64) k_tri_gemm_d(int nb, const double *__
   }
 }
 
-// complex dense level: plain wave-per-row-strip VALU version (no complex MFMA on gfx950);
-// one lane per (row, column) pair of a 64/R-row strip, k sequential.
-__global__ void __launch_bounds__(256) k_dense_gemm_z(int mrows_total, int mrows_valid, int kend, int tri,
-                                                      const cplx *__restrict__ A, int lda,
-                                                      const cplx *__restrict__ X, int logR,
-                                                      const int32_t *__restrict__ rowmap,
-                                                      cplx *__restrict__ Out, const cplx *__restrict__ dscale,
-                                                      cplx *__restrict__ Out2) {
+// Complex products on the real matrix cores: with X viewed as a real [rows][2R] block (re, im interleaved),
+// T1 = A_re * X and T2 = A_im * X are two real MFMA products (k_dense_gemm_d / k_tri_gemm_d at logR + 1);
+// this kernel recombines  out = (T1_re - T2_im) + i (T1_im + T2_re),  applies the output row permutation
+// and the optional fused division (same epilogue as the real kernels).
+__global__ void __launch_bounds__(256) k_zcombine(int64_t nrows, const double *__restrict__ T1,
+                                                  const double *__restrict__ T2, int logR,
+                                                  const int32_t *__restrict__ rowmap, cplx *__restrict__ Out,
+                                                  const cplx *__restrict__ dscale, cplx *__restrict__ Out2) {
   const LaneMap lm = lane_map(logR);
   const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t i = wave * lm.G + lm.g; i < mrows_total; i += nwaves * lm.G) {
-    cplx acc{0.0, 0.0};
-    if (i < mrows_valid) {
-      const int kb = (tri == 1) ? (int)i : 0, ke = (tri == 2) ? min(kend, (int)i + 1) : kend;
-      for (int k = kb; k < ke; ++k) acc = vadd(acc, vmul(A[(int64_t)k * lda + i], X[((int64_t)k << logR) + lm.c]));
-    }
+  for (int64_t i = wave * lm.G + lm.g; i < nrows; i += nwaves * lm.G) {
+    const int64_t o = (i << (logR + 1)) + 2 * lm.c;
+    const cplx val{T1[o] - T2[o + 1], T1[o + 1] + T2[o]};
     const int64_t orow = rowmap ? rowmap[i] : i;
-    Out[(orow << logR) + lm.c] = acc;
-    if (Out2) Out2[(orow << logR) + lm.c] = vdiv(acc, dscale[orow]);
+    Out[(orow << logR) + lm.c] = val;
+    if (Out2) Out2[(orow << logR) + lm.c] = vdiv(val, dscale[orow]);
   }
 }
 

@@ -19,6 +19,13 @@ mode = sys.argv[2]
 nrhs = int(sys.argv[3])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 A = poisson2d(nx)
+cplx = mode.endswith("-z")  # e.g. "default-z": complex shifted Laplacian (BASELINE config 5 stand-in)
+if cplx:
+    import scipy.sparse as sp
+
+    A = (A - (0.3 + 0.2j) * sp.identity(A.shape[0])).tocsr()
+    A.sort_indices()
+    mode = mode[:-2]
 n = A.shape[0]
 P = None if mode == "default" else ref.make_params(tau=1e-2, kappa=5.0, alpha=3.0)
 t0 = time.time()
@@ -31,6 +38,8 @@ M = hifir_amd.HIF.from_levels(levels, max_nrhs=min(nrhs, 64))
 print(f"import+upload {time.time() - t0:.1f}s stats={M.stats()}", flush=True)
 rng = np.random.default_rng(20260101)
 B = rng.uniform(-1, 1, size=(n, nrhs))
+if cplx:
+    B = B + 1j * rng.uniform(-1, 1, size=(n, nrhs))
 B[:, 0] = np.sin(0.001 * np.arange(n)) + 1
 Bd = torch.from_numpy(B).cuda()
 Xd = torch.empty_like(Bd)
