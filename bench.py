@@ -185,6 +185,10 @@ def main():
         dev_ms = M.time_apply(B, X, warmup=1, reps=max(5, steps // 2))
         balg = M.algorithmic_bytes(args.nrhs)
         stage_bytes = M.stage_bytes(args.nrhs)
+        # BASELINE configs[1]: the same hierarchy with ONE right-hand side (latency-bound; reported, not the metric)
+        b1 = B[:, :1].contiguous()
+        x1 = torch.empty_like(b1)
+        nrhs1_ms = M.time_apply(b1, x1, warmup=1, reps=5) if world == 1 else None
         st = M.stats()
         # one end-of-batch gather of the solution blocks (not in the per-step data path)
         gather_ms = None
@@ -204,7 +208,7 @@ def main():
             xo = orc.Oracle(levels).solve(B[:, 0].cpu().numpy())
             xg = X[:, 0].cpu().numpy()
             parity = float(np.abs(xg - xo).max() / np.abs(xo).max())
-        res = dict(ms_per_step=1e3 * el / steps, value=world * args.nrhs * steps / el, dev_ms=dev_ms, balg=balg, stage_bytes=stage_bytes,
+        res = dict(ms_per_step=1e3 * el / steps, value=world * args.nrhs * steps / el, dev_ms=dev_ms, balg=balg, stage_bytes=stage_bytes, nrhs1_ms=nrhs1_ms,
                    stats=st, cpu=cpu, gather_ms=gather_ms, parity=parity, levels=levels)
         M.close()
         del B, X
@@ -264,6 +268,9 @@ def main():
         }
         if r["gather_ms"] is not None:
             line["gather_ms"] = r["gather_ms"]
+        if r["nrhs1_ms"] is not None:
+            line["nrhs1"] = {"config": "same hierarchy, nrhs=1 (BASELINE configs[1])", "ms_per_apply": r["nrhs1_ms"],
+                             "applies_per_s": 1e3 / r["nrhs1_ms"]}
         if world == 1 and args.secondary:
             other = "tuned" if args.params == "default" else "default"
             r2 = run(other, True, max(5, args.steps // 2), 2)
