@@ -139,18 +139,18 @@ struct DevDense {
   DevBuf Rm;               // product only: R (primary engine, upper) or R^H (adjoint engine, lower)
 };
 
-struct GraphKey {
-  const void *B, *X;
+struct GraphKey {  // one graph per SHAPE: the caller's pointers are read from a device slot at replay time
   int64_t ldb, ldx, nrhs, rank;
   int kind;  // 0: apply (prec_solve), 1: product (prec_prod)
   bool operator<(const GraphKey &o) const {
-    return std::tie(B, X, ldb, ldx, nrhs, rank, kind) < std::tie(o.B, o.X, o.ldb, o.ldx, o.nrhs, o.rank, o.kind);
+    return std::tie(ldb, ldx, nrhs, rank, kind) < std::tie(o.ldb, o.ldx, o.nrhs, o.rank, o.kind);
   }
 };
 
 struct GraphEntry {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  void **slots = nullptr;  // device: {B base, X base}, rewritten (stream-ordered) before every replay
   int64_t launches = 0;
   uint64_t stamp = 0;
 };
@@ -181,6 +181,9 @@ class Engine : public EngineBase {
   DevCsr A;
   bool has_A = false;
   std::map<GraphKey, GraphEntry> graphs;
+  static constexpr size_t kIoRing = 1024;  // pinned staging of the (B, X) pointers handed to the graphs
+  void **io_ring = nullptr;
+  uint64_t io_next = 0;
   uint64_t clock = 0;
   int64_t last_launches = 0;
   bool use_graph = true;
@@ -230,8 +233,11 @@ class Engine : public EngineBase {
     for (auto &kv : graphs) {
       if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
       if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+      if (kv.second.slots) (void)hipFree(kv.second.slots);
     }
     graphs.clear();
+    if (io_ring) (void)hipHostFree(io_ring);
+    io_ring = nullptr;
   }
 
   // ---- import ------------------------------------------------------------------------------
@@ -639,7 +645,12 @@ class Engine : public EngineBase {
   }
 
   // one level of prec_solve (prec_solve.hpp:332-412); bin/yout may be user or arena pointers
-  void enqueue_level(hipStream_t st, size_t l, const D *bin, int64_t ldb, D *yout, int64_t ldy, int nrhs,
+  typedef IoPtr<const D> InP;
+  typedef IoPtr<D> OutP;
+  static InP in_direct(const D *p) { return InP{p, nullptr, 0}; }
+  static OutP out_direct(D *p) { return OutP{p, nullptr, 0}; }
+
+  void enqueue_level(hipStream_t st, size_t l, InP bin, int64_t ldb, OutP yout, int64_t ldy, int nrhs,
                      int logR, int64_t rank, int64_t &count) {
     DevLevel &L = *lv[l];
     const int64_t m = L.m, n = L.n, nm = n - m;
@@ -661,7 +672,7 @@ class Engine : public EngineBase {
       if (last)
         launch_dense(st, w + m * R, v + m * R, logR, rank, count);  // :371-381
       else
-        enqueue_level(st, l + 1, w + m * R, R, v + m * R, R, (int)R, logR, rank, count);  // :383-388
+        enqueue_level(st, l + 1, in_direct(w + m * R), R, out_direct(v + m * R), R, (int)R, logR, rank, count);  // :383-388
       // S5  :392-403   (v[m:n] already is "work[m:n] = y[m:n]")
       if (m) {
         if (L.F_ncols) {
@@ -732,7 +743,7 @@ class Engine : public EngineBase {
 
   void launch_dense_mul(hipStream_t st, const D *cin, D *zout, int logR, int64_t rank, int64_t &count);
 
-  void enqueue_prod_level(hipStream_t st, size_t l, const D *bin, int64_t ldb, D *yout, int64_t ldy, int nrhs,
+  void enqueue_prod_level(hipStream_t st, size_t l, InP bin, int64_t ldb, OutP yout, int64_t ldy, int nrhs,
                           int logR, int64_t rank, int64_t &count) {
     DevLevel &L = *lv[l];
     const int64_t m = L.m, n = L.n, nm = n - m;
@@ -747,7 +758,7 @@ class Engine : public EngineBase {
       if (last)
         launch_dense_mul(st, g + m * R, cy + m * R, logR, rank, count);
       else
-        enqueue_prod_level(st, l + 1, g + m * R, R, cy + m * R, R, (int)R, logR, rank, count);
+        enqueue_prod_level(st, l + 1, in_direct(g + m * R), R, out_direct(cy + m * R), R, (int)R, logR, rank, count);
     }
     if (m) {
       // cy[0:m] = D (U + I) g   (:101-103);  r[0:m] = (L + I) cy   (:106-108)
@@ -794,16 +805,19 @@ class Engine : public EngineBase {
   }
 
   // all kernels of one batched apply, nrhs tiled by 64 columns
+  // `slots` (device: {B base, X base}) != NULL: the level-0 kernels read the caller's pointers from there
   int64_t enqueue_apply(hipStream_t st, const D *dB, int64_t ldb, D *dX, int64_t ldx, int64_t nrhs, int64_t rank,
-                        int kind = 0) {
+                        int kind = 0, D *const *slots = nullptr) {
     int64_t count = 0;
     for (int64_t c0 = 0; c0 < nrhs; c0 += 64) {
       const int64_t nc = std::min<int64_t>(64, nrhs - c0);
       const int logR = pick_logR(nc);
+      const InP bin = slots ? InP{nullptr, (const D *const *)slots, c0} : in_direct(dB + c0);
+      const OutP yout = slots ? OutP{nullptr, slots + 1, c0} : out_direct(dX + c0);
       if (kind == 0)
-        enqueue_level(st, 0, dB + c0, ldb, dX + c0, ldx, (int)nc, logR, rank, count);
+        enqueue_level(st, 0, bin, ldb, yout, ldx, (int)nc, logR, rank, count);
       else
-        enqueue_prod_level(st, 0, dB + c0, ldb, dX + c0, ldx, (int)nc, logR, rank, count);
+        enqueue_prod_level(st, 0, bin, ldb, yout, ldx, (int)nc, logR, rank, count);
     }
     HIP_OK(hipGetLastError());
     return count;
@@ -830,25 +844,29 @@ class Engine : public EngineBase {
       last_launches = enqueue_apply(st, dB, ldb, dX, ldx, nrhs, rank, kind);
       return;
     }
-    GraphKey key{dB, dX, ldb, ldx, nrhs, host.has_dense ? eff_rank(rank) : 0, kind};
+    GraphKey key{ldb, ldx, nrhs, host.has_dense ? eff_rank(rank) : 0, kind};
     auto it = graphs.find(key);
     if (it == graphs.end()) {
       if (graphs.size() >= 8) {  // evict the least recently used
         auto old = graphs.begin();
         for (auto jt = graphs.begin(); jt != graphs.end(); ++jt)
           if (jt->second.stamp < old->second.stamp) old = jt;
+        HIP_OK(hipStreamSynchronize(stream));
         (void)hipGraphExecDestroy(old->second.exec);
         (void)hipGraphDestroy(old->second.graph);
+        (void)hipFree(old->second.slots);
         graphs.erase(old);
       }
       GraphEntry ge;
+      HIP_OK(hipMalloc((void **)&ge.slots, 2 * sizeof(void *)));
       HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
       try {
-        ge.launches = enqueue_apply(stream, dB, ldb, dX, ldx, nrhs, rank, kind);
+        ge.launches = enqueue_apply(stream, dB, ldb, dX, ldx, nrhs, rank, kind, (D *const *)ge.slots);
       } catch (...) {
         hipGraph_t g = nullptr;
         (void)hipStreamEndCapture(stream, &g);
         if (g) (void)hipGraphDestroy(g);
+        (void)hipFree(ge.slots);
         throw;
       }
       HIP_OK(hipStreamEndCapture(stream, &ge.graph));
@@ -857,6 +875,13 @@ class Engine : public EngineBase {
     }
     it->second.stamp = ++clock;
     last_launches = it->second.launches;
+    // hand this call's pointers to the graph: a stream-ordered 16-byte copy from a pinned ring slot
+    if (!io_ring) HIP_OK(hipHostMalloc((void **)&io_ring, kIoRing * 2 * sizeof(void *), hipHostMallocDefault));
+    if (io_next && io_next % kIoRing == 0) HIP_OK(hipStreamSynchronize(st));  // never overtake a pending slot
+    void **h = io_ring + 2 * (io_next++ % kIoRing);
+    h[0] = (void *)dB;
+    h[1] = (void *)dX;
+    HIP_OK(hipMemcpyAsync(it->second.slots, h, 2 * sizeof(void *), hipMemcpyHostToDevice, st));
     HIP_OK(hipGraphLaunch(it->second.exec, st));
   }
 

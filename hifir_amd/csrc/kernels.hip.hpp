@@ -77,14 +77,27 @@ __device__ __forceinline__ LaneMap lane_map(int logR) {
   return m;
 }
 
+// A caller-owned vector block as a kernel argument: either a plain pointer, or a pointer that the kernel
+// reads from a device slot at run time (+ a column offset).  The latter lets ONE captured hipGraph serve
+// every (B, X) pair of a given shape: the slot is rewritten before each replay instead of re-capturing
+// the ~550 nodes whenever a Krylov solver hands over a different pair of vectors.
+template <class T>
+struct IoPtr {
+  T *direct;
+  T *const *slot;
+  int64_t off;
+  __device__ __forceinline__ T *get() const { return slot ? (*slot + off) : direct; }
+};
+
 // ---------------------------------------------------------------------------------------------
 // S1: w[i] = s[p[i]] * b[p[i]],  rows [0, cnt)
 // ---------------------------------------------------------------------------------------------
 template <class T>
-__global__ void __launch_bounds__(256) k_gather_scale(const T *__restrict__ bin, int64_t ldb, int nrhs,
+__global__ void __launch_bounds__(256) k_gather_scale(IoPtr<const T> bin_, int64_t ldb, int nrhs,
                                                       const int32_t *__restrict__ p,
                                                       const double *__restrict__ s, int64_t cnt,
                                                       T *__restrict__ w, int logR) {
+  const T *__restrict__ bin = bin_.get();
   const LaneMap lm = lane_map(logR);
   const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -117,8 +130,9 @@ template <class T>
 __global__ void __launch_bounds__(256) k_scatter_scale(const T *__restrict__ v,
                                                        const int32_t *__restrict__ qinv,
                                                        const double *__restrict__ t, int64_t n,
-                                                       T *__restrict__ yout, int64_t ldy, int nrhs,
+                                                       IoPtr<T> yout_, int64_t ldy, int nrhs,
                                                        int logR) {
+  T *__restrict__ yout = yout_.get();
   const LaneMap lm = lane_map(logR);
   const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -498,10 +512,11 @@ template <class T>
 __global__ void __launch_bounds__(256) k_spmm_epi(int64_t nrows, const int32_t *__restrict__ ptr,
                                                   const int32_t *__restrict__ col,
                                                   const T *__restrict__ val, const T *__restrict__ x,
-                                                  const T *__restrict__ bin, int64_t ldb, int nrhs,
+                                                  IoPtr<const T> bin_, int64_t ldb, int nrhs,
                                                   const int32_t *__restrict__ p,
                                                   const double *__restrict__ s, int64_t roff,
                                                   T *__restrict__ out, int logR) {
+  const T *__restrict__ bin = bin_.get();
   const LaneMap lm = lane_map(logR);
   const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -558,9 +573,10 @@ __device__ __forceinline__ cplx vdivr(cplx a, double r) { return cplx{a.x / r, a
 
 // g[i] = b[q[i]] / t[q[i]], rows [0, cnt)   (:76, :97; with (p, s) for the transposed product)
 template <class T>
-__global__ void __launch_bounds__(256) k_gather_div(const T *__restrict__ bin, int64_t ldb, int nrhs,
+__global__ void __launch_bounds__(256) k_gather_div(IoPtr<const T> bin_, int64_t ldb, int nrhs,
                                                     const int32_t *__restrict__ q, const double *__restrict__ t,
                                                     int64_t cnt, T *__restrict__ g, int logR) {
+  const T *__restrict__ bin = bin_.get();
   const LaneMap lm = lane_map(logR);
   const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -575,8 +591,9 @@ __global__ void __launch_bounds__(256) k_gather_div(const T *__restrict__ bin, i
 // y[i] = r[p_inv[i]] / s[i], rows [0, n)   (:132)
 template <class T>
 __global__ void __launch_bounds__(256) k_scatter_div(const T *__restrict__ r, const int32_t *__restrict__ pinv,
-                                                     const double *__restrict__ s, int64_t n, T *__restrict__ yout,
+                                                     const double *__restrict__ s, int64_t n, IoPtr<T> yout_,
                                                      int64_t ldy, int nrhs, int logR) {
+  T *__restrict__ yout = yout_.get();
   const LaneMap lm = lane_map(logR);
   const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
