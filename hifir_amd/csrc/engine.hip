@@ -125,6 +125,7 @@ struct DevCsr {
 
 struct DevLevel {
   int64_t m = 0, n = 0, F_ncols = 0;
+  bool E_void = false;  // adjoint of a level without F: the restriction F^H does not exist (not merely empty)
   DevCsr L, U, E, F;
   DevBuf d, s, t, p, qinv;
   DevBuf w, v;  // arena: n * Rmax each
@@ -349,6 +350,7 @@ class Engine : public EngineBase {
     if (P.F_ncols) {
       H.Er = adjoint_rows(P.F);  // F^H: nm x m
     } else {                     // no F: y[m:n] = t[q] b[q] (:574) -- an empty restriction
+      H.E_void = true;
       H.Er.nrows = nm;
       H.Er.ncols = nm ? P.m : 0;
       H.Er.ptr.assign((size_t)nm + 1, 0);
@@ -445,6 +447,7 @@ class Engine : public EngineBase {
       L.m = H.m;
       L.n = H.n;
       L.F_ncols = H.F_ncols;
+      L.E_void = H.E_void;
       L.L.upload(H.Lr, &H.Lp, &H.Ltinv);
       L.U.upload(H.Ur, &H.Up, &H.Utinv);
       std::vector<double>().swap(H.Ltinv);
@@ -786,10 +789,18 @@ class Engine : public EngineBase {
                            (const D *)nullptr, (int64_t)0);  // v += g   (:123)
         ++count;
       }
-      // r[m:n] = E v + cy[m:n]   (:125-127)
-      hipLaunchKernelGGL((k_spmm_prod<D, 1>), dim3(grid_for(nm, logR)), dim3(256), 0, st, nm, L.E.ptr.as<int32_t>(),
-                         L.E.col.as<int32_t>(), L.E.val.as<D>(), (const D *)v, r + m * R, (D *)nullptr,
-                         (const D *)(cy + m * R), logR);
+      if (L.E_void) {
+        // transposed product of a level WITHOUT F: the reference's F.multiply_t_low writes F.ncols() = 0
+        // entries (prec_prod.hpp:223), so work[m:n] still holds the permuted input when y[m:n] is added
+        // (:225) -- reproduced literally (no factorization yields such a level; synthetic tests do)
+        hipLaunchKernelGGL((k_vec_op<D>), dim3(vec_grid(nm * R)), dim3(256), 0, st, 3, nm, (int)R, r + m * R, R,
+                           (const D *)(g + m * R), R, (const D *)(cy + m * R), R);
+      } else {
+        // r[m:n] = E v + cy[m:n]   (:125-127)
+        hipLaunchKernelGGL((k_spmm_prod<D, 1>), dim3(grid_for(nm, logR)), dim3(256), 0, st, nm, L.E.ptr.as<int32_t>(),
+                           L.E.col.as<int32_t>(), L.E.val.as<D>(), (const D *)v, r + m * R, (D *)nullptr,
+                           (const D *)(cy + m * R), logR);
+      }
       ++count;
     }
     // y = r[p_inv] / s   (:132)

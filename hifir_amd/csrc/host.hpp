@@ -559,6 +559,7 @@ Csr<T> permute_rows(const Csr<T> &A, const std::vector<int32_t> &order) {
 template <class T>
 struct HostLevel {
   int64_t m = 0, n = 0, F_ncols = 0;
+  bool E_void = false;  // adjoint levels only: the original level had no F
   Ccs<T> L, U, E, F;  // as imported
   std::vector<T> d;
   std::vector<double> s, t;

@@ -50,6 +50,15 @@ def _check(levels, nrhs, exact_expected, tol=1e-12, seed=0):
     if exact_expected:
         assert np.array_equal(X, Xo), relerr(X, Xo)
     assert relerr(X, Xo) <= tol
+    # the other three operators of lhf?Apply on the same (possibly degenerate) hierarchy, first columns
+    k = min(nrhs, 3)
+    Bk = np.ascontiguousarray(B[:, :k])
+    XH = M.solve_mrhs(Bk, trans=True)
+    Y, YH = M.mmultiply(Bk), M.mmultiply(Bk, trans=True)
+    for c in range(k):
+        assert relerr(XH[:, c], O.solve(Bk[:, c].copy(), trans=True)) <= tol * 10
+        assert relerr(Y[:, c], O.mmultiply(Bk[:, c].copy(), rank=-1)) <= 1e-10
+        assert relerr(YH[:, c], O.mmultiply(Bk[:, c].copy(), rank=-1, trans=True)) <= 1e-10
     return M
 
 
@@ -110,3 +119,49 @@ def test_degenerate_shapes():
     m = 1000
     d = _level(m, m, sp.csr_matrix((m, m)), sp.csr_matrix((m, m)), sp.csr_matrix((0, m)), sp.csr_matrix((m, 0)), rng)
     _check([d], 64, exact_expected=True)
+
+
+def test_rank_deficient_dense_block_all_operators():
+    # a dense tail with 9 exactly dependent columns: QRCP truncates through ?laic1 (QRCP.hpp:333-364) and every
+    # operator uses the numerical rank (solve) or the rank it is given
+    rng = np.random.default_rng(12)
+    n, m = 400, 260
+    nd = n - m
+    lv = _level(m, n, _rand_tri(m, 0.05, True, rng), _rand_tri(m, 0.05, False, rng),
+                sp.random(nd, m, density=0.1, random_state=np.random.RandomState(3), format="csr"),
+                sp.random(m, nd, density=0.1, random_state=np.random.RandomState(4), format="csr"), rng)
+    D = rng.normal(size=(nd, nd)) + 3 * np.eye(nd)
+    D[:, nd - 9:] = D[:, :9] @ rng.normal(size=(9, 9))
+    lv["dense_n"], lv["dense"] = nd, D.ravel(order="F")
+    M = hifir_amd.HIF.from_levels([lv], max_nrhs=8)
+    O = orc.Oracle([lv])
+    assert M.schur_rank() == O.dense_rank == nd - 9
+    B = rng.uniform(-1, 1, size=(n, 4))
+    for c in range(4):
+        b = B[:, c].copy()
+        assert relerr(M.solve(b), O.solve(b)) <= 1e-9
+        assert relerr(M.solve(b, trans=True), O.solve(b, trans=True)) <= 1e-9
+        assert relerr(M.solve(b, rank=50), O.solve(b, rank=50)) <= 1e-9
+        assert relerr(M.mmultiply(b, rank=0), O.mmultiply(b, rank=0)) <= 1e-9
+        assert relerr(M.mmultiply(b, rank=0, trans=True), O.mmultiply(b, rank=0, trans=True)) <= 1e-9
+
+
+def test_one_based_matrix_input():
+    # the outer matrix may come 1-based like the reference accepts it (builder.hpp:311-329)
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(3)
+    m = 500
+    lv = _level(m, m, _rand_tri(m, 0.02, True, rng), _rand_tri(m, 0.02, False, rng), sp.csr_matrix((0, m)),
+                sp.csr_matrix((m, 0)), rng)
+    A = (sp.random(m, m, density=0.02, random_state=np.random.RandomState(1), format="csr") + 4 * sp.identity(m)).tocsr()
+    A.sort_indices()
+    X = rng.uniform(-1, 1, size=(m, 5))
+    Y = []
+    for base in (0, 1):
+        M = hifir_amd.HIF.from_levels([lv], max_nrhs=8)
+        M.set_matrix(A.indptr.astype(np.int64) + base, A.indices.astype(np.int32) + base, A.data)
+        Yd = M.spmv(torch.from_numpy(X).cuda())
+        M.sync()
+        Y.append(Yd.cpu().numpy())
+    assert np.array_equal(Y[0], Y[1])
+    assert relerr(Y[0], A @ X) <= 1e-14
