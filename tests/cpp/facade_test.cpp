@@ -1,0 +1,138 @@
+// tests/cpp/facade_test.cpp -- TEST (built by oracle/Makefile into oracle/_ref/facade_test, only where the
+// reference headers exist; run on the GPU box by tests/test_gpu_cpp_facade.py).
+//
+// A reference user's C++ program: factorize with hif::HIF on the host, then route every apply-side call
+// through the header-only facade include/hifir_amd.hpp (same method names and defaults) and compare with
+// what the reference itself returns for the same call.  Exit code 0 = every check within its tolerance.
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <vector>
+
+#define HIF_THROW 1
+#include <hifir.hpp>
+#include <gmres.hpp>  // examples/advanced/gmres.hpp: the reference's GMRES driver
+
+#include "hifir_amd.hpp"
+
+typedef hif::HIF<double, int, std::ptrdiff_t> ref_t;
+typedef hif::CRS<double, int, std::ptrdiff_t> crs_t;
+typedef hif::Array<double> arr_t;
+
+static int failures = 0;
+
+template <class A, class B>
+static double relerr(const A &x, const B &y) {
+  double num = 0, den = 1e-300;
+  for (size_t i = 0; i < x.size(); ++i) {
+    num = std::max(num, std::fabs((double)(x[i] - y[i])));
+    den = std::max(den, std::fabs((double)y[i]));
+  }
+  return num / den;
+}
+static void report(const char *what, double err, double tol) {
+  std::printf("%-44s relerr %.3e (tol %.0e) %s\n", what, err, tol, err <= tol ? "ok" : "FAIL");
+  if (!(err <= tol)) ++failures;
+}
+
+int main() {
+  // 2-D 5-pt Poisson with a convection term (nonsymmetric so that the transposed operators differ)
+  const int nx = 90, n = nx * nx;
+  std::vector<std::ptrdiff_t> ip(1, 0);
+  std::vector<int> ci;
+  std::vector<double> v;
+  for (int j = 0; j < nx; ++j)
+    for (int i = 0; i < nx; ++i) {
+      const int r = j * nx + i;
+      if (j > 0) ci.push_back(r - nx), v.push_back(-1.3);
+      if (i > 0) ci.push_back(r - 1), v.push_back(-1.2);
+      ci.push_back(r), v.push_back(4.0);
+      if (i + 1 < nx) ci.push_back(r + 1), v.push_back(-0.8);
+      if (j + 1 < nx) ci.push_back(r + nx), v.push_back(-0.7);
+      ip.push_back((std::ptrdiff_t)ci.size());
+    }
+  crs_t A(n, n, ip.data(), ci.data(), v.data(), true);
+  hif::Params params = hif::DEFAULT_PARAMS;
+  params.verbose = hif::VERBOSE_NONE;
+  ref_t M;
+  M.factorize(A, params);
+
+  hifamd::HIF<double> G;
+  G.attach(M);
+  G.set_matrix(A);
+  if (G.levels() != M.levels() || G.nnz() != M.nnz() || G.rank() != M.rank() || G.schur_size() != M.schur_size() ||
+      G.schur_rank() != M.schur_rank() || G.nrows() != M.nrows()) {
+    std::printf("queries differ: levels %zu/%zu nnz %zu/%zu rank %zu/%zu\n", G.levels(), M.levels(), G.nnz(), M.nnz(),
+                G.rank(), M.rank());
+    ++failures;
+  }
+
+  arr_t b(n), x0(n), x1(n);
+  for (int i = 0; i < n; ++i) b[i] = std::sin(0.001 * i) + 1.0;
+  M.solve(b, x0);
+  G.solve(b, x1);
+  report("solve(b, x)", relerr(x1, x0), 1e-12);
+  M.solve(b, x0, true);
+  G.solve(b, x1, true);
+  report("solve(b, x, true)", relerr(x1, x0), 1e-12);
+  M.solve(b, x0, false, 40);
+  G.solve(b, x1, false, 40);
+  report("solve(b, x, false, r=40)", relerr(x1, x0), 1e-10);
+  arr_t y0(n), y1(n);
+  M.solve(b, x0);
+  M.mmultiply(x0, y0);
+  G.mmultiply(x0, y1);
+  report("mmultiply(x, y)", relerr(y1, y0), 1e-10);
+  M.mmultiply(x0, y0, true);
+  G.mmultiply(x0, y1, true);
+  report("mmultiply(x, y, true)", relerr(y1, y0), 1e-10);
+  M.hifir(A, b, 3, x0);
+  G.hifir(A, b, 3, x1);
+  report("hifir(A, b, 3, x)", relerr(x1, x0), 1e-11);
+  const double betas[2] = {1e-10, 1e3};
+  const auto s0 = M.hifir(A, b, 16, betas, x0);
+  const auto s1 = G.hifir(A, b, 16, betas, x1);
+  report("hifir(A, b, 16, betas, x)", relerr(x1, x0), 1e-11);
+  if (s0.first != s1.first || s0.second != s1.second) {
+    std::printf("hifir status differs: (%zu,%d) vs (%zu,%d)\n", s0.first, s0.second, s1.first, s1.second);
+    ++failures;
+  }
+  // multiple right-hand sides: the reference's own solve_mrhs is defective (prec_solve.hpp:489-497), so the
+  // expected block is built column by column with HIF::solve
+  hif::Array<std::array<double, 4>> B4(n), X4(n);
+  std::vector<arr_t> cols;  // (hif::Array copies are shallow: build the four columns one by one)
+  for (int k = 0; k < 4; ++k) cols.push_back(arr_t(n));
+  for (int k = 0; k < 4; ++k) {
+    arr_t bk(n);
+    for (int i = 0; i < n; ++i) bk[i] = B4[i][k] = b[i] + 0.01 * k * std::cos(0.01 * i);
+    M.solve(bk, cols[k]);
+  }
+  G.solve_mrhs(B4, X4);
+  double e4 = 0;
+  for (int k = 0; k < 4; ++k) {
+    arr_t xk(n);
+    for (int i = 0; i < n; ++i) xk[i] = X4[i][k];
+    e4 = std::max(e4, relerr(xk, cols[k]));
+  }
+  report("solve_mrhs<4>(B, X) vs column-wise solve", e4, 1e-12);
+  // the GMRES driver
+  const auto g0 = gmres_hif(A, b, M, 30, 1e-10, 200, 0);
+  const auto g1 = G.gmres(A, b, 30, 1e-10, 200);
+  report("gmres(A, b, 30, 1e-10, 200)", relerr(std::get<0>(g1), std::get<0>(g0)), 1e-8);
+  if (std::get<1>(g0) != std::get<1>(g1) || std::get<2>(g0) != std::get<2>(g1)) {
+    std::printf("gmres (flag, iters) differ: (%d,%d) vs (%d,%d)\n", std::get<1>(g0), std::get<2>(g0), std::get<1>(g1),
+                std::get<2>(g1));
+    ++failures;
+  }
+  // error behaviour: an empty preconditioner throws like the reference does (builder.hpp:412)
+  hifamd::HIF<double> E;
+  bool threw = false;
+  try {
+    E.solve(b, x1);
+  } catch (const std::runtime_error &) {
+    threw = true;
+  }
+  if (!threw) ++failures, std::printf("empty facade did not throw\n");
+  std::printf(failures ? "FACADE TEST FAILED (%d)\n" : "FACADE TEST OK\n", failures);
+  return failures ? 1 : 0;
+}
