@@ -87,3 +87,35 @@ def test_level_schedule_is_valid(name):
     assert M.nnz() == sum((len(lv["L_vals"]) + len(lv["U_vals"]) + lv["m"] if lv["m"] else 0) +
                           (len(lv["E_vals"]) + len(lv["F_vals"]) if lv["n"] > lv["m"] else 0) for lv in levels) + \
         int(levels[-1].get("dense_n", 0)) ** 2
+
+
+def test_cpp_facade_header_compiles_standalone(tmp_path):
+    # include/hifir_amd.hpp must be usable with nothing but the C ABI header and the standard library
+    # (std::vector stands in for hif::Array; a minimal mock stands in for the reference's hierarchy)
+    import subprocess
+
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include <vector>
+#include <array>
+#include "hifir_amd.hpp"
+struct MockCcs { std::vector<long> cs; std::vector<int> ri; std::vector<double> v; size_t nc = 0;
+  const std::vector<long>& col_start() const { return cs; } const std::vector<int>& row_ind() const { return ri; }
+  const std::vector<double>& vals() const { return v; } size_t ncols() const { return nc; } };
+struct MockDense { std::vector<double> a; size_t n = 0; bool empty() const { return true; }
+  const MockDense& mat_backup() const { return *this; } size_t nrows() const { return n; } const double* data() const { return a.data(); } };
+struct MockPrec { size_t m = 0, n = 0; MockCcs L_B, U_B, E, F; std::vector<double> d_B, s, t; std::vector<int> p, p_inv, q, q_inv;
+  MockDense dense_solver; };
+struct MockHif { std::vector<MockPrec> ps; const std::vector<MockPrec>& precs() const { return ps; } };
+int main() {
+  hifamd::HIF<double> G;
+  MockHif M;
+  std::vector<double> b(4), x(4);
+  std::vector<std::array<double, 2>> B(4), X(4);
+  if (false) { G.attach(M); G.solve(b, x); G.solve(b, x, true, 3); G.solve_mrhs(B, X); G.mmultiply(b, x, true);
+               G.set_matrix(4, nullptr, nullptr, nullptr); }
+  return (int)G.levels() + (int)G.empty();
+}
+''')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-I", inc, str(src)])
