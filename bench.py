@@ -208,26 +208,25 @@ def main():
             xo = orc.Oracle(levels).solve(B[:, 0].cpu().numpy())
             xg = X[:, 0].cpu().numpy()
             parity = float(np.abs(xg - xo).max() / np.abs(xo).max())
-        # two independent 64-RHS batches in flight (two handles = two arenas and streams): what a caller with
-        # 128 right-hand sides gets; reported next to the metric, never as the metric
+        # a 128-column batch through the same handle: its two 64-column tiles run on two lanes (second work
+        # arena + stream, shared matrices) and hide each other's latency-bound phases; reported next to the
+        # metric, never as the metric
         pipelined = None
         if world == 1 and want_cpu:
-            M2 = hifir_amd.HIF.from_levels(levels, max_nrhs=args.nrhs, device=local_rank)
-            B2 = B.clone()
+            B2 = torch.cat([B, B.flip(1)], dim=1).contiguous()
             X2 = torch.empty_like(B2)
-            M2.solve_mrhs(B2, X2)
-            M2.sync()
+            M.solve_mrhs(B2, X2)
+            M.sync()
             t1 = time.perf_counter()
             for _ in range(steps):
-                M.solve_mrhs(B, X)
-                M2.solve_mrhs(B2, X2)
+                M.solve_mrhs(B2, X2)
             M.sync()
-            M2.sync()
             torch.cuda.synchronize()
             el2 = time.perf_counter() - t1
-            pipelined = {"batches_in_flight": 2, "rhs_applies_per_s": 2 * args.nrhs * steps / el2,
-                         "ms_per_pair_of_batches": 1e3 * el2 / steps, "same_result": bool(torch.equal(X, X2))}
-            M2.close()
+            pipelined = {"nrhs": 2 * args.nrhs, "tiles_in_flight": 2, "rhs_applies_per_s": 2 * args.nrhs * steps / el2,
+                         "ms_per_batch": 1e3 * el2 / steps,
+                         "roofline_frac": M.algorithmic_bytes(2 * args.nrhs) / (el2 / steps) / 1e9 / HBM_PEAK_GBS,
+                         "first_tile_equals_64_column_result": bool(torch.equal(X2[:, :args.nrhs], X))}
             del B2, X2
         res = dict(ms_per_step=1e3 * el / steps, value=world * args.nrhs * steps / el, dev_ms=dev_ms, balg=balg, stage_bytes=stage_bytes, nrhs1_ms=nrhs1_ms, pipelined=pipelined,
                    stats=st, cpu=cpu, gather_ms=gather_ms, parity=parity, levels=levels)
@@ -290,7 +289,7 @@ def main():
         if r["gather_ms"] is not None:
             line["gather_ms"] = r["gather_ms"]
         if r["pipelined"] is not None:
-            line["two_batches_in_flight"] = r["pipelined"]
+            line["wide_batch"] = r["pipelined"]
         if r["nrhs1_ms"] is not None:
             line["nrhs1"] = {"config": "same hierarchy, nrhs=1 (BASELINE configs[1])", "ms_per_apply": r["nrhs1_ms"],
                              "applies_per_s": 1e3 / r["nrhs1_ms"]}
