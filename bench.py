@@ -122,8 +122,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and "OMP_NUM_THREADS" not in os.environ:
+    if world > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
         # every rank analyses the (replicated) hierarchy on the host with OpenMP: share the cores
+        # (torch.distributed.run pins OMP_NUM_THREADS=1 by default, which would serialise that analysis)
         os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // world))
     import torch
     import torch.distributed as dist
