@@ -1416,6 +1416,111 @@ class Engine : public EngineBase {
     HIP_OK(hipStreamSynchronize(stream));
   }
 
+  // ---- on-disk form of the imported hierarchy (exactly the hifamd_add_level / hifamd_set_dense arguments) ---
+  // so that a hierarchy factorized once on a host with the reference can be applied on GPU nodes that do
+  // not have it.  Little-endian, 8-byte aligned records: see hifir_amd.h.
+  template <class V>
+  static void put_vec(std::FILE *f, const std::vector<V> &v) {
+    const int64_t cnt = (int64_t)v.size();
+    if (std::fwrite(&cnt, sizeof(cnt), 1, f) != 1) throw Error(HIFAMD_HIFIR_ERROR, "short write");
+    if (cnt && std::fwrite(v.data(), sizeof(V), (size_t)cnt, f) != (size_t)cnt) throw Error(HIFAMD_HIFIR_ERROR, "short write");
+    const size_t padb = (8 - (cnt * sizeof(V)) % 8) % 8;
+    const char zeros[8] = {0};
+    if (padb && std::fwrite(zeros, 1, padb, f) != padb) throw Error(HIFAMD_HIFIR_ERROR, "short write");
+  }
+  template <class V>
+  static void get_vec(std::FILE *f, std::vector<V> &v) {
+    int64_t cnt = 0;
+    if (std::fread(&cnt, sizeof(cnt), 1, f) != 1 || cnt < 0 || cnt > (int64_t)1 << 40) throw Error(HIFAMD_BAD_PREC, "corrupt hierarchy file");
+    v.resize((size_t)cnt);
+    if (cnt && std::fread(v.data(), sizeof(V), (size_t)cnt, f) != (size_t)cnt) throw Error(HIFAMD_BAD_PREC, "truncated hierarchy file");
+    const size_t padb = (8 - (cnt * sizeof(V)) % 8) % 8;
+    char skip[8];
+    if (padb && std::fread(skip, 1, padb, f) != padb) throw Error(HIFAMD_BAD_PREC, "truncated hierarchy file");
+  }
+  static void put_ccs(std::FILE *f, const Ccs<T> &A) {
+    const int64_t hdr[2] = {A.nrows, A.ncols};
+    if (std::fwrite(hdr, sizeof(hdr), 1, f) != 1) throw Error(HIFAMD_HIFIR_ERROR, "short write");
+    put_vec(f, A.colptr);
+    put_vec(f, A.rowind);
+    put_vec(f, A.vals);
+  }
+  static void get_ccs(std::FILE *f, Ccs<T> &A) {
+    int64_t hdr[2];
+    if (std::fread(hdr, sizeof(hdr), 1, f) != 1) throw Error(HIFAMD_BAD_PREC, "truncated hierarchy file");
+    A.nrows = hdr[0];
+    A.ncols = hdr[1];
+    get_vec(f, A.colptr);
+    get_vec(f, A.rowind);
+    get_vec(f, A.vals);
+  }
+  void save(std::FILE *f) const {
+    if (adjoint || is_twin) throw Error(HIFAMD_HIFIR_ERROR, "internal engines are not saved");
+    const int64_t nl = (int64_t)host.levels.size(), hd = host.has_dense ? 1 : 0;
+    if (std::fwrite(&nl, 8, 1, f) != 1 || std::fwrite(&hd, 8, 1, f) != 1) throw Error(HIFAMD_HIFIR_ERROR, "short write");
+    for (const auto &H : host.levels) {
+      const int64_t hdr[3] = {H.m, H.n, H.F_ncols};
+      if (std::fwrite(hdr, sizeof(hdr), 1, f) != 1) throw Error(HIFAMD_HIFIR_ERROR, "short write");
+      put_ccs(f, H.L);
+      put_ccs(f, H.U);
+      put_ccs(f, H.E);
+      put_ccs(f, H.F);
+      put_vec(f, H.d);
+      put_vec(f, H.s);
+      put_vec(f, H.t);
+      put_vec(f, H.p);
+      put_vec(f, H.p_inv);
+      put_vec(f, H.q);
+      put_vec(f, H.q_inv);
+    }
+    if (hd) {
+      const int64_t nd = host.dense.n;
+      if (std::fwrite(&nd, 8, 1, f) != 1 || std::fwrite(&host.dense.rrqr_cond, 8, 1, f) != 1)
+        throw Error(HIFAMD_HIFIR_ERROR, "short write");
+      put_vec(f, host.dense.mat);
+    }
+  }
+  void load(std::FILE *f) {
+    int64_t nl = 0, hd = 0;
+    if (std::fread(&nl, 8, 1, f) != 1 || std::fread(&hd, 8, 1, f) != 1 || nl < 1 || nl > 4096) throw Error(HIFAMD_BAD_PREC, "corrupt hierarchy file");
+    for (int64_t l = 0; l < nl; ++l) {
+      int64_t hdr[3];
+      if (std::fread(hdr, sizeof(hdr), 1, f) != 1) throw Error(HIFAMD_BAD_PREC, "truncated hierarchy file");
+      Ccs<T> L, U, E, F;
+      std::vector<T> d;
+      std::vector<double> s, t;
+      std::vector<int32_t> p, p_inv, q, q_inv;
+      get_ccs(f, L);
+      get_ccs(f, U);
+      get_ccs(f, E);
+      get_ccs(f, F);
+      get_vec(f, d);
+      get_vec(f, s);
+      get_vec(f, t);
+      get_vec(f, p);
+      get_vec(f, p_inv);
+      get_vec(f, q);
+      get_vec(f, q_inv);
+      const int64_t m = hdr[0], n = hdr[1];
+      if ((int64_t)d.size() != m || (int64_t)s.size() != n || (int64_t)t.size() != n || (int64_t)p.size() != n ||
+          (int64_t)q_inv.size() != n || (int64_t)L.colptr.size() != m + 1 || (int64_t)U.colptr.size() != m + 1)
+        throw Error(HIFAMD_BAD_PREC, "inconsistent hierarchy file");
+      add_level(m, n, L.colptr.data(), L.rowind.data(), L.vals.data(), U.colptr.data(), U.rowind.data(), U.vals.data(),
+                E.colptr.data(), E.rowind.data(), E.vals.data(), hdr[2], hdr[2] ? F.colptr.data() : nullptr,
+                F.rowind.data(), F.vals.data(), d.data(), s.data(), t.data(), p.data(),
+                p_inv.empty() ? nullptr : p_inv.data(), q.empty() ? nullptr : q.data(), q_inv.data());
+    }
+    if (hd) {
+      int64_t nd = 0;
+      double cond = 0.0;
+      if (std::fread(&nd, 8, 1, f) != 1 || std::fread(&cond, 8, 1, f) != 1) throw Error(HIFAMD_BAD_PREC, "truncated hierarchy file");
+      std::vector<T> mat;
+      get_vec(f, mat);
+      if ((int64_t)mat.size() != nd * nd) throw Error(HIFAMD_BAD_PREC, "inconsistent hierarchy file");
+      set_dense(nd, mat.data(), cond);
+    }
+  }
+
   // operator selection of lhf?Apply (libhifir.cpp:447-472): S on this engine, SH on the adjoint one
   Engine<T> &for_op(int op) {
     if (op == HIFAMD_S || op == HIFAMD_M) return *this;
@@ -1799,6 +1904,68 @@ HifAmdStatus hifamd_add_level(HifAmdHdl h, int64_t m, int64_t n, const int64_t *
                             (const zdouble *)Ev, F_ncols, Fcp, Fri, (const zdouble *)Fv, (const zdouble *)d, s, t,
                             p, p_inv, q, q_inv))
   API_END
+}
+
+static const char kFileMagic[8] = {'H', 'I', 'F', 'A', 'M', 'D', '1', 0};
+
+HifAmdStatus hifamd_save(HifAmdHdl h, const char *path) {
+  API_BEGIN
+  if (!path) throw Error(HIFAMD_NULL_OBJ, "NULL path");
+  std::FILE *f = std::fopen(path, "wb");
+  if (!f) throw Error(HIFAMD_HIFIR_ERROR, std::string("cannot open for writing: ") + path);
+  try {
+    const int64_t vt = h->vt;
+    if (std::fwrite(kFileMagic, 8, 1, f) != 1 || std::fwrite(&vt, 8, 1, f) != 1) throw Error(HIFAMD_HIFIR_ERROR, "short write");
+    DISPATCH(ENG_D->save(f), ENG_Z->save(f))
+  } catch (...) {
+    std::fclose(f);
+    throw;
+  }
+  if (std::fclose(f) != 0) throw Error(HIFAMD_HIFIR_ERROR, "write failed");
+  API_END
+}
+
+HifAmdStatus hifamd_load(const char *path, int device, HifAmdHdl *out) {
+  if (!out || !path) {
+    set_err("NULL argument");
+    return HIFAMD_NULL_OBJ;
+  }
+  *out = nullptr;
+  std::FILE *f = std::fopen(path, "rb");
+  if (!f) {
+    set_err(std::string("cannot open hierarchy file: ") + path);
+    return HIFAMD_HIFIR_ERROR;
+  }
+  char magic[8];
+  int64_t vt = -1;
+  if (std::fread(magic, 8, 1, f) != 1 || std::memcmp(magic, kFileMagic, 8) != 0 || std::fread(&vt, 8, 1, f) != 1 ||
+      (vt != HIFAMD_D && vt != HIFAMD_Z)) {
+    std::fclose(f);
+    set_err("not a hifir_amd hierarchy file");
+    return HIFAMD_BAD_PREC;
+  }
+  HifAmdHdl h = nullptr;
+  HifAmdStatus st = hifamd_create((HifAmdValueType)vt, device, &h);
+  if (st != HIFAMD_SUCCESS) {
+    std::fclose(f);
+    return st;
+  }
+  try {
+    DISPATCH(ENG_D->load(f), ENG_Z->load(f))
+  } catch (const Error &e) {
+    std::fclose(f);
+    hifamd_destroy(h);
+    set_err(e.what());
+    return (HifAmdStatus)e.code;
+  } catch (const std::exception &e) {
+    std::fclose(f);
+    hifamd_destroy(h);
+    set_err(e.what());
+    return HIFAMD_HIFIR_ERROR;
+  }
+  std::fclose(f);
+  *out = h;
+  return HIFAMD_SUCCESS;
 }
 
 HifAmdStatus hifamd_set_dense(HifAmdHdl h, int64_t nd, const void *mat, double rrqr_cond) {

@@ -579,6 +579,8 @@ struct HostLevel {
 template <class T>
 struct HostDense {
   int64_t n = 0, rank = 0;
+  std::vector<T> mat;          // the unfactored block as imported (kept for hifamd_save)
+  double rrqr_cond = 0.0;
   std::vector<T> qr, tau;      // GEQP3 layout
   std::vector<int32_t> jpvt0;  // 0-based column permutation
   std::vector<T> QH, Rinv;     // explicit operators, column-major
@@ -837,6 +839,8 @@ void dense_adjoint_ops(HostDense<T> &D) {
 template <class T>
 void dense_factorize(HostDense<T> &D, const T *mat_colmajor, int64_t n, double rrqr_cond) {
   D.n = n;
+  D.mat.assign(mat_colmajor, mat_colmajor + n * n);
+  D.rrqr_cond = rrqr_cond;
   D.qr.assign(mat_colmajor, mat_colmajor + n * n);
   qr_colpiv(n, D.qr, D.jpvt0, D.tau);
   const double eps = std::numeric_limits<double>::epsilon();

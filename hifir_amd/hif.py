@@ -14,6 +14,7 @@ Errors follow the reference convention (status code + message, libhifir.cpp:34-5
 HifAmdStatus raises HifAmdError carrying the code and the library's message.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -75,6 +76,24 @@ class HIF:
         if int(last.get("dense_n", 0)) > 0:
             self.set_dense(last["dense"], rrqr_cond)
         self.finalize(max_nrhs)
+        return self
+
+    def save(self, path):
+        """Write the imported hierarchy (the add_level / set_dense arguments) to a file (hifamd_save)."""
+        _check(lib().hifamd_save(self._h, os.fsencode(path)))
+
+    @classmethod
+    def load(cls, path, max_nrhs=64, device=-1):
+        """Read a hierarchy written by save() and ship it to the device (hifamd_load + finalize)."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        self._A = None
+        _check(lib().hifamd_load(os.fsencode(path), device, C.byref(self._h)))
+        with open(path, "rb") as f:
+            f.seek(8)
+            self.dtype = np.dtype(np.complex128 if int.from_bytes(f.read(8), "little") == 1 else np.float64)
+        if max_nrhs:
+            self.finalize(max_nrhs)
         return self
 
     def add_level(self, lv):

@@ -90,6 +90,17 @@ HifAmdStatus hifamd_set_dense(HifAmdHdl h, int64_t nd, const void *mat_colmajor,
  * on first use only, builder.hpp:414-416 -- not replicated). */
 HifAmdStatus hifamd_finalize(HifAmdHdl h, int64_t max_nrhs);
 
+/* ---- on-disk form of an imported hierarchy ---------------------------------- */
+/* hifamd_save writes exactly what hifamd_add_level / hifamd_set_dense received (before or after
+ * hifamd_finalize); hifamd_load creates a handle and replays those calls -- the caller then calls
+ * hifamd_finalize.  Lets a hierarchy factorized once on a host that has the reference be applied on
+ * GPU nodes that do not.  Format (little-endian): "HIFAMD1\0", int64 value type, int64 #levels, int64
+ * has_dense; per level int64 {m, n, F_ncols}, the four CCS matrices as int64 {nrows, ncols} + three
+ * counted arrays (int64 count, data, zero padding to 8 bytes), then d, s, t, p, p_inv, q, q_inv as
+ * counted arrays; the dense block as int64 nd, double rrqr_cond and a counted column-major array. */
+HifAmdStatus hifamd_save(HifAmdHdl h, const char *path);
+HifAmdStatus hifamd_load(const char *path, int device, HifAmdHdl *out);
+
 /* ---- queries (cf. lhf?GetLevels/GetNnz/GetSchurSize/GetSchurRank, libhifir.h:722-740) ------ */
 int64_t hifamd_nrows(HifAmdHdl h);
 int64_t hifamd_levels(HifAmdHdl h);     /* counts the dense block as a level (builder.hpp:141-147) */

@@ -119,3 +119,34 @@ int main() {
 ''')
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
     subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-I", inc, str(src)])
+
+
+@pytest.mark.parametrize("name", ["p2d_64_deep", "young1c", "p2d_100_tuned"])
+def test_hierarchy_file_roundtrip(name, tmp_path):
+    # hifamd_save / hifamd_load (host side only: no GPU needed before finalize): the reloaded handle holds
+    # the same hierarchy -- same counts, same level schedules -- and a corrupt file is refused
+    levels, d = load_hier(name)
+    M = hifir_amd.HIF(dtype=d["b"].dtype)
+    for lv in levels:
+        M.add_level(lv)
+    if int(levels[-1].get("dense_n", 0)) > 0:
+        M.set_dense(levels[-1]["dense"])
+    path = str(tmp_path / "h.hifamd")
+    M.save(path)
+    M2 = hifir_amd.HIF.load(path, max_nrhs=0)  # 0: do not finalize (no device here)
+    assert M2.dtype == M.dtype
+    assert (M2.nnz(), M2.levels(), M2.nrows(), M2.schur_size(), M2.schur_rank()) == \
+           (M.nnz(), M.levels(), M.nrows(), M.schur_size(), M.schur_rank())
+    for l in range(len(levels)):
+        for which in (0, 1):
+            o1, w1 = M.level_schedule(l, which)
+            o2, w2 = M2.level_schedule(l, which)
+            assert np.array_equal(o1, o2) and np.array_equal(w1, w2)
+    raw = open(path, "rb").read()
+    bad = str(tmp_path / "bad.hifamd")
+    open(bad, "wb").write(raw[: len(raw) // 2])
+    with pytest.raises(hifir_amd.HifAmdError):
+        hifir_amd.HIF.load(bad, max_nrhs=0)
+    open(bad, "wb").write(b"garbage!" + raw[8:])
+    with pytest.raises(hifir_amd.HifAmdError):
+        hifir_amd.HIF.load(bad, max_nrhs=0)

@@ -224,6 +224,18 @@ def test_rotating_buffers_share_one_graph(cache):
         assert relerr(Xs[k].cpu().numpy(), Xo) <= TOL
 
 
+@pytest.mark.parametrize("name", ["cd2d_48", "young1c"])
+def test_saved_hierarchy_applies_identically(cache, name, tmp_path):
+    # hifamd_save -> hifamd_load -> finalize on a "GPU node without the reference": same bits as the original
+    levels, d, M, O = _get(cache, name)
+    path = str(tmp_path / "h.hifamd")
+    M.save(path)
+    M2 = hifir_amd.HIF.load(path, max_nrhs=64)
+    for tr in (False, True):
+        assert np.array_equal(M2.solve_mrhs(d["B4"], trans=tr), M.solve_mrhs(d["B4"], trans=tr))
+    assert np.array_equal(M2.mmultiply(d["x"]), M.mmultiply(d["x"]))
+
+
 def test_spmv_bitwise(cache):
     torch = pytest.importorskip("torch")
     levels, d, M, O = _get(cache, "cd2d_48")
