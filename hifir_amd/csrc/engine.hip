@@ -237,6 +237,10 @@ class Engine : public EngineBase {
   DevBuf zt1, zt2;       // complex handles: the two real partial products A_re X, A_im X (k_zcombine)
   // IR scratch
   DevBuf ir_r, ir_xk, ir_part, stage_b, stage_x;
+  // constant-mode null-space filter of this engine's solve (HIF::nsp on the primary, HIF::nsp_tran on the adjoint)
+  bool nsp_on = false;
+  int64_t nsp_r0 = 0, nsp_r1 = -1;
+  DevBuf nsp_part;
   DevBuf gm_v, gm_w, gm_Q, gm_alpha;  // GMRES: work vectors, Krylov basis, per-column coefficients
   int64_t ir_cols = 0;
 
@@ -999,9 +1003,29 @@ class Engine : public EngineBase {
         total += Tw.last_launches;
       }
       last_launches = total;
+      if (kind == 0) apply_nsp(dX, ldx, nrhs, st);
       return;
     }
     launch_part(dB, ldb, dX, ldx, nrhs, rank, st, kind, 0, 1);
+    if (kind == 0) apply_nsp(dX, ldx, nrhs, st);
+  }
+
+  // builder.hpp:419-422: after the solve, x loses its component along the (constant) null space
+  void apply_nsp(D *dX, int64_t ldx, int64_t nrhs, hipStream_t st) {
+    if (!nsp_on) return;
+    const int64_t n = lv[0]->n;
+    const int64_t r0 = nsp_r0, r1 = (nsp_r1 < 0 || nsp_r1 < nsp_r0) ? n : nsp_r1;  // NspFilter.hpp:163-167
+    if (r1 > n) throw Error(HIFAMD_MISMATCHED_SIZES, "null-space filter range exceeds the system size");
+    if (r0 == r1) return;
+    const int nblk = 256;
+    if (nsp_part.bytes < (size_t)nblk * 64 * sizeof(T)) nsp_part.alloc((size_t)nblk * 64 * sizeof(T));
+    for (int64_t c0 = 0; c0 < nrhs; c0 += 64) {
+      const int nc = (int)std::min<int64_t>(64, nrhs - c0);
+      hipLaunchKernelGGL((k_colsum_partial<D>), dim3(nblk), dim3(256), 0, st, r0, r1, nc, (const D *)(dX + c0), ldx,
+                         nsp_part.as<D>());
+      hipLaunchKernelGGL((k_sub_colmean<D>), dim3(vec_grid((r1 - r0) * nc)), dim3(256), 0, st, r0, r1, nc, dX + c0, ldx,
+                         (const D *)nsp_part.as<D>(), nblk);
+    }
   }
 
   void launch_part(const D *dB, int64_t ldb, D *dX, int64_t ldx, int64_t nrhs, int64_t rank, hipStream_t st, int kind,
@@ -1903,6 +1927,20 @@ HifAmdStatus hifamd_add_level(HifAmdHdl h, int64_t m, int64_t n, const int64_t *
            ENG_Z->add_level(m, n, Lcp, Lri, (const zdouble *)Lv, Ucp, Uri, (const zdouble *)Uv, Ecp, Eri,
                             (const zdouble *)Ev, F_ncols, Fcp, Fri, (const zdouble *)Fv, (const zdouble *)d, s, t,
                             p, p_inv, q, q_inv))
+  API_END
+}
+
+HifAmdStatus hifamd_set_nsp_const(HifAmdHdl h, HifAmdOp op, int64_t start, int64_t end) {
+  API_BEGIN
+  if (op != HIFAMD_S && op != HIFAMD_SH) throw Error(HIFAMD_MISMATCHED_SIZES, "the filter belongs to HIFAMD_S or HIFAMD_SH");
+  const bool on = !(end >= 0 && start > end);
+  if (h->vt == HIFAMD_D) {
+    Engine<double> &E = ENG_D->for_op(op);
+    E.nsp_on = on, E.nsp_r0 = start, E.nsp_r1 = end;
+  } else {
+    Engine<zdouble> &E = ENG_Z->for_op(op);
+    E.nsp_on = on, E.nsp_r0 = start, E.nsp_r1 = end;
+  }
   API_END
 }
 

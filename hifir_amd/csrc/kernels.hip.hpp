@@ -64,6 +64,9 @@ __device__ __forceinline__ unsigned xcd_block() {
   return x * q + (x < r ? x : r) + (b >> 3);
 }
 
+__device__ __forceinline__ double vdivr(double a, double r) { return a / r; }
+__device__ __forceinline__ cplx vdivr(cplx a, double r) { return cplx{a.x / r, a.y / r}; }
+
 // lane decomposition
 struct LaneMap {
   int g, c, G;
@@ -568,9 +571,6 @@ __global__ void __launch_bounds__(256) k_crs_spmm(int64_t nrows, const int32_t *
 // prec_prod (y = M b, alg/prec_prod.hpp:55-147): the inverse direction of the apply.  No dependent steps
 // except the one LDU solve of the Schur coupling term, so these are plain row-gather kernels.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double vdivr(double a, double r) { return a / r; }
-__device__ __forceinline__ cplx vdivr(cplx a, double r) { return cplx{a.x / r, a.y / r}; }
-
 // g[i] = b[q[i]] / t[q[i]], rows [0, cnt)   (:76, :97; with (p, s) for the transposed product)
 template <class T>
 __global__ void __launch_bounds__(256) k_gather_div(IoPtr<const T> bin_, int64_t ldb, int nrhs,
@@ -690,6 +690,49 @@ __global__ void __launch_bounds__(256) k_colnorm2_partial(int64_t n, int nrhs, c
     double tot = 0.0;
     for (int r = 0; r < rows_per_pass; ++r) tot += sm[r * cpad + threadIdx.x];
     partial[(int64_t)blockIdx.x * nrhs + threadIdx.x] = tot;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Constant-mode null-space filter (NspFilter::_const_filter, NspFilter.hpp:161-175): every column loses
+// the mean of its rows [r0, r1).  Two launches, no host round trip: per-block partial column sums, then
+// every block re-adds the partials (fixed order: deterministic) and subtracts.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256) k_colsum_partial(int64_t r0, int64_t r1, int nrhs, const T *x, int64_t ldx,
+                                                        T *partial /* [gridDim.x][nrhs] */) {
+  __shared__ T sm[256];
+  const int cpad = nrhs;  // nrhs <= 64 here
+  const int rows_per_pass = 256 / cpad;
+  const int c = threadIdx.x % cpad, rloc = threadIdx.x / cpad;
+  T acc = vzero(T());
+  if (rloc < rows_per_pass)
+    for (int64_t i = r0 + (int64_t)blockIdx.x * rows_per_pass + rloc; i < r1; i += (int64_t)gridDim.x * rows_per_pass)
+      acc = vadd(acc, x[i * ldx + c]);
+  sm[threadIdx.x] = (rloc < rows_per_pass) ? acc : vzero(T());
+  __syncthreads();
+  if (threadIdx.x < cpad) {
+    T tot = vzero(T());
+    for (int r = 0; r < rows_per_pass; ++r) tot = vadd(tot, sm[r * cpad + threadIdx.x]);
+    partial[(int64_t)blockIdx.x * nrhs + threadIdx.x] = tot;
+  }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) k_sub_colmean(int64_t r0, int64_t r1, int nrhs, T *x, int64_t ldx,
+                                                     const T *__restrict__ partial, int nblk) {
+  __shared__ T mean[64];
+  if (threadIdx.x < nrhs) {
+    T tot = vzero(T());
+    for (int b = 0; b < nblk; ++b) tot = vadd(tot, partial[(int64_t)b * nrhs + threadIdx.x]);
+    mean[threadIdx.x] = vdivr(tot, (double)(r1 - r0));
+  }
+  __syncthreads();
+  const int64_t total = (r1 - r0) * nrhs;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = r0 + e / nrhs;
+    const int c = (int)(e % nrhs);
+    x[i * ldx + c] = vsub(x[i * ldx + c], mean[c]);
   }
 }
 

@@ -250,6 +250,11 @@ class HIF:
             _check(lib().hifamd_solve_batch(self._h, _p(B), B.shape[1], _p(X), X.shape[1], B.shape[1], int(rank)))
         return X
 
+    def set_nsp_const(self, start=0, end=-1, trans=False):
+        """Constant-mode null-space filter of solve() (HIF::nsp; trans: HIF::nsp_tran): rows [start, end) of
+        every solution lose their mean; start > end >= 0 removes the filter."""
+        _check(lib().hifamd_set_nsp_const(self._h, OP_SH if trans else OP_S, int(start), int(end)))
+
     def mmultiply(self, x, trans=False, rank=-1):
         """y = M x (trans: M^H x), the multilevel product HIF::mmultiply (builder.hpp:503-513) -- the inverse
         direction of solve().  x: [n] or [n][nrhs], host array or CUDA tensor."""

@@ -151,6 +151,14 @@ HifAmdStatus hifamd_hifir_batch_dev(HifAmdHdl h, const void *dB, int64_t ldb, vo
                                     int64_t nrhs, int nirs, const double *betas, int64_t rank,
                                     int *ir_status);
 
+/* ---- null-space filter (HIF::nsp / HIF::nsp_tran, builder.hpp:419-422, 491-492) --------------- */
+/* Constant mode (NspFilter::set_nsp_const, NspFilter.hpp:118-125): after every HIFAMD_S (op = HIFAMD_S)
+ * or HIFAMD_SH (op = HIFAMD_SH) apply -- inside iterative refinement and GMRES too -- each column loses
+ * the mean of its rows [start, end); end < 0 means "to the last row"; start > end >= 0 removes the
+ * filter.  Unlike the reference (builder.hpp:439) batched applies are filtered as well.  Needs a
+ * finalized handle. */
+HifAmdStatus hifamd_set_nsp_const(HifAmdHdl h, HifAmdOp op, int64_t start, int64_t end);
+
 /* ---- lhf?Apply with an operator tag (libhifir.h:685, libhifir.cpp:447-472), batched ----------- */
 /* op = HIFAMD_S / HIFAMD_SH: nirs <= 1 direct apply (ir_status, if given, gets {1, -1} per column);
  * nirs > 1: iterative refinement with A (HIFAMD_S) or A^H (HIFAMD_SH, IterRefine.hpp:93-96).

@@ -131,6 +131,12 @@ class HIF {
     _has_A = false;
   }
   HifAmdHdl handle() const { return _h; }  ///< for the device-pointer entry points of hifir_amd.h
+  /// HIF::nsp / nsp_tran with NspFilter::set_nsp_const (NspFilter.hpp:118-125); start > end removes it
+  void set_nsp_const(const size_type start = 0, const size_type end = static_cast<size_type>(-1), const bool trans = false) {
+    require();
+    detail::check(hifamd_set_nsp_const(_h, trans ? HIFAMD_SH : HIFAMD_S, (std::int64_t)start,
+                                       end == static_cast<size_type>(-1) ? -1 : (std::int64_t)end));
+  }
 
   // ---- x = M^{-1} b / M^{-H} b (builder.hpp:409-423) ---------------------------------------------
   template <class RhsType, class SolType>

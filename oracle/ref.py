@@ -166,6 +166,16 @@ def _gmres(self, b, restart=30, rtol=1e-6, maxit=500, full_rank=False):
 RefHIF.gmres = _gmres
 
 
+def _set_nsp_const(self, start=0, end=-1, trans=False):
+    """HIF::nsp (trans: nsp_tran) = constant-mode filter on rows [start, end) (end < 0: to the end);
+    start > end >= 0 removes it.  Real handles only."""
+    lib().hifref_d_set_nsp_const.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64]
+    lib().hifref_d_set_nsp_const(self.h, int(trans), start, end)
+
+
+RefHIF.set_nsp_const = _set_nsp_const
+
+
 def spmv(indptr, indices, vals, x):
     vals = np.ascontiguousarray(vals)
     k = "z" if np.iscomplexobj(vals) else "d"

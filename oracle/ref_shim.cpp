@@ -347,6 +347,17 @@ int hifref_d_mmultiply_tran(void *h, const double *x, double *y, int64_t rank) {
 int hifref_z_mmultiply_tran(void *h, const void *x, void *y, int64_t rank) {
   return do_mmultiply<zt>(h, (const zt *)x, (zt *)y, rank, true);
 }
+// HIF::nsp / HIF::nsp_tran (builder.hpp:491-492): constant-mode null-space filter applied inside solve
+// (NspFilter::set_nsp_const, NspFilter.hpp:118-125); start > end removes the filter
+void hifref_d_set_nsp_const(void *h, int tran, int64_t start, int64_t end) {
+  auto *r = (Ref<double> *)h;
+  hif::NspFilterPtr f;
+  if (start <= end || end < 0) {
+    f = hif::create_nsp_filter();
+    f->set_nsp_const((size_t)start, end < 0 ? (size_t)-1 : (size_t)end);
+  }
+  (tran ? r->M.nsp_tran : r->M.nsp) = f;
+}
 int hifref_d_hifir(void *h, const double *b, int nirs, const double *betas, double *x, int *st) {
   return do_hifir<double>(h, b, nirs, betas, x, st);
 }

@@ -166,3 +166,35 @@ def test_complex_helmholtz_like_vs_oracle():
     assert relerr(XH, O.solve_batch(B, threads=4, trans=True)) <= 1e-12
     assert relerr(XH[:, 3], R.solve(B[:, 3].copy(), trans=True)) <= 1e-12
     assert relerr(XH, X) > 1e-3
+
+
+def test_constant_null_space_filter_matches_reference():
+    # HIF::nsp / HIF::nsp_tran in constant mode (NspFilter.hpp:118-125, applied inside solve: builder.hpp:419-422)
+    A = poisson2d(60)
+    n = A.shape[0]
+    R = ref.RefHIF(A.indptr, A.indices, A.data)
+    M = hifir_amd.HIF.from_levels(R.levels(), max_nrhs=8)
+    M.set_matrix(A.indptr, A.indices, A.data)
+    rng = np.random.default_rng(9)
+    b = rng.uniform(-1, 1, n)
+    B = rng.uniform(-1, 1, size=(n, 70))
+    plain = M.solve(b)
+    for start, end in ((0, -1), (100, 1300)):
+        R.set_nsp_const(start, end)
+        M.set_nsp_const(start, end)
+        x = M.solve(b)
+        assert relerr(x, R.solve(b)) <= 1e-12
+        e = n if end < 0 else end
+        assert abs(x[start:e].mean()) <= 1e-14 * np.abs(x).max() + 1e-16
+        assert relerr(M.solve(b, trans=True), R.solve(b, trans=True)) <= 1e-12  # nsp does not touch the transposed solve
+        X = M.solve_mrhs(B)  # batched applies are filtered too, column by column
+        assert relerr(X[:, 69], R.solve(B[:, 69].copy())) <= 1e-12
+        x4, _ = R.hifir(b, 4)
+        assert relerr(M.hifir(b, 4), x4) <= 1e-11  # the filter sits inside every refinement sweep
+    R.set_nsp_const(5, 2)  # start > end: remove
+    M.set_nsp_const(5, 2)
+    assert np.array_equal(M.solve(b), plain)
+    R.set_nsp_const(0, -1, trans=True)
+    M.set_nsp_const(0, -1, trans=True)
+    assert relerr(M.solve(b, trans=True), R.solve(b, trans=True)) <= 1e-12
+    assert np.array_equal(M.solve(b), plain)
