@@ -7,6 +7,7 @@
 // alg/IterRefine.hpp:77-165.  There is NO host fallback: every compute path needs a HIP device.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -125,7 +126,7 @@ struct DevCsr {
     blk_inv_off = o.blk_inv_off;
   }
   template <class T>
-  void upload(const Csr<T> &A, const BandPlan *P, const std::vector<double> *inv = nullptr) {
+  void upload(const Csr<T> &A, const BandPlan *P) {
     nrows = A.nrows;
     ncols = A.ncols;
     nnz = (int64_t)A.col.size();
@@ -145,7 +146,6 @@ struct DevCsr {
       blk_slot0 = P->blk_slot0;
       blk_slot1 = P->blk_slot1;
       blk_inv_off = P->blk_inv_off;
-      if (inv) tinv.upload(*inv);
       band_slot_ptr.clear();
       for (size_t b = 0; b < band_wg_ptr.size(); ++b)
         band_slot_ptr.push_back(P->grp_slot_ptr[(size_t)P->wg_grp_ptr[(size_t)band_wg_ptr[b]]]);
@@ -353,17 +353,26 @@ class Engine : public EngineBase {
 
   // schedules, band plans, slot-ordered matrices and block inverses of one level (H.Lr .. H.Fr given)
   void analyze_level(HostLevel<T> &H) {
+    const bool dump = env_int("HIFIR_AMD_PLAN_DUMP", 0) != 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
     H.Ls = level_schedule(H.Lr, true);
     H.Us = level_schedule(H.Ur, false);
+    double t1 = now();
     H.Lp = plan_bands(H.Lr, H.Ls, true, band_opt);
     H.Up = plan_bands(H.Ur, H.Us, false, band_opt);
+    double t2 = now();
     H.Lr = permute_rows(H.Lr, H.Lp.order);
     H.Ur = permute_rows(H.Ur, H.Up.order);
     finish_band_plan(H.Lp, H.Lr);
     finish_band_plan(H.Up, H.Ur);
-    build_dense_blocks(H.Lp, H.Lr, band_opt, H.Ltinv);
-    build_dense_blocks(H.Up, H.Ur, band_opt, H.Utinv);
-    if (env_int("HIFIR_AMD_PLAN_DUMP", 0)) {  // development aid: one line per band
+    double t3 = now();
+    H.Ltinv_elems = plan_dense_blocks<T>(H.Lp, band_opt);
+    H.Utinv_elems = plan_dense_blocks<T>(H.Up, band_opt);
+    if (dump)
+      std::fprintf(stderr, "ANALYZE m=%ld: schedule %.2f s, band plan %.2f s, permute+finish %.2f s, block inverses %.2f s\n",
+                   (long)H.m, t1 - t0, t2 - t1, t3 - t2, now() - t3);
+    if (dump) {  // development aid: one line per band
       for (int tri = 0; tri < 2; ++tri) {
         const BandPlan &P = tri ? H.Up : H.Lp;
         const Csr<T> &A = tri ? H.Ur : H.Lr;
@@ -562,6 +571,42 @@ class Engine : public EngineBase {
     host.has_dense = true;
   }
 
+  // Block inverses of a triangle's block-dense thin bands: built one block at a time into two pinned staging
+  // buffers (reused, so the host never holds more than two blocks) and streamed to HBM while the next block
+  // is being inverted.  A band whose inverse grows beyond dense_max_growth reverts to the sequential scheme.
+  void ship_block_inverses(BandPlan &P, const Csr<T> &A, int64_t total_elems, DevCsr &M) {
+    M.upload(A, &P);
+    if (!total_elems) return;
+    M.tinv.alloc((size_t)total_elems * sizeof(double));
+    const bool cplx = sizeof(T) != sizeof(double);
+    const size_t cap = (size_t)dense_block_elems(band_opt.dense_block, cplx) * sizeof(double);
+    if (!pin[0]) {
+      HIP_OK(hipHostMalloc((void **)&pin[0], cap, hipHostMallocDefault));
+      HIP_OK(hipHostMalloc((void **)&pin[1], cap, hipHostMallocDefault));
+      HIP_OK(hipEventCreateWithFlags(&pin_done[0], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&pin_done[1], hipEventDisableTiming));
+    }
+    std::vector<uint8_t> bad(P.blk_slot0.size(), 0);
+    for (size_t q = 0; q < P.blk_slot0.size(); ++q) {
+      const int which = (int)(pin_next++ & 1);
+      HIP_OK(hipEventSynchronize(pin_done[which]));  // the copy that last used this buffer has finished
+      const int64_t nb = P.blk_slot1[q] - P.blk_slot0[q];
+      const double growth = build_dense_block(P, A, q, pin[which]);
+      if (!(growth <= band_opt.dense_max_growth)) bad[q] = 1;
+      HIP_OK(hipMemcpyAsync(M.tinv.as<double>() + P.blk_inv_off[q], pin[which],
+                            (size_t)dense_block_elems(nb, cplx) * sizeof(double), hipMemcpyHostToDevice, stream));
+      HIP_OK(hipEventRecord(pin_done[which], stream));
+    }
+    bool any_bad = false;
+    for (int64_t b = 0; b < P.nbands(); ++b)
+      for (int32_t q = P.band_blk_ptr[(size_t)b]; q < P.band_blk_ptr[(size_t)b + 1]; ++q)
+        if (bad[(size_t)q]) P.band_dense[(size_t)b] = 0, any_bad = true;
+    if (any_bad) M.band_dense = P.band_dense;  // (launch_trsv walks the band table of the device copy)
+  }
+  double *pin[2] = {nullptr, nullptr};
+  hipEvent_t pin_done[2] = {nullptr, nullptr};
+  uint64_t pin_next = 0;
+
   void finalize(int64_t max_nrhs_) {
     if (finalized) throw Error(HIFAMD_BAD_PREC, "hierarchy already finalized");
     if (host.levels.empty()) throw Error(HIFAMD_BAD_PREC, "empty hierarchy");
@@ -581,10 +626,8 @@ class Engine : public EngineBase {
       L.n = H.n;
       L.F_ncols = H.F_ncols;
       L.E_void = H.E_void;
-      L.L.upload(H.Lr, &H.Lp, &H.Ltinv);
-      L.U.upload(H.Ur, &H.Up, &H.Utinv);
-      std::vector<double>().swap(H.Ltinv);
-      std::vector<double>().swap(H.Utinv);
+      ship_block_inverses(H.Lp, H.Lr, H.Ltinv_elems, L.L);
+      ship_block_inverses(H.Up, H.Ur, H.Utinv_elems, L.U);
       L.E.upload(H.Er, nullptr);
       L.F.upload(H.Fr, nullptr);
       L.d.upload(H.d);
@@ -635,6 +678,12 @@ class Engine : public EngineBase {
       HIP_OK(hipMemset(blk_tmp.p, 0, blk_tmp.bytes));
     }
     HIP_OK(hipDeviceSynchronize());
+    for (int k = 0; k < 2; ++k) {  // the staging buffers of the block inverses are not needed any more
+      if (pin[k]) (void)hipHostFree(pin[k]);
+      if (pin_done[k]) (void)hipEventDestroy(pin_done[k]);
+      pin[k] = nullptr;
+      pin_done[k] = nullptr;
+    }
     finalized = true;
   }
 

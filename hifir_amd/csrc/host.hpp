@@ -9,7 +9,11 @@
 #include <cmath>
 #include <complex>
 #include <cstdint>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <omp.h>
 #include <limits>
 #include <stdexcept>
 #include <string>
@@ -434,72 +438,98 @@ BandPlan plan_bands(const Csr<T> &A, const Schedule &S, bool lower, const BandOp
 // This changes the order of summation inside thin bands (tolerance-level differences, 1e-15 relative
 // on the hierarchies measured); a band whose inverse entries grow beyond dense_max_growth keeps the
 // sequential scheme, which is backward stable for any factor.
+inline void put_operand(double *base, int64_t, int64_t idx, double v) { base[idx] = v; }
+inline void put_operand(double *base, int64_t plane, int64_t idx, const zdouble &v) {
+  base[idx] = v.real();
+  base[plane + idx] = v.imag();
+}
+
+// Pass 1 (import time, cheap): cut every candidate band into blocks and lay their MFMA operands out back to
+// back; returns the total number of doubles.  blk_inv_off counts doubles; complex blocks hold two planes.
 template <class T>
-void build_dense_blocks(BandPlan &P, const Csr<T> &A, const BandOptions &opt, std::vector<double> &tinv_ops) {
-  std::vector<T> tinv;  // column-major inverses, block after block; converted to MFMA operands at the end
+int64_t plan_dense_blocks(BandPlan &P, const BandOptions &opt) {
+  const int64_t nplanes = sizeof(T) == sizeof(double) ? 1 : 2;
   P.band_blk_ptr.assign(1, 0);
+  P.blk_slot0.clear();
+  P.blk_slot1.clear();
+  P.blk_inv_off.clear();
+  int64_t total = 0;
   for (int64_t b = 0; b < P.nbands(); ++b) {
     if (P.band_dense[(size_t)b]) {
       const int32_t g = P.band_wg_ptr[(size_t)b];
       const int32_t s0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]], s1 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]];
-      const size_t first_blk = P.blk_slot0.size();
-      const size_t tinv_mark = tinv.size();
-      bool ok = true;
-      for (int32_t r0 = s0; r0 < s1 && ok; r0 += (int32_t)opt.dense_block) {
-        const int32_t r1 = std::min<int32_t>(s1, r0 + (int32_t)opt.dense_block), nb = r1 - r0;
-        const size_t off = tinv.size();
-        tinv.resize(off + (size_t)nb * nb, T(0));
-        T *Y = &tinv[off];  // column-major nb x nb: column c = T_bb^{-1} e_c
-        // the block's own strict triangle, row by row (local column, value)
-        std::vector<int32_t> bp((size_t)nb + 1, 0), bq;
-        std::vector<T> bv;
-        for (int32_t r = 0; r < nb; ++r) {
-          const int32_t s = r0 + r;
-          for (int32_t k = A.ptr[(size_t)s]; k < A.ptr[(size_t)s + 1]; ++k) {
-            const int32_t q = P.srcslot[(size_t)k] - r0;
-            if (q >= 0) {
-              bq.push_back(q);
-              bv.push_back(A.val[(size_t)k]);
-            }
-          }
-          bp[(size_t)r + 1] = (int32_t)bq.size();
-        }
-        double growth = 1.0;
-#pragma omp parallel for schedule(static) reduction(max : growth)
-        for (int32_t c = 0; c < nb; ++c) {
-          T *y = Y + (size_t)c * nb;
-          y[c] = T(1);
-          for (int32_t r = c + 1; r < nb; ++r) {  // y[r] = -sum_{q in [c, r)} T(r,q) y[q]
-            T acc = T(0);
-            for (int32_t k = bp[(size_t)r]; k < bp[(size_t)r + 1]; ++k)
-              if (bq[(size_t)k] >= c) acc += bv[(size_t)k] * y[(size_t)bq[(size_t)k]];
-            y[r] = -acc;
-            growth = std::max(growth, abs_(y[r]));
-          }
-        }
-        if (!(growth <= opt.dense_max_growth)) ok = false;
+      for (int32_t r0 = s0; r0 < s1; r0 += (int32_t)opt.dense_block) {
+        const int32_t r1 = std::min<int32_t>(s1, r0 + (int32_t)opt.dense_block);
         P.blk_slot0.push_back(r0);
         P.blk_slot1.push_back(r1);
-        P.blk_inv_off.push_back((int64_t)off);
-      }
-      if (!ok) {  // unstable to invert: fall back to the sequential workgroup for this band
-        P.blk_slot0.resize(first_blk);
-        P.blk_slot1.resize(first_blk);
-        P.blk_inv_off.resize(first_blk);
-        tinv.resize(tinv_mark);
-        P.band_dense[(size_t)b] = 0;
+        P.blk_inv_off.push_back(total);
+        total += nplanes * plane_elems(r1 - r0, round_up32(r1 - r0));
       }
     }
     P.band_blk_ptr.push_back((int32_t)P.blk_slot0.size());
   }
-  // MFMA operands: strip-major, zero-padded to a multiple of 32 columns (complex: two real planes)
-  tinv_ops.clear();
-  for (size_t q = 0; q < P.blk_slot0.size(); ++q) {
-    const int64_t nb = P.blk_slot1[q] - P.blk_slot0[q];
-    const std::vector<double> st = mfma_operand(&tinv[(size_t)P.blk_inv_off[q]], nb, nb, round_up32(nb));
-    P.blk_inv_off[q] = (int64_t)tinv_ops.size();
-    tinv_ops.insert(tinv_ops.end(), st.begin(), st.end());
+  return total;
+}
+inline int64_t dense_block_elems(int64_t nb, bool cplx) { return (cplx ? 2 : 1) * plane_elems(nb, round_up32(nb)); }
+
+// Pass 2 (finalize time, one block at a time into a caller-provided buffer of dense_block_elems doubles that
+// is reused -- and shipped to the device -- block after block): the explicit inverse of block q's unit
+// triangle written straight into operand layout.  Returns the largest |entry| (the caller compares it with
+// dense_max_growth and lets an unstable band fall back to the sequential workgroup).
+template <class T>
+double build_dense_block(const BandPlan &P, const Csr<T> &A, size_t q, double *ops) {
+  const int32_t r0 = P.blk_slot0[q], nb = P.blk_slot1[q] - r0;
+  const int64_t ldk = round_up32(nb), plane = plane_elems(nb, ldk);
+  std::memset(ops, 0, sizeof(double) * (size_t)dense_block_elems(nb, sizeof(T) != sizeof(double)));
+  // the block's own strict triangle, row by row (local column, value)
+  std::vector<int32_t> bp((size_t)nb + 1, 0), bq;
+  std::vector<T> bv;
+  for (int32_t r = 0; r < nb; ++r) {
+    const int32_t s = r0 + r;
+    for (int32_t k = A.ptr[(size_t)s]; k < A.ptr[(size_t)s + 1]; ++k) {
+      const int32_t c = P.srcslot[(size_t)k] - r0;
+      if (c >= 0) {
+        bq.push_back(c);
+        bv.push_back(A.val[(size_t)k]);
+      }
+    }
+    bp[(size_t)r + 1] = (int32_t)bq.size();
   }
+  double growth = 1.0;
+  // forward substitution on the identity, CB columns at a time: the CB right-hand sides of a chunk sit
+  // side by side (row-major nb x CB scratch), so every update y[r][:] -= T(r,q) * y[q][:] is one
+  // contiguous SIMD axpy; chunks are independent (one per thread).  y[q][j] is zero for q < c0 + j, hence
+  // no per-column test is needed beyond q >= c0.
+  constexpr int32_t CB = 16;
+#pragma omp parallel reduction(max : growth)
+  {
+    std::vector<T> Yc((size_t)nb * CB);
+#pragma omp for schedule(dynamic, 1)
+    for (int32_t c0 = 0; c0 < nb; c0 += CB) {
+      const int32_t cw = std::min<int32_t>(CB, nb - c0);
+      std::fill(Yc.begin() + (size_t)c0 * CB, Yc.end(), T(0));
+      for (int32_t j = 0; j < cw; ++j) Yc[(size_t)(c0 + j) * CB + j] = T(1);
+      for (int32_t r = c0 + 1; r < nb; ++r) {
+        T *yr = &Yc[(size_t)r * CB];
+        for (int32_t k = bp[(size_t)r]; k < bp[(size_t)r + 1]; ++k) {
+          const int32_t c = bq[(size_t)k];
+          if (c < c0) continue;
+          const T a = bv[(size_t)k];
+          const T *yq = &Yc[(size_t)c * CB];
+          for (int32_t j = 0; j < CB; ++j) yr[j] -= a * yq[j];
+        }
+      }
+      for (int32_t r = c0; r < nb; ++r) {  // element (r, c0 + j) of the strip-major operand
+        const int64_t base = ((int64_t)(r >> 4) * ldk + c0) * 16 + (r & 15);
+        for (int32_t j = 0; j < cw && c0 + j <= r; ++j) {
+          const T val = Yc[(size_t)r * CB + j];
+          put_operand(ops, plane, base + (int64_t)j * 16, val);
+          growth = std::max(growth, abs_(val));
+        }
+      }
+    }
+  }
+  return growth;
 }
 
 template <class T>
@@ -568,7 +598,7 @@ struct HostLevel {
   Csr<T> Lr, Ur, Er, Fr;
   Schedule Ls, Us;   // plain level schedules (wavefronts), kept for queries
   BandPlan Lp, Up;   // what the device executes
-  std::vector<double> Ltinv, Utinv;  // explicit inverses of the diagonal blocks of block-dense thin bands (MFMA operands)
+  int64_t Ltinv_elems = 0, Utinv_elems = 0;  // doubles of block-inverse operands (built and shipped at finalize)
 };
 
 // Dense last level: A P = Q R (GEQP3 semantics), numerical rank as QRCP::factorize decides it
