@@ -73,8 +73,18 @@ struct DevBuf {
   template <class V>
   void upload(const std::vector<V> &h, size_t pad_elems = 0) {
     alloc((h.size() + pad_elems) * sizeof(V));
-    if (bytes) HIP_OK(hipMemset(p, 0, bytes));
-    if (!h.empty()) HIP_OK(hipMemcpy(p, h.data(), h.size() * sizeof(V), hipMemcpyHostToDevice));
+    // ONE blocking copy covers the whole buffer (zero padding included): no asynchronous memset is left
+    // pending behind it (a hipMemset queued before a small blocking hipMemcpy was seen to land after it)
+    if (pad_elems) {
+      std::vector<V> padded(h.size() + pad_elems);
+      std::copy(h.begin(), h.end(), padded.begin());
+      std::fill(padded.begin() + (std::ptrdiff_t)h.size(), padded.end(), V());
+      HIP_OK(hipMemcpy(p, padded.data(), bytes, hipMemcpyHostToDevice));
+    } else if (!h.empty()) {
+      HIP_OK(hipMemcpy(p, h.data(), bytes, hipMemcpyHostToDevice));
+    }
+    // many callers hand over temporaries: make sure the copy has really consumed the host buffer
+    HIP_OK(hipStreamSynchronize(nullptr));
   }
   void release() {
     if (p && owner) (void)hipFree(p);
@@ -728,6 +738,7 @@ class Engine : public EngineBase {
   void upload_matrix(const Csr<T> &C) {
     HIP_OK(hipSetDevice(device));
     A.upload(C, nullptr);
+    HIP_OK(hipDeviceSynchronize());
     has_A = true;
   }
 
@@ -764,11 +775,13 @@ class Engine : public EngineBase {
     const size_t nb = M.band_wg_ptr.size() - 1;
     for (size_t b = 0; b < nb; ++b) {
       const int32_t g0 = M.band_wg_ptr[b], g1 = M.band_wg_ptr[b + 1];
-      if (M.band_prefix[b]) {
+      // the kernel that touches a U row first starts it from w[i] / d[i] (the L kernels no longer write v)
+      const int pre = M.band_prefix[b] ? 1 : 0;
+      if (pre) {
         const int64_t s0 = M.band_slot_ptr[b], s1 = M.band_slot_ptr[b + 1];
         hipLaunchKernelGGL((k_trsv_wide<D, LOWER, true>), dim3(grid_for(s1 - s0, logR)), dim3(256), 0, st, s0, s1,
                            M.ptr.as<int32_t>(), M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(),
-                           M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR);
+                           M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR, 1);
         ++count;
       }
       if (M.band_dense[b]) {  // block by block: sparse update, then ONE dense product per block
@@ -779,7 +792,7 @@ class Engine : public EngineBase {
       hipLaunchKernelGGL((k_trsv_band<D, LOWER>), dim3((unsigned)(g1 - g0)), dim3(1024), 0, st, g0,
                          M.wg_grp_ptr.as<int32_t>(), M.grp_slot_ptr.as<int32_t>(), M.ptr.as<int32_t>(),
                          M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(), M.srcslot.as<int32_t>(),
-                         M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR, errflag.as<unsigned>());
+                         M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR, errflag.as<unsigned>(), pre ? 0 : 1);
       ++count;
     }
   }
@@ -1594,6 +1607,31 @@ class Engine : public EngineBase {
     }
   }
 
+  // development aid: one checksum per device-resident array (order documented in tests), to tell which
+  // upload differs when two handles built from the same hierarchy disagree
+  static uint64_t cksum(const DevBuf &b) {
+    if (!b.p || !b.bytes) return 0;
+    std::vector<unsigned char> h(b.bytes);
+    if (hipMemcpy(h.data(), b.p, b.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ~0ull;
+    uint64_t s = 1469598103934665603ull;
+    for (unsigned char c : h) s = (s ^ c) * 1099511628211ull;
+    return s;
+  }
+  int debug_checksums(uint64_t *out, int cap) const {
+    std::vector<uint64_t> v;
+    for (const auto &Lp : lv) {
+      const DevLevel &L = *Lp;
+      for (const DevCsr *M : {&L.L, &L.U, &L.E, &L.F})
+        for (const DevBuf *b : {&M->ptr, &M->col, &M->val, &M->rowid, &M->srcslot, &M->split, &M->wg_grp_ptr, &M->grp_slot_ptr, &M->tinv})
+          v.push_back(cksum(*b));
+      for (const DevBuf *b : {&L.d, &L.s, &L.t, &L.p, &L.qinv}) v.push_back(cksum(*b));
+    }
+    for (const DevBuf *b : {&dn.QH, &dn.Rinv, &dn.jpvt0}) v.push_back(cksum(*b));
+    v.push_back((uint64_t)dn.rank);
+    for (int i = 0; i < cap && i < (int)v.size(); ++i) out[i] = v[(size_t)i];
+    return (int)v.size();
+  }
+
   // operator selection of lhf?Apply (libhifir.cpp:447-472): S on this engine, SH on the adjoint one
   Engine<T> &for_op(int op) {
     if (op == HIFAMD_S || op == HIFAMD_M) return *this;
@@ -1790,8 +1828,7 @@ const unsigned pairs = (g + 1) / 2;
 #define HIFAMD_BLOCK_GEMM(NW)                                                                                   \
   hipLaunchKernelGGL(k_tri_gemm_d<NW>, dim3(pairs, ((1u << logR) + 15) / 16), dim3(NW * 64), 0, st, nb,         \
                      M.tinv.as<double>() + M.blk_inv_off[(size_t)q], (int)round_up32(nb), (const double *)tb,    \
-                     logR, M.rowid.as<int32_t>() + r0, x, LOWER ? L.d.as<double>() : (const double *)nullptr,    \
-                     LOWER ? L.v.as<double>() : (double *)nullptr)
+                     logR, M.rowid.as<int32_t>() + r0, x, (const double *)nullptr, (double *)nullptr)
   if (gemm_waves >= 16) {
     HIFAMD_BLOCK_GEMM(16);
   } else if (gemm_waves >= 8) {
@@ -1815,7 +1852,7 @@ void Engine<zdouble>::launch_dense_block(hipStream_t st, const DevLevel &L, cons
                      M.rowid.as<int32_t>(), (const cplx *)x, tb, logR);
   ++count;
   zgemm_tri(st, nb, M.tinv.as<double>() + M.blk_inv_off[(size_t)q], (const cplx *)tb, logR, M.rowid.as<int32_t>() + r0, x,
-            LOWER ? L.d.as<cplx>() : (const cplx *)nullptr, LOWER ? L.v.as<cplx>() : (cplx *)nullptr, count);
+            (const cplx *)nullptr, (cplx *)nullptr, count);
 }
 
 }  // namespace hifamd
@@ -1991,6 +2028,11 @@ HifAmdStatus hifamd_set_nsp_const(HifAmdHdl h, HifAmdOp op, int64_t start, int64
     E.nsp_on = on, E.nsp_r0 = start, E.nsp_r1 = end;
   }
   API_END
+}
+
+int hifamd_debug_checksums(HifAmdHdl h, uint64_t *out, int cap) {
+  if (!h || !h->eng) return -1;
+  return h->vt == HIFAMD_D ? ENG_D->debug_checksums(out, cap) : ENG_Z->debug_checksums(out, cap);
 }
 
 static const char kFileMagic[8] = {'H', 'I', 'F', 'A', 'M', 'D', '1', 0};

@@ -12,14 +12,49 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <thread>
+#include <mutex>
 #include <cstring>
-#include <omp.h>
 #include <limits>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
 namespace hifamd {
+
+// Host-side parallel loop on plain std::thread (dynamic chunks off an atomic counter).  Deliberately NOT
+// OpenMP: the library lives in processes that already carry an OpenMP runtime of their own (PyTorch / MKL),
+// and a second runtime in the same address space corrupted host memory intermittently (seen as two
+// overwritten row pointers right after the dense factorization).  f(begin, end) handles [begin, end).
+template <class F>
+inline void parallel_for(int64_t n, int64_t chunk, F f) {
+  if (n <= 0) return;
+  if (chunk < 1) chunk = 1;
+  unsigned hw = std::thread::hardware_concurrency();
+  if (hw == 0) hw = 4;
+  if (const char *e = std::getenv("HIFIR_AMD_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));
+  const int64_t nchunks = (n + chunk - 1) / chunk;
+  const unsigned nt = (unsigned)std::min<int64_t>(hw, nchunks);
+  if (nt <= 1) {
+    f((int64_t)0, n);
+    return;
+  }
+  std::atomic<int64_t> next(0);
+  auto worker = [&]() {
+    for (;;) {
+      const int64_t c = next.fetch_add(1);
+      if (c >= nchunks) break;
+      f(c * chunk, std::min(n, (c + 1) * chunk));
+    }
+  };
+  std::vector<std::thread> pool;
+  pool.reserve(nt - 1);
+  for (unsigned t = 1; t < nt; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto &th : pool) th.join();
+}
+
 
 typedef std::complex<double> zdouble;
 
@@ -501,11 +536,12 @@ double build_dense_block(const BandPlan &P, const Csr<T> &A, size_t q, double *o
   // contiguous SIMD axpy; chunks are independent (one per thread).  y[q][j] is zero for q < c0 + j, hence
   // no per-column test is needed beyond q >= c0.
   constexpr int32_t CB = 16;
-#pragma omp parallel reduction(max : growth)
-  {
+  std::mutex gmx;
+  parallel_for((nb + CB - 1) / CB, 1, [&](int64_t cb0, int64_t cb1) {
     std::vector<T> Yc((size_t)nb * CB);
-#pragma omp for schedule(dynamic, 1)
-    for (int32_t c0 = 0; c0 < nb; c0 += CB) {
+    double g = 1.0;
+    for (int64_t cb = cb0; cb < cb1; ++cb) {
+      const int32_t c0 = (int32_t)cb * CB;
       const int32_t cw = std::min<int32_t>(CB, nb - c0);
       std::fill(Yc.begin() + (size_t)c0 * CB, Yc.end(), T(0));
       for (int32_t j = 0; j < cw; ++j) Yc[(size_t)(c0 + j) * CB + j] = T(1);
@@ -524,11 +560,13 @@ double build_dense_block(const BandPlan &P, const Csr<T> &A, size_t q, double *o
         for (int32_t j = 0; j < cw && c0 + j <= r; ++j) {
           const T val = Yc[(size_t)r * CB + j];
           put_operand(ops, plane, base + (int64_t)j * 16, val);
-          growth = std::max(growth, abs_(val));
+          g = std::max(g, abs_(val));
         }
       }
     }
-  }
+    std::lock_guard<std::mutex> lk(gmx);
+    growth = std::max(growth, g);
+  });
   return growth;
 }
 
@@ -815,41 +853,43 @@ template <class T>
 void dense_explicit_ops(HostDense<T> &D) {
   const int64_t n = D.n;
   const T *A = D.qr.data();
-  // explicit Q^H: start from I and apply H(0)^H, H(1)^H, ... to its columns (Q^H = H(n-1)^H...H(0)^H)
+  // explicit Q^H: start from I and apply H(0)^H, H(1)^H, ... to its columns (Q^H = H(n-1)^H...H(0)^H);
+  // the columns are independent of each other
   D.QH.assign((size_t)(n * n), T(0));
   for (int64_t j = 0; j < n; ++j) D.QH[(size_t)(j + j * n)] = T(1);
-  for (int64_t i = 0; i < n; ++i) {
-    const T ctau = conj_(D.tau[(size_t)i]);
-    if (ctau == T(0)) continue;
-    const T *v = A + i + i * n;  // v[0] is implicit 1
-#pragma omp parallel for schedule(static)
-    for (int64_t j = 0; j < n; ++j) {
-      T *c = &D.QH[(size_t)(i + j * n)];
-      T dot = c[0];
-      for (int64_t r = 1; r < n - i; ++r) dot += conj_(v[r]) * c[r];
-      dot *= ctau;
-      c[0] -= dot;
-      for (int64_t r = 1; r < n - i; ++r) c[r] -= v[r] * dot;
-    }
-  }
+  parallel_for(n, 8, [&](int64_t j0, int64_t j1) {
+    for (int64_t j = j0; j < j1; ++j)
+      for (int64_t i = 0; i < n; ++i) {
+        const T ctau = conj_(D.tau[(size_t)i]);
+        if (ctau == T(0)) continue;
+        const T *v = A + i + i * n;  // v[0] is implicit 1
+        T *c = &D.QH[(size_t)(i + j * n)];
+        T dot = c[0];
+        for (int64_t r = 1; r < n - i; ++r) dot += conj_(v[r]) * c[r];
+        dot *= ctau;
+        c[0] -= dot;
+        for (int64_t r = 1; r < n - i; ++r) c[r] -= v[r] * dot;
+      }
+  });
   // explicit R^{-1} (upper triangular), column by column: R X = I  =>  back substitution
   D.Rinv.assign((size_t)(n * n), T(0));
-#pragma omp parallel for schedule(dynamic, 8)
-  for (int64_t j = 0; j < n; ++j) {
-    T *x = &D.Rinv[(size_t)(j * n)];
-    x[j] = T(1);
-    for (int64_t k = j; k >= 0; --k) {  // column-oriented sweep: contiguous reads of R(:,k)
-      const T rkk = A[k + k * n];
-      if (rkk == T(0)) {  // exactly singular pivot: such columns lie beyond any usable rank
-        for (int64_t i = 0; i <= j; ++i) x[i] = T(0);
-        break;
+  parallel_for(n, 8, [&](int64_t j0, int64_t j1) {
+    for (int64_t j = j0; j < j1; ++j) {
+      T *x = &D.Rinv[(size_t)(j * n)];
+      x[j] = T(1);
+      for (int64_t k = j; k >= 0; --k) {  // column-oriented sweep: contiguous reads of R(:,k)
+        const T rkk = A[k + k * n];
+        if (rkk == T(0)) {  // exactly singular pivot: such columns lie beyond any usable rank
+          for (int64_t i = 0; i <= j; ++i) x[i] = T(0);
+          break;
+        }
+        x[k] /= rkk;
+        const T xk = x[k];
+        const T *rk = A + k * n;
+        for (int64_t i = 0; i < k; ++i) x[i] -= rk[i] * xk;
       }
-      x[k] /= rkk;
-      const T xk = x[k];
-      const T *rk = A + k * n;
-      for (int64_t i = 0; i < k; ++i) x[i] -= rk[i] * xk;
     }
-  }
+  });
 }
 
 // adjoint operators: conjugate transposes of the two explicit factors

@@ -148,8 +148,8 @@ __global__ void __launch_bounds__(256) k_scatter_scale(const T *__restrict__ v,
 }
 
 // ---------------------------------------------------------------------------------------------
-// one row of a triangular solve.  LOWER: acc = w[i] - sum_asc L(i,j) w[j]; w[i] = acc; v[i] = acc/d[i]
-//                                 UPPER: acc = v[i] - sum_desc U(i,j) v[j]; v[i] = acc
+// one row of a triangular solve.  LOWER: acc = w[i] - sum_asc L(i,j) w[j]; w[i] = acc
+//                                 UPPER: acc = w[i]/d[i] (first touch) or v[i]; acc -= sum_desc U(i,j) v[j]; v[i] = acc
 // (the CSR row already lists its columns in the order the reference's column sweep meets them)
 // ---------------------------------------------------------------------------------------------
 template <class T, bool LOWER, bool PREFIX>
@@ -157,11 +157,12 @@ __device__ __forceinline__ void trsv_row(int64_t slot, const int32_t *__restrict
                                          const int32_t *__restrict__ split,
                                          const int32_t *__restrict__ col, const T *__restrict__ val,
                                          const int32_t *__restrict__ rowid, const T *__restrict__ d,
-                                         T *w, T *v, int logR, int c) {
+                                         T *w, T *v, int logR, int c, bool first_u) {
   const int64_t i = rowid[slot];
   const int32_t k0 = ptr[slot], k1 = PREFIX ? split[slot] : ptr[slot + 1];
   T *x = LOWER ? w : v;
-  T acc = x[(i << logR) + c];
+  // U's right-hand side is D^{-1} (L^{-1} w): the kernel that touches a U row FIRST divides (prec_solve.hpp:219)
+  T acc = (!LOWER && first_u) ? vdiv(w[(i << logR) + c], d[i]) : x[(i << logR) + c];
   int32_t k = k0;
   for (; k + 4 <= k1; k += 4) {  // 4 independent gathers in flight, accumulated in order
     const int32_t j0 = col[k], j1 = col[k + 1], j2 = col[k + 2], j3 = col[k + 3];
@@ -175,7 +176,6 @@ __device__ __forceinline__ void trsv_row(int64_t slot, const int32_t *__restrict
   }
   for (; k < k1; ++k) acc = vsub(acc, vmul(val[k], x[((int64_t)col[k] << logR) + c]));
   x[(i << logR) + c] = acc;
-  if (LOWER && !PREFIX) v[(i << logR) + c] = vdiv(acc, d[i]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -186,7 +186,7 @@ __device__ __forceinline__ void trsv_row(int64_t slot, const int32_t *__restrict
 // its right-hand side and pivot) is always in flight while the current one is consumed, and the
 // row headers run two rows ahead on the scalar unit.  Gathers go out eight 512-byte rows at a time;
 // accumulation stays in the reference's order.  In place: x[i] holds the rhs on entry and the
-// solution on exit; LOWER additionally writes out2[i] = x[i] / d[i] (off the critical path).
+// solution on exit.  UPPER rows start from rhs_u[i] / d[i] when this kernel is the first to touch them (first_u).
 //   MODE 0: all dependencies were finished by earlier launches                   (k_trsv_wide)
 //   MODE 2: dependencies with srcslot >= slot0 are acquired through LDS flags     (k_trsv_tail)
 // ---------------------------------------------------------------------------------------------
@@ -207,8 +207,8 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
                                                 const int32_t *__restrict__ col,
                                                 const T *__restrict__ val, const int32_t *__restrict__ srcslot,
                                                 const int32_t *__restrict__ rowid, const T *__restrict__ d, T *x,
-                                                T *__restrict__ out2, int lane, int *flag, int32_t slot0,
-                                                unsigned *errflag) {
+                                                const T *__restrict__ rhs_u, int lane, int *flag, int32_t slot0,
+                                                unsigned *errflag, bool first_u) {
   int32_t s = rfl(s_first);
   if (s >= s_end) return true;
   // nonzero range of a row: the whole row, its PREFIX [ptr, split) (dependencies finished before the
@@ -234,9 +234,9 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
       if (MODE == 2) ssv = srcslot[kk];
     }
   }
-  T acc = x[((int64_t)i_c << 6) + lane];
-  T dd = vzero(T());
-  if (LOWER && !PREFIX) dd = d[i_c];
+  // U rows start from D^{-1} times the L solution (rhs_u = w) when this kernel is the first to touch them
+  const bool div_u = !LOWER && first_u;
+  T acc = div_u ? vdiv(rhs_u[((int64_t)i_c << 6) + lane], d[i_c]) : x[((int64_t)i_c << 6) + lane];
   // head of the wave's next row: its first item, right-hand side, pivot, and the header two rows
   // ahead.  MODE 0 issues it while the current row is consumed; MODE 2 only AFTER the current row's
   // flag is up, because a workgroup-scope release waits for every outstanding vector-memory
@@ -249,8 +249,7 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
       valv2 = val[kk_];                                     \
       if (MODE == 2) ssv2 = srcslot[kk_];                   \
     }                                                       \
-    acc2 = x[((int64_t)i_n << 6) + lane];                   \
-    if (LOWER && !PREFIX) dd2 = d[i_n];                     \
+    acc2 = div_u ? vdiv(rhs_u[((int64_t)i_n << 6) + lane], d[i_n]) : x[((int64_t)i_n << 6) + lane]; \
     s_nn = s_n + stride;                                    \
     has_nn = s_nn < s_end;                                  \
     if (has_nn) {                                           \
@@ -264,7 +263,7 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
     const bool row_done = (k_c + 64 >= e_c);
     // ---- prefetch the next item (and, at a row end, the header two rows ahead)
     int32_t colv2 = 0, ssv2 = 0;
-    T valv2 = vzero(T()), acc2 = vzero(T()), dd2 = vzero(T());
+    T valv2 = vzero(T()), acc2 = vzero(T());
     int32_t s_nn = 0, i_nn = 0, k_nn = 0, e_nn = 0;
     bool has_nn = false;
     if (!row_done) {
@@ -323,7 +322,6 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
       if (MODE == 2) {  // release: the row's stores (all 64 lanes) are complete before its flag goes up
         if (lane == 0) __hip_atomic_store(&flag[s - slot0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      if (LOWER && !PREFIX) out2[((int64_t)i_c << 6) + lane] = vdiv(acc, dd);
       if (!has_n) break;
       if (MODE == 2) HIFAMD_PREFETCH_NEXT_ROW();
       s = s_n;
@@ -331,7 +329,6 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
       k_c = k_n;
       e_c = e_n;
       acc = acc2;
-      dd = dd2;
       s_n = s_nn;
       has_n = has_nn;
       i_n = i_nn;
@@ -354,17 +351,18 @@ __global__ void __launch_bounds__(256) k_trsv_wide(int64_t s0, int64_t s1, const
                                                    const int32_t *__restrict__ col,
                                                    const T *__restrict__ val,
                                                    const int32_t *__restrict__ rowid,
-                                                   const T *__restrict__ d, T *w, T *v, int logR) {
+                                                   const T *__restrict__ d, T *w, T *v, int logR, int first_u) {
   const LaneMap lm = lane_map(logR);
   const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   if (logR == 6) {
     trsv_stream_r64<T, 0, LOWER, PREFIX>((int32_t)(s0 + wave), (int32_t)s1, (int32_t)nwaves, ptr, split, col, val,
-                                         nullptr, rowid, d, LOWER ? w : v, v, threadIdx.x & 63, nullptr, 0, nullptr);
+                                         nullptr, rowid, d, LOWER ? w : v, w, threadIdx.x & 63, nullptr, 0, nullptr,
+                                         first_u != 0);
     return;
   }
   for (int64_t slot = s0 + wave * lm.G + lm.g; slot < s1; slot += nwaves * lm.G)
-    trsv_row<T, LOWER, PREFIX>(slot, ptr, split, col, val, rowid, d, w, v, logR, lm.c);
+    trsv_row<T, LOWER, PREFIX>(slot, ptr, split, col, val, rowid, d, w, v, logR, lm.c, first_u != 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -389,7 +387,7 @@ __global__ void __launch_bounds__(1024) k_trsv_band(int32_t wg0, const int32_t *
                                                     const int32_t *__restrict__ col, const T *__restrict__ val,
                                                     const int32_t *__restrict__ srcslot,
                                                     const int32_t *__restrict__ rowid, const T *__restrict__ d,
-                                                    T *w, T *v, int logR, unsigned *errflag) {
+                                                    T *w, T *v, int logR, unsigned *errflag, int first_u) {
   __shared__ int flag[HIFAMD_TAIL_MAX];
   const LaneMap lm = lane_map(logR);
   const int lane = threadIdx.x & 63;
@@ -401,8 +399,8 @@ __global__ void __launch_bounds__(1024) k_trsv_band(int32_t wg0, const int32_t *
   __syncthreads();
   T *x = LOWER ? w : v;
   if (logR == 6) {
-    trsv_stream_r64<T, 2, LOWER, false>(slot0 + wave, slot1, nw, ptr, split, col, val, srcslot, rowid, d, x, v, lane,
-                                        flag, slot0, errflag);
+    trsv_stream_r64<T, 2, LOWER, false>(slot0 + wave, slot1, nw, ptr, split, col, val, srcslot, rowid, d, x, w, lane,
+                                        flag, slot0, errflag, first_u != 0);
     return;
   }
   for (int32_t wf = wf0; wf < wf1; ++wf) {
@@ -417,7 +415,7 @@ __global__ void __launch_bounds__(1024) k_trsv_band(int32_t wg0, const int32_t *
         i = rowid[slot];
         k = split[slot];  // [ptr, split) was folded in by the prefix pass
         k1 = ptr[slot + 1];
-        acc = x[(i << logR) + lm.c];
+        acc = (!LOWER && first_u) ? vdiv(w[(i << logR) + lm.c], d[i]) : x[(i << logR) + lm.c];
       }
       while (__any(k < k1)) {
         const int nb = min(4, k1 - k);
@@ -458,7 +456,6 @@ __global__ void __launch_bounds__(1024) k_trsv_band(int32_t wg0, const int32_t *
       }
       if (active) {
         x[(i << logR) + lm.c] = acc;
-        if (LOWER) v[(i << logR) + lm.c] = vdiv(acc, d[i]);
       }
       // release: every lane's stores are complete before the row's flag goes up
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

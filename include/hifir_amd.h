@@ -192,6 +192,9 @@ HifAmdStatus hifamd_gmres_batch_dev(HifAmdHdl h, const void *dB, int64_t ldb, vo
 HifAmdStatus hifamd_time_apply(HifAmdHdl h, const void *dB, int64_t ldb, void *dX, int64_t ldx,
                                int64_t nrhs, int64_t rank, int warmup, int reps, double *ms_avg);
 HifAmdStatus hifamd_sync(HifAmdHdl h);
+/* development aid: checksums of the device-resident arrays of a finalized handle (per level: the nine
+ * arrays of L, U, E, F, then d, s, t, p, q_inv; finally Q^H, R^{-1}, jpvt and the rank); returns how many */
+int hifamd_debug_checksums(HifAmdHdl h, uint64_t *out, int cap);
 
 #ifdef __cplusplus
 }

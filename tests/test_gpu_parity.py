@@ -3,6 +3,8 @@ the C restatement pinned to the real reference) and against the committed golden
 
 Bars: sparse stages bit-exact (real, no dense level); dense level and complex within 1e-12
 (relative, infinity norm) -- BASELINE.json north_star "residual within 1e-12 of CPU reference"."""
+import os
+
 import numpy as np
 import pytest
 
@@ -231,8 +233,14 @@ def test_saved_hierarchy_applies_identically(cache, name, tmp_path):
     path = str(tmp_path / "h.hifamd")
     M.save(path)
     M2 = hifir_amd.HIF.load(path, max_nrhs=64)
+    # (the per-array device checksums told an intermittent mismatch apart: a second OpenMP runtime in the
+    #  process corrupted host memory during the dense factorization -- the library is OpenMP-free since)
+    ck = lambda H: (lambda o: o[:hifir_amd.lib().hifamd_debug_checksums(H._h, o.ctypes.data, 256)])(np.zeros(256, np.uint64))
+    M3 = hifir_amd.HIF.load(path, max_nrhs=64)
+    assert np.array_equal(ck(M2), ck(M3))
     for tr in (False, True):
-        assert np.array_equal(M2.solve_mrhs(d["B4"], trans=tr), M.solve_mrhs(d["B4"], trans=tr))
+        X2, X1 = M2.solve_mrhs(d["B4"], trans=tr), M.solve_mrhs(d["B4"], trans=tr)
+        assert np.array_equal(X2, X1), (tr, relerr(X2, d["XT4"] if tr else d["X4"]))
     assert np.array_equal(M2.mmultiply(d["x"]), M.mmultiply(d["x"]))
 
 
