@@ -122,10 +122,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and os.environ.get("OMP_NUM_THREADS", "1") == "1":
-        # every rank analyses the (replicated) hierarchy on the host with OpenMP: share the cores
-        # (torch.distributed.run pins OMP_NUM_THREADS=1 by default, which would serialise that analysis)
-        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 8) // world))
+    if world > 1 and "HIFIR_AMD_THREADS" not in os.environ:
+        # every rank analyses the (replicated) hierarchy on the host (std::thread pool of the library): share the cores
+        os.environ["HIFIR_AMD_THREADS"] = str(max(1, (os.cpu_count() or 8) // world))
     import torch
     import torch.distributed as dist
 
