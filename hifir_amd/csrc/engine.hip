@@ -53,6 +53,40 @@ static int env_int(const char *name, int dflt) {
 }
 
 // -------------------------------------------------------------------------------------------
+// Transfers never touch the legacy default stream: while ANOTHER host thread captures a graph on its
+// handle's stream, ROCm rejects any legacy-stream operation in the process ("would make the legacy
+// stream depend on a capturing blocking stream"), and handles are meant to be usable from distinct
+// threads.  One non-blocking transfer stream per device, always synchronised before returning.
+// -------------------------------------------------------------------------------------------
+static hipStream_t xfer_stream() {
+  static std::mutex mx;
+  static hipStream_t s[64] = {};
+  int d = 0;
+  HIP_OK(hipGetDevice(&d));
+  std::lock_guard<std::mutex> lk(mx);
+  if (!s[d & 63]) HIP_OK(hipStreamCreateWithFlags(&s[d & 63], hipStreamNonBlocking));
+  return s[d & 63];
+}
+static void copy_h2d(void *dst, const void *src, size_t n) {
+  if (!n) return;
+  hipStream_t xs = xfer_stream();
+  HIP_OK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, xs));
+  HIP_OK(hipStreamSynchronize(xs));
+}
+static void copy_d2h(void *dst, const void *src, size_t n) {
+  if (!n) return;
+  hipStream_t xs = xfer_stream();
+  HIP_OK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, xs));
+  HIP_OK(hipStreamSynchronize(xs));
+}
+static void zero_dev(void *p, size_t n) {
+  if (!n) return;
+  hipStream_t xs = xfer_stream();
+  HIP_OK(hipMemsetAsync(p, 0, n, xs));
+  HIP_OK(hipStreamSynchronize(xs));
+}
+
+// -------------------------------------------------------------------------------------------
 // device containers
 // -------------------------------------------------------------------------------------------
 struct DevBuf {
@@ -79,12 +113,10 @@ struct DevBuf {
       std::vector<V> padded(h.size() + pad_elems);
       std::copy(h.begin(), h.end(), padded.begin());
       std::fill(padded.begin() + (std::ptrdiff_t)h.size(), padded.end(), V());
-      HIP_OK(hipMemcpy(p, padded.data(), bytes, hipMemcpyHostToDevice));
+      copy_h2d(p, padded.data(), bytes);
     } else if (!h.empty()) {
-      HIP_OK(hipMemcpy(p, h.data(), bytes, hipMemcpyHostToDevice));
+      copy_h2d(p, h.data(), bytes);
     }
-    // many callers hand over temporaries: make sure the copy has really consumed the host buffer
-    HIP_OK(hipStreamSynchronize(nullptr));
   }
   void release() {
     if (p && owner) (void)hipFree(p);
@@ -498,8 +530,8 @@ class Engine : public EngineBase {
         L.qinv.alias(Pl->qinv);
         L.w.alloc(Pl->w.bytes);
         L.v.alloc(Pl->v.bytes);
-        if (L.w.bytes) HIP_OK(hipMemset(L.w.p, 0, L.w.bytes));
-        if (L.v.bytes) HIP_OK(hipMemset(L.v.p, 0, L.v.bytes));
+        if (L.w.bytes) zero_dev(L.w.p, L.w.bytes);
+        if (L.v.bytes) zero_dev(L.v.p, L.v.bytes);
         E->lv.push_back(std::move(Lp));
       }
       E->dn.n = dn.n;
@@ -512,10 +544,10 @@ class Engine : public EngineBase {
       if (dn.tmp.bytes) E->dn.tmp.alloc(dn.tmp.bytes);
       if (dn.tmp2.bytes) E->dn.tmp2.alloc(dn.tmp2.bytes);
       E->errflag.alloc(sizeof(unsigned));
-      HIP_OK(hipMemset(E->errflag.p, 0, E->errflag.bytes));
+      zero_dev(E->errflag.p, E->errflag.bytes);
       if (blk_tmp.bytes) {
         E->blk_tmp.alloc(blk_tmp.bytes);
-        HIP_OK(hipMemset(E->blk_tmp.p, 0, E->blk_tmp.bytes));
+        zero_dev(E->blk_tmp.p, E->blk_tmp.bytes);
       }
       if (zt1.bytes) {
         E->zt1.alloc(zt1.bytes);
@@ -524,7 +556,7 @@ class Engine : public EngineBase {
       hipEvent_t ej = nullptr;
       HIP_OK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
       ev_join.push_back(ej);
-      HIP_OK(hipDeviceSynchronize());
+      HIP_OK(hipStreamSynchronize(stream));  // (transfers were synchronous on the transfer stream)
       E->finalized = true;
       twins.push_back(std::move(E));
     }
@@ -547,7 +579,7 @@ class Engine : public EngineBase {
     dn.Qm.alias(P.dn.Qm);
     dn.Rm.alias(P.dn.Rm);
     if (P.dn.tmp2.bytes && !dn.tmp2.bytes) dn.tmp2.alloc(P.dn.tmp2.bytes);
-    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipStreamSynchronize(stream));  // (transfers were synchronous on the transfer stream)
     prod_ready = true;
   }
 
@@ -647,8 +679,8 @@ class Engine : public EngineBase {
       L.qinv.upload(H.q_inv);
       L.w.alloc((size_t)H.n * Rmax * sizeof(T));
       L.v.alloc((size_t)H.n * Rmax * sizeof(T));
-      HIP_OK(hipMemset(L.w.p, 0, L.w.bytes));
-      HIP_OK(hipMemset(L.v.p, 0, L.v.bytes));
+      zero_dev(L.w.p, L.w.bytes);
+      zero_dev(L.v.p, L.v.bytes);
 
       lv.push_back(std::move(Lp));
     }
@@ -673,7 +705,7 @@ class Engine : public EngineBase {
       std::vector<T>().swap(host.dense.Rinv);
     }
     errflag.alloc(sizeof(unsigned));
-    HIP_OK(hipMemset(errflag.p, 0, errflag.bytes));
+    zero_dev(errflag.p, errflag.bytes);
     if (sizeof(T) != sizeof(double)) {
       const size_t rows = (size_t)std::max<int64_t>(band_opt.dense_block + 32, host.has_dense ? host.dense.n + 32 : 0);
       zt1.alloc(rows * (size_t)Rmax * 2 * sizeof(double));
@@ -681,13 +713,14 @@ class Engine : public EngineBase {
     }
     {
       const int remap = env_int("HIFIR_AMD_XCD", 1);
-      HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_xcd_remap), &remap, sizeof(int)));
+      HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_xcd_remap), &remap, sizeof(int), 0, hipMemcpyHostToDevice, xfer_stream()));
+      HIP_OK(hipStreamSynchronize(xfer_stream()));
     }
     if (band_opt.dense_block > 0) {  // +32 rows: the MFMA kernel reads whole 32-k operand sets (masked)
       blk_tmp.alloc((size_t)(band_opt.dense_block + 32) * Rmax * sizeof(T));
-      HIP_OK(hipMemset(blk_tmp.p, 0, blk_tmp.bytes));
+      zero_dev(blk_tmp.p, blk_tmp.bytes);
     }
-    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipStreamSynchronize(stream));  // (transfers were synchronous on the transfer stream)
     for (int k = 0; k < 2; ++k) {  // the staging buffers of the block inverses are not needed any more
       if (pin[k]) (void)hipHostFree(pin[k]);
       if (pin_done[k]) (void)hipEventDestroy(pin_done[k]);
@@ -702,9 +735,9 @@ class Engine : public EngineBase {
     if (adj) adj->check_device_error();
     for (auto &tw : twins) tw->check_device_error();
     unsigned e = 0;
-    HIP_OK(hipMemcpy(&e, errflag.p, sizeof(e), hipMemcpyDeviceToHost));
+    copy_d2h(&e, errflag.p, sizeof(e));
     if (e) {
-      HIP_OK(hipMemset(errflag.p, 0, sizeof(e)));
+      zero_dev(errflag.p, sizeof(e));
       throw Error(HIFAMD_HIFIR_ERROR, "a triangular-solve workgroup timed out waiting for a dependency (device fault)");
     }
   }
@@ -738,7 +771,7 @@ class Engine : public EngineBase {
   void upload_matrix(const Csr<T> &C) {
     HIP_OK(hipSetDevice(device));
     A.upload(C, nullptr);
-    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipStreamSynchronize(stream));  // (transfers were synchronous on the transfer stream)
     has_A = true;
   }
 
@@ -937,7 +970,7 @@ class Engine : public EngineBase {
       std::vector<T>().swap(Dn.Q);
       std::vector<T>().swap(Dn.RinvH);
     }
-    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipStreamSynchronize(stream));  // (transfers were synchronous on the transfer stream)
     prod_ready = true;
   }
 
@@ -1612,7 +1645,7 @@ class Engine : public EngineBase {
   static uint64_t cksum(const DevBuf &b) {
     if (!b.p || !b.bytes) return 0;
     std::vector<unsigned char> h(b.bytes);
-    if (hipMemcpy(h.data(), b.p, b.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ~0ull;
+    copy_d2h(h.data(), b.p, b.bytes);
     uint64_t s = 1469598103934665603ull;
     for (unsigned char c : h) s = (s ^ c) * 1099511628211ull;
     return s;

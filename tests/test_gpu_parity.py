@@ -244,6 +244,34 @@ def test_saved_hierarchy_applies_identically(cache, name, tmp_path):
     assert np.array_equal(M2.mmultiply(d["x"]), M.mmultiply(d["x"]))
 
 
+def test_two_handles_from_two_threads(cache):
+    # "distinct handles may be used from distinct threads" (hifir_amd.h conventions, like the reference):
+    # two hierarchies applied concurrently from two host threads (ctypes releases the GIL) keep their results
+    import threading
+
+    la, da, Ma, Oa = _get(cache, "cd2d_48")
+    lb, db, Mb, Ob = _get(cache, "p2d_64_deep")
+    out = {}
+
+    def work(tag, M, d):
+        res = []
+        for k in range(12):
+            res.append(M.solve_mrhs(d["B4"] * (1.0 + k)))
+            res.append(M.solve(d["b"], trans=True))
+        out[tag] = res
+
+    ta = threading.Thread(target=work, args=("a", Ma, da))
+    tb = threading.Thread(target=work, args=("b", Mb, db))
+    ta.start()
+    tb.start()
+    ta.join()
+    tb.join()
+    for tag, d in (("a", da), ("b", db)):
+        for k in range(12):
+            assert relerr(out[tag][2 * k], d["X4"] * (1.0 + k)) <= TOL
+            assert relerr(out[tag][2 * k + 1], d["xt"]) <= TOL
+
+
 def test_spmv_bitwise(cache):
     torch = pytest.importorskip("torch")
     levels, d, M, O = _get(cache, "cd2d_48")
