@@ -42,6 +42,7 @@ SIGNATURES = {
     "hifamd_apply_batch_dev": (_int, [_vp, _int, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
     "hifamd_gmres_batch": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _int, _dbl, _int, _i64, _vp, _vp]),
     "hifamd_gmres_batch_dev": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _int, _dbl, _int, _i64, _vp, _vp]),
+    "hifamd_fgmres_batch": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _int, _dbl, _int, _i64, _vp, _vp, _vp]),
     "hifamd_time_apply": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _int, _int, _vp]),
     "hifamd_sync": (_int, [_vp]),
     "hifamd_debug_checksums": (_int, [_vp, _vp, _int]),

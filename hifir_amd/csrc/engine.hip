@@ -283,7 +283,7 @@ class Engine : public EngineBase {
   bool nsp_on = false;
   int64_t nsp_r0 = 0, nsp_r1 = -1;
   DevBuf nsp_part;
-  DevBuf gm_v, gm_w, gm_Q, gm_alpha;  // GMRES: work vectors, Krylov basis, per-column coefficients
+  DevBuf gm_v, gm_w, gm_Q, gm_Z, gm_alpha;  // GMRES: work vectors, Krylov basis, per-column coefficients
   int64_t ir_cols = 0;
 
   explicit Engine(int dev) : device(dev) {
@@ -1380,14 +1380,18 @@ class Engine : public EngineBase {
   uint64_t gm_slot = 0;
 
   void gmres_tile(const double *dB, int64_t ldb, double *dX, int64_t ldx, int nc, int restart, double rtol, int maxit,
-                  int64_t rank, int *flags, int *iters) {
+                  int64_t rank, int *flags, int *iters, bool flexible, int *sweeps) {
     const int64_t n = lv[0]->n;
     const size_t vec = (size_t)n * nc * sizeof(double);
     if (gm_v.bytes < vec) gm_v.alloc(vec);
     if (gm_w.bytes < vec) gm_w.alloc(vec);
     if (gm_Q.bytes < vec * (size_t)restart) gm_Q.alloc(vec * (size_t)restart);
-    double *v = gm_v.as<double>(), *w = gm_w.as<double>(), *Q = gm_Q.as<double>();
+    // flexible variant (fgmres_hifir, gmres.hpp:127-231): the preconditioned vectors are kept as well
+    if (flexible && gm_Z.bytes < vec * (size_t)restart) gm_Z.alloc(vec * (size_t)restart);
+    double *v = gm_v.as<double>(), *w = gm_w.as<double>(), *Q = gm_Q.as<double>(), *Z = gm_Z.as<double>();
     auto Qk = [&](int k) { return Q + (size_t)k * (size_t)n * nc; };
+    auto Zk = [&](int k) { return Z + (size_t)k * (size_t)n * nc; };
+    std::vector<int> num_mv((size_t)nc, 0);
     std::vector<double> beta0, beta, tmp((size_t)nc), alpha((size_t)nc);
     std::vector<double> y((size_t)nc * (restart + 1)), w2((size_t)nc * restart), R((size_t)nc * restart * restart),
         J((size_t)nc * restart * 2), resid((size_t)nc, 1.0);
@@ -1415,9 +1419,18 @@ class Engine : public EngineBase {
       }
       col_op(1, n, nc, Qk(0), nc, v, nc, alpha.data());  // Q(:,0) = v / beta  (:55)
       int j = 0;
+      const int nirs = 1 << std::min(outer, 20);  // :157
       for (;;) {
         vec_op(1, n, nc, (D *)v, nc, (const D *)Qk(j), nc, nullptr, 0);  // :58
-        solve_dev((const D *)v, nc, (D *)w, nc, nc, rank, nullptr);      // w = M^{-1} v  (:59)
+        if (flexible) {
+          // w = hifir(A, v, 2^outer sweeps)  (:160); kept in Z (:164)
+          hifir_dev((const D *)v, nc, (D *)w, nc, nc, nirs, nullptr, rank < 0 ? -1 : rank, nullptr);
+          vec_op(1, n, nc, (D *)Zk(j), nc, (const D *)w, nc, nullptr, 0);
+          for (int c = 0; c < nc; ++c)
+            if (active[(size_t)c]) num_mv[(size_t)c] += nirs;
+        } else {
+          solve_dev((const D *)v, nc, (D *)w, nc, nc, rank, nullptr);  // w = M^{-1} v  (:59)
+        }
         spmv_dev((const D *)w, nc, (D *)v, nc, nc, nullptr);            // v = A w       (:60)
         for (int k = 0; k <= j; ++k) {                                   // modified Gram-Schmidt (:63-66)
           col_dots(v, nc, Qk(k), nc, n, nc, tmp.data());
@@ -1486,15 +1499,23 @@ class Engine : public EngineBase {
           for (int i = k - 1; i > -1; --i) yc[i] -= t0 * Rc[(size_t)k * restart + i];
         }
       }
-      vec_op(0, n, nc, (D *)v, nc, nullptr, 0, nullptr, 0);  // v = Q y  (:112-116)
-      for (int i = 0; i <= jmax; ++i) {
-        for (int c = 0; c < nc; ++c)
-          alpha[(size_t)c] = (jfin[(size_t)c] >= i) ? y[(size_t)c * (restart + 1) + i] : 0.0;
-        col_op(0, n, nc, v, nc, Qk(i), nc, alpha.data());
+      if (flexible) {  // x += Z y  (:214-218)
+        for (int i = 0; i <= jmax; ++i) {
+          for (int c = 0; c < nc; ++c)
+            alpha[(size_t)c] = (jfin[(size_t)c] >= i) ? y[(size_t)c * (restart + 1) + i] : 0.0;
+          col_op(0, n, nc, dX, ldx, Zk(i), nc, alpha.data());
+        }
+      } else {
+        vec_op(0, n, nc, (D *)v, nc, nullptr, 0, nullptr, 0);  // v = Q y  (:112-116)
+        for (int i = 0; i <= jmax; ++i) {
+          for (int c = 0; c < nc; ++c)
+            alpha[(size_t)c] = (jfin[(size_t)c] >= i) ? y[(size_t)c * (restart + 1) + i] : 0.0;
+          col_op(0, n, nc, v, nc, Qk(i), nc, alpha.data());
+        }
+        solve_dev((const D *)v, nc, (D *)w, nc, nc, rank, nullptr);  // :118
+        for (int c = 0; c < nc; ++c) alpha[(size_t)c] = (jfin[(size_t)c] >= 0) ? 1.0 : 0.0;
+        col_op(0, n, nc, dX, ldx, w, nc, alpha.data());  // x += w  (:119)
       }
-      solve_dev((const D *)v, nc, (D *)w, nc, nc, rank, nullptr);  // :118
-      for (int c = 0; c < nc; ++c) alpha[(size_t)c] = (jfin[(size_t)c] >= 0) ? 1.0 : 0.0;
-      col_op(0, n, nc, dX, ldx, w, nc, alpha.data());  // x += w  (:119)
       for (int c = 0; c < nc; ++c)
         if (jfin[(size_t)c] >= 0 && (resid[(size_t)c] <= rtol || flag[(size_t)c] != 0)) done[(size_t)c] = 1;  // :120
     }
@@ -1503,11 +1524,12 @@ class Engine : public EngineBase {
     for (int c = 0; c < nc; ++c) {
       if (flags) flags[c] = flag[(size_t)c];
       if (iters) iters[c] = iter[(size_t)c];
+      if (sweeps) sweeps[c] = num_mv[(size_t)c];
     }
   }
 
   void gmres_dev(const double *dB, int64_t ldb, double *dX, int64_t ldx, int64_t nrhs, int restart, double rtol,
-                 int maxit, int64_t rank, int *flags, int *iters) {
+                 int maxit, int64_t rank, int *flags, int *iters, bool flexible = false, int *sweeps = nullptr) {
     check_batch(dB, ldb, dX, ldx, nrhs);
     if (!has_A) throw Error(HIFAMD_BAD_PREC, "GMRES needs the matrix (hifamd_set_matrix)");
     if (restart < 1 || maxit < 1 || !(rtol > 0.0)) throw Error(HIFAMD_MISMATCHED_SIZES, "need restart >= 1, maxit >= 1, rtol > 0");
@@ -1515,12 +1537,12 @@ class Engine : public EngineBase {
     for (int64_t c0 = 0; c0 < nrhs; c0 += 64) {
       const int nc = (int)std::min<int64_t>(64, nrhs - c0);
       gmres_tile(dB + c0, ldb, dX + c0, ldx, nc, restart, rtol, maxit, rank, flags ? flags + c0 : nullptr,
-                 iters ? iters + c0 : nullptr);
+                 iters ? iters + c0 : nullptr, flexible, sweeps ? sweeps + c0 : nullptr);
     }
   }
 
   void gmres_host(const double *B, int64_t ldb, double *X, int64_t ldx, int64_t nrhs, int restart, double rtol,
-                  int maxit, int64_t rank, int *flags, int *iters) {
+                  int maxit, int64_t rank, int *flags, int *iters, bool flexible = false, int *sweeps = nullptr) {
     check_batch(B, ldb, X, ldx, nrhs);
     HIP_OK(hipSetDevice(device));
     const int64_t n = lv[0]->n;
@@ -1529,7 +1551,8 @@ class Engine : public EngineBase {
     if (stage_x.bytes < need) stage_x.alloc(need);
     HIP_OK(hipMemcpy2DAsync(stage_b.p, nrhs * sizeof(double), B, ldb * sizeof(double), nrhs * sizeof(double), n,
                             hipMemcpyHostToDevice, stream));
-    gmres_dev(stage_b.as<double>(), nrhs, stage_x.as<double>(), nrhs, nrhs, restart, rtol, maxit, rank, flags, iters);
+    gmres_dev(stage_b.as<double>(), nrhs, stage_x.as<double>(), nrhs, nrhs, restart, rtol, maxit, rank, flags, iters, flexible,
+              sweeps);
     HIP_OK(hipMemcpy2DAsync(X, ldx * sizeof(double), stage_x.p, nrhs * sizeof(double), nrhs * sizeof(double), n,
                             hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
@@ -2261,6 +2284,14 @@ HifAmdStatus hifamd_gmres_batch_dev(HifAmdHdl h, const void *dB, int64_t ldb, vo
   API_BEGIN
   if (h->vt != HIFAMD_D) throw Error(HIFAMD_HIFIR_ERROR, "the GMRES driver is real-valued (the reference example's inner product is not Hermitian)");
   ENG_D->gmres_dev((const double *)dB, ldb, (double *)dX, ldx, nrhs, restart, rtol, maxit, rank, flags, iters);
+  API_END
+}
+
+HifAmdStatus hifamd_fgmres_batch(HifAmdHdl h, const void *B, int64_t ldb, void *X, int64_t ldx, int64_t nrhs, int restart,
+                                 double rtol, int maxit, int64_t rank, int *flags, int *iters, int *sweeps) {
+  API_BEGIN
+  if (h->vt != HIFAMD_D) throw Error(HIFAMD_HIFIR_ERROR, "the GMRES drivers are real-valued (the reference example's inner product is not Hermitian)");
+  ENG_D->gmres_host((const double *)B, ldb, (double *)X, ldx, nrhs, restart, rtol, maxit, rank, flags, iters, true, sweeps);
   API_END
 }
 

@@ -353,6 +353,19 @@ class HIF:
             return X.reshape(-1), int(fl[0]), int(it[0])
         return X, fl, it
 
+    def fgmres(self, b, restart=30, rtol=1e-6, maxit=500, full_rank=False):
+        """Flexible GMRES with 2^k refinement sweeps as the preconditioner of outer cycle k (the reference's
+        fgmres_hifir, examples/advanced/gmres.hpp:127-231); host arrays.  Returns (x, flags, iters, sweeps)."""
+        vec = (b.ndim == 1)
+        B = np.ascontiguousarray(b, dtype=self.dtype).reshape(b.shape[0], -1)
+        X = np.empty_like(B)
+        fl, it, mv = (np.zeros(B.shape[1], dtype=np.int32) for _ in range(3))
+        _check(lib().hifamd_fgmres_batch(self._h, _p(B), B.shape[1], _p(X), X.shape[1], B.shape[1], int(restart),
+                                        float(rtol), int(maxit), -1 if full_rank else 0, _p(fl), _p(it), _p(mv)))
+        if vec:
+            return X.reshape(-1), int(fl[0]), int(it[0]), int(mv[0])
+        return X, fl, it, mv
+
     def time_apply(self, B, X, rank=0, warmup=2, reps=10):
         """Average device milliseconds of one batched apply, HIP events on the handle's stream."""
         ms = C.c_double()

@@ -186,6 +186,13 @@ HifAmdStatus hifamd_gmres_batch(HifAmdHdl h, const void *B, int64_t ldb, void *X
 HifAmdStatus hifamd_gmres_batch_dev(HifAmdHdl h, const void *dB, int64_t ldb, void *dX, int64_t ldx, int64_t nrhs,
                                     int restart, double rtol, int maxit, int64_t rank, int *flags, int *iters);
 
+/* The flexible variant fgmres_hifir (examples/advanced/gmres.hpp:127-231): the preconditioner of outer cycle
+ * k is iterative refinement with 2^k sweeps (HIF::hifir), the preconditioned basis is kept and x is updated
+ * from it.  sweeps[c] (may be NULL) = refinement sweeps spent on column c (the driver's num_mv). */
+HifAmdStatus hifamd_fgmres_batch(HifAmdHdl h, const void *B, int64_t ldb, void *X, int64_t ldx, int64_t nrhs,
+                                 int restart, double rtol, int maxit, int64_t rank, int *flags, int *iters,
+                                 int *sweeps);
+
 /* ---- instrumentation ---------------------------------------------------------------------- */
 /* Average device time (ms) of the last `hifamd_solve_batch_dev`-shaped graph over `reps` replays,
  * measured with HIP events on the handle's stream (the stream the kernels run on). */

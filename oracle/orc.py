@@ -188,7 +188,14 @@ def qrcp(mat_colmajor, b, op=0, rank=0, rrqr_cond=0.0):
     return x, int(rk[0])
 
 
-def gmres(O, indptr, indices, vals, b, restart=30, rtol=1e-6, maxit=500, full_rank=False):
+def fgmres(O, indptr, indices, vals, b, restart=30, rtol=1e-6, maxit=500, full_rank=False):
+    """fgmres_hifir (examples/advanced/gmres.hpp:127-231): the same loop as gmres_hif, but the preconditioner
+    of outer cycle k is HIF::hifir with 2^k refinement sweeps (:160-162), the preconditioned vectors are
+    kept (Z, :164) and x is updated with Z y directly (:214-218).  Returns (x, flag, iterations, sweeps)."""
+    return gmres(O, indptr, indices, vals, b, restart, rtol, maxit, full_rank, flexible=True)
+
+
+def gmres(O, indptr, indices, vals, b, restart=30, rtol=1e-6, maxit=500, full_rank=False, flexible=False):
     """numpy restatement of the reference's right-preconditioned GMRES driver gmres_hif
     (examples/advanced/gmres.hpp:19-123; real arithmetic) around the oracle's apply `O.solve`:
     x0 = 0, modified Gram-Schmidt, Givens rotations, relative residual |y_{j+1}| / ||b||.
@@ -199,12 +206,13 @@ def gmres(O, indptr, indices, vals, b, restart=30, rtol=1e-6, maxit=500, full_ra
     n = len(b)
     A = sp.csr_matrix((np.asarray(vals, dtype=np.float64), indices, indptr), shape=(n, n))
     rr = -1 if full_rank else 0                                     # :26
-    it, flag = 0, 0
+    it, flag, num_mv = 0, 0, 0
     beta0 = np.linalg.norm(b)                                        # :30
     x = np.zeros(n)
     if beta0 == 0.0:                                                 # :36
-        return x, 0, 0
+        return (x, 0, 0, 0) if flexible else (x, 0, 0)
     Q = np.zeros((n, restart))
+    Z = np.zeros((n, restart)) if flexible else None
     R = np.zeros((restart, restart))
     J = np.zeros((restart, 2))
     y = np.zeros(restart + 1)
@@ -216,8 +224,14 @@ def gmres(O, indptr, indices, vals, b, restart=30, rtol=1e-6, maxit=500, full_ra
         y[0] = beta
         Q[:, 0] = v / beta
         j = 0
+        nirs = 1 << outer                                            # :157
         while True:
-            w = O.solve(Q[:, j].copy(), rank=rr)                     # :59
+            if flexible:
+                w, _ = O.hifir(indptr, indices, vals, Q[:, j].copy(), nirs, None, rr)   # :160
+                num_mv += nirs
+                Z[:, j] = w
+            else:
+                w = O.solve(Q[:, j].copy(), rank=rr)                 # :59
             v = A @ w                                                # :60
             for k in range(j + 1):                                   # :63-66
                 w2[k] = v @ Q[:, k]
@@ -252,8 +266,11 @@ def gmres(O, indptr, indices, vals, b, restart=30, rtol=1e-6, maxit=500, full_ra
         for k in range(j, -1, -1):                                   # :106-110
             y[k] /= R[k, k]
             y[:k] -= y[k] * R[:k, k]
-        v = Q[:, :j + 1] @ y[:j + 1]                                 # :112-116
-        x = x + O.solve(v, rank=rr)                                  # :118-119
+        if flexible:
+            x = x + Z[:, :j + 1] @ y[:j + 1]                         # :214-218
+        else:
+            v = Q[:, :j + 1] @ y[:j + 1]                             # :112-116
+            x = x + O.solve(v, rank=rr)                              # :118-119
         if resid <= rtol or flag != 0:                               # :120
             break
-    return x, flag, it
+    return (x, flag, it, num_mv) if flexible else (x, flag, it)

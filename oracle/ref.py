@@ -166,6 +166,20 @@ def _gmres(self, b, restart=30, rtol=1e-6, maxit=500, full_rank=False):
 RefHIF.gmres = _gmres
 
 
+def _fgmres(self, b, restart=30, rtol=1e-6, maxit=500, full_rank=False):
+    """fgmres_hifir of examples/advanced/gmres.hpp:127-231: returns (x, flag, iterations, sweeps)."""
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros_like(b)
+    out = np.zeros(3, dtype=np.int32)
+    lib().hifref_d_fgmres.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    if lib().hifref_d_fgmres(self.h, _p(b), restart, rtol, maxit, int(full_rank), _p(x), _p(out)):
+        raise RuntimeError(lib().hifref_error().decode())
+    return x, int(out[0]), int(out[1]), int(out[2])
+
+
+RefHIF.fgmres = _fgmres
+
+
 def _set_nsp_const(self, start=0, end=-1, trans=False):
     """HIF::nsp (trans: nsp_tran) = constant-mode filter on rows [start, end) (end < 0: to the end);
     start > end >= 0 removes it.  Real handles only."""

@@ -216,6 +216,27 @@ int do_gmres(void *h, const T *b, int restart, double rtol, int maxit, int full_
   }
 }
 
+// fgmres_hifir (examples/advanced/gmres.hpp:127-231): flexible GMRES whose inner preconditioner is
+// HIF::hifir with 2^outer refinement sweeps; out[0] = flag, out[1] = iterations, out[2] = number of sweeps
+template <class T>
+int do_fgmres(void *h, const T *b, int restart, double rtol, int maxit, int full_rank, T *x, int *out) {
+  auto *r = (Ref<T> *)h;
+  try {
+    typename Ref<T>::crs_t A(r->n, r->n, r->ip.data(), r->ind.data(), r->val.data(), true);
+    hif::Array<T> bb(r->n, const_cast<T *>(b), true);
+    auto res = fgmres_hifir(A, bb, r->M, restart, rtol, maxit, 0, full_rank != 0);
+    const hif::Array<T> &xs = std::get<0>(res);
+    for (size_t i = 0; i < r->n; ++i) x[i] = xs[i];
+    out[0] = std::get<1>(res);
+    out[1] = std::get<2>(res);
+    out[2] = std::get<3>(res);
+    return 0;
+  } catch (const std::exception &e) {
+    g_err = e.what();
+    return 1;
+  }
+}
+
 // y = A x with the reference CRS kernel (serial multiply_nt; mt_mv.hpp partitions rows only)
 template <class T>
 void do_spmv(size_t n, const int64_t *indptr, const int *indices, const T *vals, const T *x, T *y) {
@@ -367,6 +388,10 @@ int hifref_z_hifir(void *h, const void *b, int nirs, const double *betas, void *
 int hifref_d_gmres(void *h, const double *b, int restart, double rtol, int maxit, int full_rank, double *x,
                    int *out) {
   return do_gmres<double>(h, b, restart, rtol, maxit, full_rank, x, out);
+}
+int hifref_d_fgmres(void *h, const double *b, int restart, double rtol, int maxit, int full_rank, double *x,
+                    int *out) {
+  return do_fgmres<double>(h, b, restart, rtol, maxit, full_rank, x, out);
 }
 void hifref_d_spmv(size_t n, const int64_t *ip, const int *ind, const double *v, const double *x,
                    double *y) {

@@ -95,3 +95,25 @@ def test_gmres_wide_batch_and_errors(cache):
     Mz.set_matrix(dz["A_indptr"], dz["A_indices"], dz["A_vals"])
     with pytest.raises(hifir_amd.HifAmdError):  # real-valued driver only
         Mz.gmres(dz["b"])
+
+
+@pytest.mark.parametrize("name,restart,rtol,maxit", [("p2d_100_tuned", 10, 1e-8, 200), ("cd2d_48", 30, 1e-10, 100),
+                                                      ("p2d_100_tuned", 8, 1e-14, 9)])
+def test_flexible_gmres(cache, name, restart, rtol, maxit):
+    # fgmres_hifir (gmres.hpp:127-231): refinement sweeps (1, 2, 4, ... per outer cycle) as the preconditioner
+    levels, d, M, O = _get(cache, name)
+    n = len(d["b"])
+    rng = np.random.default_rng(31)
+    B = rng.uniform(-1, 1, size=(n, 3))
+    B[:, 0] = d["b"]
+    X, fl, it, mv = M.fgmres(B, restart=restart, rtol=rtol, maxit=maxit)
+    for k in range(3):
+        xo, fo, io, mo = orc.fgmres(O, d["A_indptr"], d["A_indices"], d["A_vals"], B[:, k].copy(), restart=restart,
+                                    rtol=rtol, maxit=maxit)
+        assert (int(fl[k]), int(it[k]), int(mv[k])) == (fo, io, mo), k
+        assert relerr(X[:, k], xo) <= 1e-7
+    if ref.available():
+        R = ref.RefHIF(d["A_indptr"], d["A_indices"], d["A_vals"], None if not d["params"].any() else d["params"])
+        xr, fr, ir, mr = R.fgmres(d["b"], restart=restart, rtol=rtol, maxit=maxit)
+        assert (int(fl[0]), int(it[0]), int(mv[0])) == (fr, ir, mr)
+        assert relerr(X[:, 0], xr) <= 1e-7

@@ -131,3 +131,8 @@ def test_gmres_restatement(nx, params, rtol, maxit, restart):
     x1, f1, i1 = orc.gmres(O, A.indptr, A.indices, A.data, b, restart=restart, rtol=rtol, maxit=maxit)
     assert (f0, i0) == (f1, i1)
     assert relerr(x1, x0) <= 1e-8
+    # the flexible variant (fgmres_hifir, gmres.hpp:127-231): refinement sweeps as the preconditioner
+    y0, g0, j0, m0 = M.fgmres(b, restart=restart, rtol=rtol, maxit=maxit)
+    y1, g1, j1, m1 = orc.fgmres(O, A.indptr, A.indices, A.data, b, restart=restart, rtol=rtol, maxit=maxit)
+    assert (g0, j0, m0) == (g1, j1, m1)
+    assert relerr(y1, y0) <= 1e-8
