@@ -11,13 +11,17 @@
 //
 // Reference loops restated as row gathers (file:line relative to the reference tree):
 //   k_trsv_*  L: CCS::solve_as_strict_lower   ds/CompressedStorage.hpp:2268-2279 (+ mrhs :2287)
-//             D: y[i] /= d[i]                 alg/prec_solve.hpp:219 (fused: v[i] = w[i] / d[i])
+//             D: y[i] /= d[i]                 alg/prec_solve.hpp:219 (fused into the first U kernel that touches a row)
 //             U: CCS::solve_as_strict_upper   ds/CompressedStorage.hpp:2357-2369 (+ mrhs :2377)
 //   k_spmm_epi    CCS::multiply_nt_low :2079 fused with  y = s[p]*b[p] - y  prec_solve.hpp:366-368,397-399
 //   k_gather_scale   work[i] = s[p[i]]*b[p[i]]           alg/prec_solve.hpp:359,402
 //   k_scatter_scale  y[i] = t[i]*work[q_inv[i]]          alg/prec_solve.hpp:411
 //   k_dense_gemm     QRCP::_solve_nt (ormqr, trsv, perm) small_scale/QRCP.hpp:371-411 on f64 MFMA
 //   k_crs_spmm       CRS::multiply_nt_low(x,istart,len,y) ds/CompressedStorage.hpp:1109-1127
+//   k_thin_update + k_tri_gemm_d   the thin tail of a triangle in block-dense form (host.hpp plan_dense_blocks)
+//   k_gather_div / k_prod_rows / k_spmm_prod / k_scatter_div   prec_prod, alg/prec_prod.hpp:55-147
+//   k_zcombine       complex products as two real MFMA products
+//   k_coldot_partial / k_col_op / k_colsum_partial / k_sub_colmean   GMRES and null-space-filter BLAS-1
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -188,7 +192,7 @@ __device__ __forceinline__ void trsv_row(int64_t slot, const int32_t *__restrict
 // accumulation stays in the reference's order.  In place: x[i] holds the rhs on entry and the
 // solution on exit.  UPPER rows start from rhs_u[i] / d[i] when this kernel is the first to touch them (first_u).
 //   MODE 0: all dependencies were finished by earlier launches                   (k_trsv_wide)
-//   MODE 2: dependencies with srcslot >= slot0 are acquired through LDS flags     (k_trsv_tail)
+//   MODE 2: dependencies with srcslot >= slot0 are acquired through LDS flags     (k_trsv_band)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int32_t rl32(int32_t v, int idx) { return __builtin_amdgcn_readlane(v, idx); }
 __device__ __forceinline__ double rl64(double v, int idx) {
