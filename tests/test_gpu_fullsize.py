@@ -198,3 +198,25 @@ def test_constant_null_space_filter_matches_reference():
     M.set_nsp_const(0, -1, trans=True)
     assert relerr(M.solve(b, trans=True), R.solve(b, trans=True)) <= 1e-12
     assert np.array_equal(M.solve(b), plain)
+
+
+def test_1m_complex_stand_in_for_config5():
+    # BASELINE config 5 stand-in at full size: complex fp64, 1M rows, nrhs = 16 (the SuiteSparse saddle point
+    # cannot be fetched offline): complex shifted 2-D Laplacian, columns vs the oracle and the real reference,
+    # forward and conjugate-transpose
+    A = (poisson2d(1000) - (0.3 + 0.2j) * sp.identity(1000 * 1000)).tocsr()
+    A.sort_indices()
+    R = ref.RefHIF(A.indptr, A.indices, A.data)
+    levels = R.levels()
+    M = hifir_amd.HIF.from_levels(levels, max_nrhs=16)
+    O = orc.Oracle(levels)
+    rng = np.random.default_rng(10)
+    n = A.shape[0]
+    B = rng.uniform(-1, 1, size=(n, 16)) + 1j * rng.uniform(-1, 1, size=(n, 16))
+    X = M.solve_mrhs(B)
+    assert relerr(X[:, 0], O.solve(B[:, 0].copy())) <= 1e-12
+    assert relerr(X[:, 15], R.solve(B[:, 15].copy())) <= 1e-12
+    XH = M.solve_mrhs(B, trans=True)
+    assert relerr(XH[:, 7], R.solve(B[:, 7].copy(), trans=True)) <= 1e-12
+    Y = M.mmultiply(X)
+    assert (np.linalg.norm(Y - B, axis=0) / np.linalg.norm(B, axis=0)).max() <= 1e-10
