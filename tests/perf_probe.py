@@ -18,7 +18,16 @@ nx = int(sys.argv[1])
 mode = sys.argv[2]
 nrhs = int(sys.argv[3])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
-A = poisson2d(nx)
+if mode.endswith("-3d"):  # e.g. "tuned-3d": 3-D 7-pt Poisson nx^3 (BASELINE config 4's stencil)
+    import scipy.sparse as sp
+
+    T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(nx, nx), format="csr")
+    I = sp.identity(nx, format="csr")
+    A = (sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(T, I), I)).tocsr()
+    A.sort_indices()
+    mode = mode[:-3]
+else:
+    A = poisson2d(nx)
 cplx = mode.endswith("-z")  # e.g. "default-z": complex shifted Laplacian (BASELINE config 5 stand-in)
 if cplx:
     import scipy.sparse as sp
