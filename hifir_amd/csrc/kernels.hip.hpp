@@ -508,6 +508,112 @@ __global__ void __launch_bounds__(256) k_thin_update(int32_t r0, int32_t r1, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// R = 64 software pipeline of the Schur products (k_spmm_epi): a wave owns rows row0, row0 + stride, ...
+// and streams each as items of up to 64 nonzeros, exactly like trsv_stream_r64 (MODE 0): the lanes fetch
+// an item's (column, value) pairs with one coalesced load each and broadcast them with v_readlane,
+// gathers go out eight 512-byte rows at a time, and while an item is consumed the next one (or the first
+// item, scaled right-hand side and header of the wave's next row) is already in flight.  The sum starts
+// from 0.0 and runs in ascending column order; the scaled right-hand side is combined at the end, as
+// y = E*work; y = s*b - y does (prec_solve.hpp:366-368, :397-399).
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ void spmm_stream_r64(int64_t row0, int64_t nrows, int64_t stride,
+                                                const int32_t *__restrict__ ptr, const int32_t *__restrict__ col,
+                                                const T *__restrict__ val, const T *__restrict__ x,
+                                                const T *__restrict__ bin, int64_t ldb, int nrhs,
+                                                const int32_t *__restrict__ p, const double *__restrict__ s,
+                                                int64_t roff, T *__restrict__ out, int lane) {
+  if (row0 >= nrows) return;
+  int64_t i = row0;
+  int32_t k_c = rfl(ptr[i]), e_c = rfl(ptr[i + 1]);
+  int64_t i_n = i + stride;
+  bool has_n = i_n < nrows;
+  int32_t k_n = 0, e_n = 0;
+  if (has_n) {
+    k_n = rfl(ptr[i_n]);
+    e_n = rfl(ptr[i_n + 1]);
+  }
+  int32_t colv = 0;
+  T valv = vzero(T());
+  if (k_c + lane < e_c) {
+    colv = col[k_c + lane];
+    valv = val[k_c + lane];
+  }
+  T rhs = vzero(T());
+  {
+    const int32_t src = rfl(p[roff + i]);
+    if (lane < nrhs) rhs = vscale(s[src], bin[(int64_t)src * ldb + lane]);
+  }
+  T acc = vzero(T());
+  for (;;) {
+    const int32_t cnt = min(64, e_c - k_c);  // <= 0 for an empty row
+    const bool row_done = (k_c + 64 >= e_c);
+    int32_t colv2 = 0;
+    T valv2 = vzero(T()), rhs2 = vzero(T());
+    int64_t i_nn = 0;
+    int32_t k_nn = 0, e_nn = 0;
+    bool has_nn = false;
+    if (!row_done) {
+      const int32_t kk = k_c + 64 + lane;
+      if (kk < e_c) {
+        colv2 = col[kk];
+        valv2 = val[kk];
+      }
+    } else if (has_n) {
+      const int32_t kk = k_n + lane;
+      if (kk < e_n) {
+        colv2 = col[kk];
+        valv2 = val[kk];
+      }
+      const int32_t src = rfl(p[roff + i_n]);
+      if (lane < nrhs) rhs2 = vscale(s[src], bin[(int64_t)src * ldb + lane]);
+      i_nn = i_n + stride;
+      has_nn = i_nn < nrows;
+      if (has_nn) {
+        k_nn = rfl(ptr[i_nn]);
+        e_nn = rfl(ptr[i_nn + 1]);
+      }
+    }
+    int32_t t = 0;
+    while (t < cnt) {
+      const int nb = min(8, cnt - t);
+      int32_t j[8];
+      T a[8], xv[8];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int idx = min(t + b, 63);
+        j[b] = rl32(colv, idx);
+        a[b] = rlv(valv, idx);
+      }
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+        if (b < nb) xv[b] = x[((int64_t)j[b] << 6) + lane];
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+        if (b < nb) acc = vadd(acc, vmul(xv[b], a[b]));
+      t += nb;
+    }
+    if (row_done) {
+      out[(i << 6) + lane] = vsub(rhs, acc);
+      if (!has_n) break;
+      i = i_n;
+      k_c = k_n;
+      e_c = e_n;
+      rhs = rhs2;
+      acc = vzero(T());
+      i_n = i_nn;
+      has_n = has_nn;
+      k_n = k_nn;
+      e_n = e_nn;
+    } else {
+      k_c += 64;
+    }
+    colv = colv2;
+    valv = valv2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // S3 / S5:  out[i] = s[p[roff+i]] * b[p[roff+i]] - sum_asc A(i,j) x[j],  rows [0, nrows)
 // (accumulate from 0.0 in ascending column order, THEN subtract from the scaled rhs: exactly
 //  y = E*work followed by y = s*b - y of prec_solve.hpp:366-368 / :397-399)
@@ -524,6 +630,11 @@ __global__ void __launch_bounds__(256) k_spmm_epi(int64_t nrows, const int32_t *
   const LaneMap lm = lane_map(logR);
   const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  if (logR == 6) {
+    spmm_stream_r64<T>(__builtin_amdgcn_readfirstlane((int)wave), nrows, nwaves, ptr, col, val, x, bin, ldb, nrhs, p, s,
+                       roff, out, threadIdx.x & 63);
+    return;
+  }
   for (int64_t i = wave * lm.G + lm.g; i < nrows; i += nwaves * lm.G) {
     const int32_t k0 = ptr[i], k1 = ptr[i + 1];
     T acc = vzero(T());
