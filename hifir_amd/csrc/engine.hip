@@ -275,6 +275,9 @@ class Engine : public EngineBase {
   int gemm_waves = 16;   // split-K width of the block-inverse GEMM
   BandOptions band_opt;  // how triangles are cut into bands (host.hpp)
   DevBuf errflag;        // sticky error word: a bounded spin of k_trsv_band expired
+#ifdef HIFAMD_PROBE
+  DevBuf probe;          // development probe (make PROBE=1): wave timestamps of k_trsv_band, dumped at destruction
+#endif
   DevBuf blk_tmp;        // right-hand side of one diagonal block of a block-dense thin band
   DevBuf zt1, zt2;       // complex handles: the two real partial products A_re X, A_im X (k_zcombine)
   // IR scratch
@@ -313,6 +316,17 @@ class Engine : public EngineBase {
 
   ~Engine() override {
     if (stream) (void)hipSetDevice(device);
+#ifdef HIFAMD_PROBE
+    if (probe.p && getenv("HIFIR_AMD_PROBE_OUT")) {
+      std::vector<unsigned long long> h(probe.bytes / 8);
+      (void)hipDeviceSynchronize();
+      (void)hipMemcpy(h.data(), probe.p, probe.bytes, hipMemcpyDeviceToHost);
+      if (FILE *f = fopen(getenv("HIFIR_AMD_PROBE_OUT"), "wb")) {
+        fwrite(h.data(), 8, h.size(), f);
+        fclose(f);
+      }
+    }
+#endif
     adj.reset();
     twins.clear();
     if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -706,6 +720,12 @@ class Engine : public EngineBase {
     }
     errflag.alloc(sizeof(unsigned));
     zero_dev(errflag.p, errflag.bytes);
+#ifdef HIFAMD_PROBE
+    if (getenv("HIFIR_AMD_PROBE_OUT")) {  // 600 launches x 256 workgroups x 16 waves x 16 words
+      probe.alloc((size_t)600 * 256 * 16 * 16 * 8);
+      zero_dev(probe.p, probe.bytes);
+    }
+#endif
     if (sizeof(T) != sizeof(double)) {
       const size_t rows = (size_t)std::max<int64_t>(band_opt.dense_block + 32, host.has_dense ? host.dense.n + 32 : 0);
       zt1.alloc(rows * (size_t)Rmax * 2 * sizeof(double));
@@ -825,7 +845,12 @@ class Engine : public EngineBase {
       hipLaunchKernelGGL((k_trsv_band<D, LOWER>), dim3((unsigned)(g1 - g0)), dim3(1024), 0, st, g0,
                          M.wg_grp_ptr.as<int32_t>(), M.grp_slot_ptr.as<int32_t>(), M.ptr.as<int32_t>(),
                          M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(), M.srcslot.as<int32_t>(),
-                         M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR, errflag.as<unsigned>(), pre ? 0 : 1);
+                         M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR, errflag.as<unsigned>(), pre ? 0 : 1
+#ifdef HIFAMD_PROBE
+                         ,
+                         probe.as<unsigned long long>(), (int)count
+#endif
+      );
       ++count;
     }
   }

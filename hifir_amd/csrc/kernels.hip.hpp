@@ -205,6 +205,22 @@ __device__ __forceinline__ double rlv(double v, int idx) { return rl64(v, idx); 
 __device__ __forceinline__ cplx rlv(cplx v, int idx) { return cplx{rl64(v.x, idx), rl64(v.y, idx)}; }
 __device__ __forceinline__ int32_t rfl(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Development probe (make PROBE=1): wall_clock64 stamps of every wave of k_trsv_band -- kernel entry, start
+// of work, exit, and per row (the wave's first two) start / first gather / last accumulation / flag, number
+// of nonzeros and poll sleeps.  tests/probe_summary.py and tests/probe_rows.py read the dump
+// (HIFIR_AMD_PROBE_OUT); profiles/r01_band_*_timestamps.* were made with it.  Compiled out by default.
+#ifdef HIFAMD_PROBE
+#define HIFAMD_PROBE_ARG , unsigned long long *tsw = nullptr
+#define HIFAMD_STAMP(k) \
+  if (tsw && lane == 0 && prow < 2) tsw[4 + prow * 6 + (k)] = wall_clock64();
+#define HIFAMD_STAMP_VAL(k, v) \
+  if (tsw && lane == 0 && prow < 2) tsw[4 + prow * 6 + (k)] = (unsigned long long)(v);
+#else
+#define HIFAMD_PROBE_ARG
+#define HIFAMD_STAMP(k)
+#define HIFAMD_STAMP_VAL(k, v)
+#endif
+
 template <class T, int MODE, bool LOWER, bool PREFIX>
 __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, int32_t stride,
                                                 const int32_t *__restrict__ ptr, const int32_t *__restrict__ split,
@@ -212,9 +228,13 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
                                                 const T *__restrict__ val, const int32_t *__restrict__ srcslot,
                                                 const int32_t *__restrict__ rowid, const T *__restrict__ d, T *x,
                                                 const T *__restrict__ rhs_u, int lane, int *flag, int32_t slot0,
-                                                unsigned *errflag, bool first_u) {
+                                                unsigned *errflag, bool first_u HIFAMD_PROBE_ARG) {
   int32_t s = rfl(s_first);
   if (s >= s_end) return true;
+#ifdef HIFAMD_PROBE
+  int prow = 0;
+  bool pfirst = false;
+#endif
   // nonzero range of a row: the whole row, its PREFIX [ptr, split) (dependencies finished before the
   // thin run started; exact partial sum, no division yet) or, in a thin run, the rest [split, end)
 #define HIFAMD_KBEG(sl) rfl((MODE == 2) ? split[sl] : ptr[sl])
@@ -285,6 +305,13 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
     // item is consumed (eight gathers per batch) and only then is the rest polled again.
     int32_t t = 0;
     unsigned spins = 0;
+#ifdef HIFAMD_PROBE
+    if (k_c == HIFAMD_KBEG(s)) {
+      HIFAMD_STAMP(0)
+      HIFAMD_STAMP_VAL(4, e_c - k_c)
+      pfirst = false;
+    }
+#endif
     while (t < cnt) {
       int32_t lim = cnt;
       if (MODE == 2) {
@@ -302,6 +329,12 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
           continue;
         }
       }
+#ifdef HIFAMD_PROBE
+      if (!pfirst) {
+        HIFAMD_STAMP(1)
+        pfirst = true;
+      }
+#endif
       while (t < lim) {
         const int nb = min(8, lim - t);
         int32_t j[8];
@@ -322,10 +355,16 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
       }
     }
     if (row_done) {
+      HIFAMD_STAMP(2)
       x[((int64_t)i_c << 6) + lane] = acc;
       if (MODE == 2) {  // release: the row's stores (all 64 lanes) are complete before its flag goes up
         if (lane == 0) __hip_atomic_store(&flag[s - slot0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
+#ifdef HIFAMD_PROBE
+      HIFAMD_STAMP(3)
+      HIFAMD_STAMP_VAL(5, spins)
+      ++prow;
+#endif
       if (!has_n) break;
       if (MODE == 2) HIFAMD_PREFETCH_NEXT_ROW();
       s = s_n;
@@ -391,11 +430,21 @@ __global__ void __launch_bounds__(1024) k_trsv_band(int32_t wg0, const int32_t *
                                                     const int32_t *__restrict__ col, const T *__restrict__ val,
                                                     const int32_t *__restrict__ srcslot,
                                                     const int32_t *__restrict__ rowid, const T *__restrict__ d,
-                                                    T *w, T *v, int logR, unsigned *errflag, int first_u) {
+                                                    T *w, T *v, int logR, unsigned *errflag, int first_u
+#ifdef HIFAMD_PROBE
+                                                    ,
+                                                    unsigned long long *ts, int probe_id
+#endif
+) {
   __shared__ int flag[HIFAMD_TAIL_MAX];
   const LaneMap lm = lane_map(logR);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#ifdef HIFAMD_PROBE  // [launch][workgroup < 256][wave][16]: 0 entry, 2 start of work, 3 exit, 4.. two rows x 6
+  unsigned long long *tsw =
+      (ts && blockIdx.x < 256) ? ts + (((size_t)probe_id * 256 + blockIdx.x) * 16 + wave) * 16 : nullptr;
+  if (tsw && lane == 0) tsw[0] = wall_clock64();
+#endif
   const int32_t wf0 = wg_grp_ptr[wg0 + blockIdx.x], wf1 = wg_grp_ptr[wg0 + blockIdx.x + 1];
   const int32_t *wfptr = grp_slot_ptr;
   const int32_t slot0 = wfptr[wf0], slot1 = wfptr[wf1];
@@ -403,8 +452,15 @@ __global__ void __launch_bounds__(1024) k_trsv_band(int32_t wg0, const int32_t *
   __syncthreads();
   T *x = LOWER ? w : v;
   if (logR == 6) {
+#ifdef HIFAMD_PROBE
+    if (tsw && lane == 0) tsw[2] = wall_clock64();
+    trsv_stream_r64<T, 2, LOWER, false>(slot0 + wave, slot1, nw, ptr, split, col, val, srcslot, rowid, d, x, w, lane,
+                                        flag, slot0, errflag, first_u != 0, tsw);
+    if (tsw && lane == 0) tsw[3] = wall_clock64();
+#else
     trsv_stream_r64<T, 2, LOWER, false>(slot0 + wave, slot1, nw, ptr, split, col, val, srcslot, rowid, d, x, w, lane,
                                         flag, slot0, errflag, first_u != 0);
+#endif
     return;
   }
   for (int32_t wf = wf0; wf < wf1; ++wf) {

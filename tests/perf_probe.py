@@ -70,3 +70,4 @@ ms = M.time_apply(Bd, Xd, warmup=2, reps=reps)
 balg = M.algorithmic_bytes(nrhs)
 print(f"RESULT nx={nx} mode={mode} nrhs={nrhs}: {ms:.3f} ms/batch  {nrhs / ms * 1e3:.0f} RHS-applies/s  "
       f"B_alg={balg / 1e9:.3f} GB  {balg / ms / 1e6:.1f} GB/s  frac_of_8TB/s={balg / ms / 1e6 / 8000:.4f}", flush=True)
+M.close()
