@@ -207,6 +207,7 @@ struct DevLevel {
 
 struct DevDense {
   int64_t n = 0, rank = 0;
+  bool symm = false;  // SYEIG last level: QH = diag(1/w) V^H, Qm = V (truncation order), Rm = diag(w) V^H
   DevBuf QH, Rinv, jpvt0, tmp;
   DevBuf Qm, RinvH, tmp2;  // adjoint engine only: Q, (R^{-1})^H and the permuted input
   DevBuf Rm;               // product only: R (primary engine, upper) or R^H (adjoint engine, lower)
@@ -497,7 +498,18 @@ class Engine : public EngineBase {
       E->band_opt = band_opt;
       E->gemm_waves = gemm_waves;
       for (const auto &P : host.levels) E->add_level_adjoint(P);
-      if (host.has_dense) {
+      if (host.has_dense && host.dense.kind == 1) {
+        // Hermitian last level: the conjugate-transpose solve IS the solve (prec_solve.hpp:583-584)
+        E->host.dense.kind = 1;
+        E->host.dense.spd = host.dense.spd;
+        E->host.dense.n = host.dense.n;
+        E->host.dense.rank = host.dense.rank;
+        E->host.dense.w = host.dense.w;
+        E->host.dense.trunc = host.dense.trunc;
+        E->host.dense.evec = host.dense.evec;
+        dense_symm_ops(E->host.dense);
+        E->host.has_dense = true;
+      } else if (host.has_dense) {
         E->host.dense.n = host.dense.n;
         E->host.dense.rank = host.dense.rank;
         E->host.dense.qr = host.dense.qr;
@@ -550,6 +562,7 @@ class Engine : public EngineBase {
       }
       E->dn.n = dn.n;
       E->dn.rank = dn.rank;
+      E->dn.symm = dn.symm;
       E->dn.QH.alias(dn.QH);
       E->dn.Rinv.alias(dn.Rinv);
       E->dn.jpvt0.alias(dn.jpvt0);
@@ -627,6 +640,17 @@ class Engine : public EngineBase {
     host.has_dense = true;
   }
 
+  // symmetric / Hermitian last level (the reference's symm_dense_solver, filled by symm_factor.hpp:654-657)
+  void set_dense_symm(int64_t nd, const T *mat, int spd) {
+    if (finalized) throw Error(HIFAMD_BAD_PREC, "hierarchy already finalized");
+    if (host.levels.empty()) throw Error(HIFAMD_BAD_PREC, "add the sparse levels before the dense block");
+    const auto &last = host.levels.back();
+    if (nd != last.n - last.m) throw Error(HIFAMD_MISMATCHED_SIZES, "dense block size must be n-m of the last level");
+    if (!mat) throw Error(HIFAMD_NULL_OBJ, "NULL dense block");
+    dense_factorize_symm(host.dense, mat, nd, spd);
+    host.has_dense = true;
+  }
+
   // Block inverses of a triangle's block-dense thin bands: built one block at a time into two pinned staging
   // buffers (reused, so the host never holds more than two blocks) and streamed to HBM while the next block
   // is being inverted.  A band whose inverse grows beyond dense_max_growth reverts to the sequential scheme.
@@ -698,7 +722,17 @@ class Engine : public EngineBase {
 
       lv.push_back(std::move(Lp));
     }
-    if (host.has_dense) {
+    if (host.has_dense && host.dense.kind == 1) {
+      dn.n = host.dense.n;
+      dn.rank = host.dense.rank;
+      dn.symm = true;
+      dn.QH.upload(mfma_operand(host.dense.QH.data(), dn.n, dn.n));
+      dn.Qm.upload(mfma_operand(host.dense.Q.data(), dn.n, dn.n));
+      dn.tmp.alloc((size_t)dn.n * Rmax * sizeof(T));
+      std::vector<T>().swap(host.dense.QH);
+      std::vector<T>().swap(host.dense.Q);
+      std::vector<T>().swap(host.dense.SymMul);
+    } else if (host.has_dense) {
       dn.n = host.dense.n;
       dn.rank = host.dense.rank;
       if (!adjoint) {  // MFMA operands (complex: two real planes each)
@@ -969,7 +1003,14 @@ class Engine : public EngineBase {
       L.pc.alloc(bytes);
       L.pr.alloc(bytes);
     }
-    if (host.has_dense) {
+    if (host.has_dense && host.dense.kind == 1) {  // SYEIG::multiply: V diag(w) V^H (SYEIG.hpp:256-273), either engine
+      HostDense<T> &Dn = host.dense;
+      dense_symm_ops(Dn);
+      dn.Rm.upload(mfma_operand(Dn.SymMul.data(), Dn.n, Dn.n));
+      std::vector<T>().swap(Dn.QH);
+      std::vector<T>().swap(Dn.Q);
+      std::vector<T>().swap(Dn.SymMul);
+    } else if (host.has_dense) {
       HostDense<T> &Dn = host.dense;
       const int64_t n = Dn.n;
       std::vector<T> Rm((size_t)(n * n), T(0));  // R (upper incl. diagonal) or, on the adjoint engine, R^H
@@ -1623,7 +1664,7 @@ class Engine : public EngineBase {
   }
   void save(std::FILE *f) const {
     if (adjoint || is_twin) throw Error(HIFAMD_HIFIR_ERROR, "internal engines are not saved");
-    const int64_t nl = (int64_t)host.levels.size(), hd = host.has_dense ? 1 : 0;
+    const int64_t nl = (int64_t)host.levels.size(), hd = host.has_dense ? (host.dense.kind == 1 ? 2 : 1) : 0;
     if (std::fwrite(&nl, 8, 1, f) != 1 || std::fwrite(&hd, 8, 1, f) != 1) throw Error(HIFAMD_HIFIR_ERROR, "short write");
     for (const auto &H : host.levels) {
       const int64_t hdr[3] = {H.m, H.n, H.F_ncols};
@@ -1642,7 +1683,8 @@ class Engine : public EngineBase {
     }
     if (hd) {
       const int64_t nd = host.dense.n;
-      if (std::fwrite(&nd, 8, 1, f) != 1 || std::fwrite(&host.dense.rrqr_cond, 8, 1, f) != 1)
+      const double par = host.dense.kind == 1 ? (double)host.dense.spd : host.dense.rrqr_cond;  // (hd == 2: spd)
+      if (std::fwrite(&nd, 8, 1, f) != 1 || std::fwrite(&par, 8, 1, f) != 1)
         throw Error(HIFAMD_HIFIR_ERROR, "short write");
       put_vec(f, host.dense.mat);
     }
@@ -1684,7 +1726,10 @@ class Engine : public EngineBase {
       std::vector<T> mat;
       get_vec(f, mat);
       if ((int64_t)mat.size() != nd * nd) throw Error(HIFAMD_BAD_PREC, "inconsistent hierarchy file");
-      set_dense(nd, mat.data(), cond);
+      if (hd == 2)
+        set_dense_symm(nd, mat.data(), (int)cond);
+      else
+        set_dense(nd, mat.data(), cond);
     }
   }
 
@@ -1809,6 +1854,16 @@ void Engine<double>::launch_dense(hipStream_t st, const double *cin, double *zou
   const int nd = (int)dn.n, rk = (int)eff_rank(rank);
   const unsigned g = (unsigned)((nd + 15) / 16);  // one workgroup per 16-row strip (4 waves split K)
   double *tmp = dn.tmp.as<double>();
+  if (dn.symm) {  // SYEIG::solve (SYEIG.hpp:181-200): z = V(:,to(1:rk)) diag(1/w) V(:,to(1:rk))^H c
+    hipLaunchKernelGGL(k_dense_gemm_d<4>, dim3(g, ((1u << logR) + 15) / 16), dim3(256), 0, st, nd, rk, nd, 0,
+                       dn.QH.as<double>(), nd, cin, logR, (const int32_t *)nullptr, tmp, (const double *)nullptr,
+                       (double *)nullptr);
+    hipLaunchKernelGGL(k_dense_gemm_d<4>, dim3(g, ((1u << logR) + 15) / 16), dim3(256), 0, st, nd, nd, rk, 0,
+                       dn.Qm.as<double>(), nd, (const double *)tmp, logR, (const int32_t *)nullptr, zout,
+                       (const double *)nullptr, (double *)nullptr);
+    count += 2;
+    return;
+  }
   if (adjoint) {  // QRCP::_solve_t (QRCP.hpp:413-452): z = Q(:,1:rk) R(1:rk,1:rk)^{-H} (P^T c)(1:rk)
     double *tmp2 = dn.tmp2.as<double>();
     hipLaunchKernelGGL((k_row_gather<double>), dim3(grid_for(nd, logR)), dim3(256), 0, st, cin, dn.jpvt0.as<int32_t>(),
@@ -1836,6 +1891,11 @@ template <>
 void Engine<zdouble>::launch_dense(hipStream_t st, const cplx *cin, cplx *zout, int logR, int64_t rank, int64_t &count) {
   const int nd = (int)dn.n, rk = (int)eff_rank(rank);
   cplx *tmp = dn.tmp.as<cplx>();
+  if (dn.symm) {
+    zgemm(st, nd, rk, nd, 0, dn.QH, nd, cin, logR, nullptr, tmp, nullptr, nullptr, count);
+    zgemm(st, nd, nd, rk, 0, dn.Qm, nd, tmp, logR, nullptr, zout, nullptr, nullptr, count);
+    return;
+  }
   if (adjoint) {
     cplx *tmp2 = dn.tmp2.as<cplx>();
     hipLaunchKernelGGL((k_row_gather<cplx>), dim3(grid_for(nd, logR)), dim3(256), 0, st, cin, dn.jpvt0.as<int32_t>(),
@@ -1857,6 +1917,14 @@ void Engine<double>::launch_dense_mul(hipStream_t st, const double *cin, double 
   const unsigned g = (unsigned)((nd + 15) / 16);
   const dim3 grid(g, ((1u << logR) + 15) / 16);
   double *tmp = dn.tmp.as<double>();
+  if (dn.symm) {  // SYEIG::multiply (SYEIG.hpp:256-273): z = V(:,to(1:rk)) diag(w) V(:,to(1:rk))^H c
+    hipLaunchKernelGGL(k_dense_gemm_d<4>, grid, dim3(256), 0, st, nd, rk, nd, 0, dn.Rm.as<double>(), nd, cin, logR,
+                       (const int32_t *)nullptr, tmp, (const double *)nullptr, (double *)nullptr);
+    hipLaunchKernelGGL(k_dense_gemm_d<4>, grid, dim3(256), 0, st, nd, nd, rk, 0, dn.Qm.as<double>(), nd, (const double *)tmp,
+                       logR, (const int32_t *)nullptr, zout, (const double *)nullptr, (double *)nullptr);
+    count += 2;
+    return;
+  }
   if (adjoint) {
     hipLaunchKernelGGL(k_dense_gemm_d<4>, grid, dim3(256), 0, st, nd, rk, nd, 0, dn.QH.as<double>(), nd, cin, logR,
                        (const int32_t *)nullptr, tmp, (const double *)nullptr, (double *)nullptr);
@@ -1879,6 +1947,11 @@ template <>
 void Engine<zdouble>::launch_dense_mul(hipStream_t st, const cplx *cin, cplx *zout, int logR, int64_t rank, int64_t &count) {
   const int nd = (int)dn.n, rk = (int)eff_rank(rank);
   cplx *tmp = dn.tmp.as<cplx>();
+  if (dn.symm) {
+    zgemm(st, nd, rk, nd, 0, dn.Rm, nd, cin, logR, nullptr, tmp, nullptr, nullptr, count);
+    zgemm(st, nd, nd, rk, 0, dn.Qm, nd, tmp, logR, nullptr, zout, nullptr, nullptr, count);
+    return;
+  }
   if (adjoint) {
     zgemm(st, nd, rk, nd, 0, dn.QH, nd, cin, logR, nullptr, tmp, nullptr, nullptr, count);
     zgemm(st, nd, rk, rk, 2, dn.Rm, nd, tmp, logR, dn.jpvt0.as<int32_t>(), zout, nullptr, nullptr, count);
@@ -2181,6 +2254,12 @@ HifAmdStatus hifamd_load(const char *path, int device, HifAmdHdl *out) {
 HifAmdStatus hifamd_set_dense(HifAmdHdl h, int64_t nd, const void *mat, double rrqr_cond) {
   API_BEGIN
   DISPATCH(ENG_D->set_dense(nd, (const double *)mat, rrqr_cond), ENG_Z->set_dense(nd, (const zdouble *)mat, rrqr_cond))
+  API_END
+}
+
+HifAmdStatus hifamd_set_dense_symm(HifAmdHdl h, int64_t nd, const void *mat, int spd) {
+  API_BEGIN
+  DISPATCH(ENG_D->set_dense_symm(nd, (const double *)mat, spd), ENG_Z->set_dense_symm(nd, (const zdouble *)mat, spd))
   API_END
 }
 

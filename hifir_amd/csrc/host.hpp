@@ -654,6 +654,14 @@ struct HostDense {
   std::vector<T> QH, Rinv;     // explicit operators, column-major
   // adjoint apply (QRCP::_solve_t, QRCP.hpp:413-452): z = Q(:,1:rk) * (R(1:rk,1:rk)^{-H} * (P^T c)(1:rk))
   std::vector<T> Q, RinvH;     // Q = (Q^H)^H, RinvH = (R^{-1})^H (lower triangular), column-major
+  // symmetric / Hermitian last level (the reference's SYEIG solver, small_scale/SYEIG.hpp): kind = 1.
+  // A = V diag(w) V^H, truncated in the order `trunc`.  The device then reuses the two dense operators:
+  //   QH := diag(1/w) V^H with rows in truncation order,  Q := V with columns in truncation order
+  // (solve = Q(:,1:rk) * (QH(1:rk,:) c)); SymMul := diag(w) V^H (rows in truncation order) for the product.
+  int kind = 0, spd = 0;
+  std::vector<double> w;
+  std::vector<int32_t> trunc;
+  std::vector<T> evec, SymMul;
 };
 
 
@@ -942,6 +950,211 @@ void dense_factorize(HostDense<T> &D, const T *mat_colmajor, int64_t n, double r
     D.rank = rk;
   }
   dense_explicit_ops(D);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Symmetric / Hermitian eigendecomposition A = V diag(w) V^H, w ascending (what LAPACK ?syev / ?heev
+// 'V','L' returns to SYEIG::factorize, SYEIG.hpp:107-129): Householder reduction of the lower
+// triangle to a REAL symmetric tridiagonal matrix (the unblocked ?sytd2 / ?hetd2 recurrence: the
+// reflectors are generated with a real beta, so the off-diagonal is real also for complex input),
+// explicit Q = H(0) H(1) ... H(n-2), then implicit QL with Wilkinson shifts on (d, e), the plane rotations
+// accumulated into Q.  A: column-major n x n, only the lower triangle is read; on exit the eigenvectors.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+void herm_eig(int64_t n, std::vector<T> &A, std::vector<double> &w) {
+  w.assign((size_t)n, 0.0);
+  if (n == 0) return;
+  std::vector<double> d((size_t)n, 0.0), e((size_t)n, 0.0);
+  std::vector<T> tau((size_t)n, T(0)), x((size_t)n);
+  auto at = [&](int64_t i, int64_t j) -> T & { return A[(size_t)(i + j * n)]; };
+  // work on a full Hermitian copy (upper := conj(lower)) so that the rank-2 updates are plain loops
+  for (int64_t j = 0; j < n; ++j) {
+    at(j, j) = T(real_(at(j, j)));
+    for (int64_t i = j + 1; i < n; ++i) at(j, i) = conj_(at(i, j));
+  }
+  for (int64_t i = 0; i + 1 < n; ++i) {
+    const int64_t len = n - i - 1;  // the reflector acts on rows/columns i+1 .. n-1
+    T *v = &at(i + 1, i);
+    // ?larfg: H^H (alpha; xrest) = (beta; 0), H = I - tau v v^H, v[0] = 1, beta real
+    const double xnorm = col_norm(v + 1, len - 1);
+    const T alpha = v[0];
+    const double ar = real_(alpha), ai = sizeof(T) == sizeof(zdouble) ? reinterpret_cast<const double *>(&alpha)[1] : 0.0;
+    T taui = T(0);
+    double beta = ar;
+    if (!(xnorm == 0.0 && ai == 0.0)) {
+      beta = std::sqrt(ar * ar + ai * ai + xnorm * xnorm);
+      if (ar >= 0.0) beta = -beta;
+      if (sizeof(T) == sizeof(zdouble)) {
+        double *tp = reinterpret_cast<double *>(&taui);
+        tp[0] = (beta - ar) / beta;
+        tp[1] = -ai / beta;
+      } else
+        taui = T((beta - ar) / beta);
+      const T sc = T(1.0) / (alpha - T(beta));
+      for (int64_t r = 1; r < len; ++r) v[r] *= sc;
+    }
+    e[(size_t)i] = beta;
+    if (taui != T(0)) {
+      v[0] = T(1);
+      // x = taui * A22 v;  x += (-1/2 taui (x^H v)) v;  A22 -= v x^H + x v^H
+      parallel_for(len, 64, [&](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r) {
+          T acc = T(0);
+          for (int64_t c = 0; c < len; ++c) acc += conj_(at(i + 1 + c, i + 1 + r)) * v[c];  // row r of A22 = conj of column r
+          x[(size_t)r] = taui * acc;
+        }
+      });
+      T dot = T(0);
+      for (int64_t r = 0; r < len; ++r) dot += conj_(x[(size_t)r]) * v[r];
+      const T al = T(-0.5) * taui * dot;
+      for (int64_t r = 0; r < len; ++r) x[(size_t)r] += al * v[r];
+      parallel_for(len, 64, [&](int64_t c0, int64_t c1) {
+        for (int64_t c = c0; c < c1; ++c) {
+          const T cvc = conj_(v[c]), cxc = conj_(x[(size_t)c]);
+          T *col = &at(i + 1, i + 1 + c);
+          for (int64_t r = 0; r < len; ++r) col[r] -= v[r] * cxc + x[(size_t)r] * cvc;
+        }
+      });
+    }
+    d[(size_t)i] = real_(at(i, i));
+    tau[(size_t)i] = taui;
+  }
+  d[(size_t)(n - 1)] = real_(at(n - 1, n - 1));
+  // explicit Q = H(0) ... H(n-2) in a separate array (the reflector vectors live below the subdiagonal of A)
+  std::vector<T> Q((size_t)(n * n), T(0));
+  for (int64_t j = 0; j < n; ++j) Q[(size_t)(j + j * n)] = T(1);
+  for (int64_t i = n - 2; i >= 0; --i) {
+    const T taui = tau[(size_t)i];
+    if (taui == T(0)) continue;
+    const int64_t len = n - i - 1;
+    const T *v = &at(i + 1, i);  // v[0] is 1 (set above)
+    parallel_for(n - i - 1, 16, [&](int64_t j0, int64_t j1) {  // only columns i+1.. are not yet unit vectors e_j with j <= i
+      for (int64_t jj = j0; jj < j1; ++jj) {
+        T *c = &Q[(size_t)((i + 1) + (i + 1 + jj) * n)];
+        T dot = T(0);
+        for (int64_t r = 0; r < len; ++r) dot += conj_(v[r]) * c[r];
+        dot *= taui;
+        for (int64_t r = 0; r < len; ++r) c[r] -= v[r] * dot;
+      }
+    });
+  }
+  // implicit QL (EISPACK tql2 recurrence) on the real tridiagonal (d, e), rotations applied to Q's columns
+  const double eps = std::numeric_limits<double>::epsilon();
+  for (int64_t l = 0; l < n; ++l) {
+    int iter = 0;
+    int64_t m;
+    do {
+      for (m = l; m + 1 < n; ++m) {
+        const double dd = std::fabs(d[(size_t)m]) + std::fabs(d[(size_t)m + 1]);
+        if (std::fabs(e[(size_t)m]) <= eps * dd) break;
+      }
+      if (m != l) {
+        if (iter++ == 80) throw Error(4, "symmetric eigensolver: the QL iteration did not converge");
+        double g = (d[(size_t)l + 1] - d[(size_t)l]) / (2.0 * e[(size_t)l]);
+        double r = std::hypot(g, 1.0);
+        g = d[(size_t)m] - d[(size_t)l] + e[(size_t)l] / (g + std::copysign(r, g));
+        double sn = 1.0, cs = 1.0, p = 0.0;
+        int64_t i;
+        for (i = m - 1; i >= l; --i) {
+          double f = sn * e[(size_t)i];
+          const double b = cs * e[(size_t)i];
+          r = std::hypot(f, g);
+          e[(size_t)i + 1] = r;
+          if (r == 0.0) {
+            d[(size_t)i + 1] -= p;
+            e[(size_t)m] = 0.0;
+            break;
+          }
+          sn = f / r;
+          cs = g / r;
+          g = d[(size_t)i + 1] - p;
+          r = (d[(size_t)i] - g) * sn + 2.0 * cs * b;
+          p = sn * r;
+          d[(size_t)i + 1] = g + p;
+          g = cs * r - b;
+          T *zi = &Q[(size_t)(i * n)], *zi1 = &Q[(size_t)((i + 1) * n)];
+          for (int64_t k = 0; k < n; ++k) {
+            const T fz = zi1[k];
+            zi1[k] = sn * zi[k] + cs * fz;
+            zi[k] = cs * zi[k] - sn * fz;
+          }
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[(size_t)l] -= p;
+        e[(size_t)l] = g;
+        e[(size_t)m] = 0.0;
+      }
+    } while (m != l);
+  }
+  // ascending eigenvalues, eigenvectors permuted along
+  std::vector<int64_t> ord((size_t)n);
+  for (int64_t i = 0; i < n; ++i) ord[(size_t)i] = i;
+  std::stable_sort(ord.begin(), ord.end(), [&](int64_t a, int64_t b) { return d[(size_t)a] < d[(size_t)b]; });
+  for (int64_t j = 0; j < n; ++j) {
+    w[(size_t)j] = d[(size_t)ord[(size_t)j]];
+    std::copy(Q.begin() + ord[(size_t)j] * n, Q.begin() + ord[(size_t)j] * n + n, A.begin() + j * n);
+  }
+}
+
+// SYEIG::factorize (SYEIG.hpp:107-175): eigendecomposition, then the truncation order and numerical rank
+// for positive definite (spd > 0), negative definite (spd < 0) or indefinite (spd == 0) blocks.
+template <class T>
+void dense_symm_ops(HostDense<T> &D) {
+  const int64_t n = D.n;
+  D.QH.assign((size_t)(n * n), T(0));
+  D.Q.assign((size_t)(n * n), T(0));
+  D.SymMul.assign((size_t)(n * n), T(0));
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t c = D.trunc[(size_t)i];
+    const double wi = D.w[(size_t)c];
+    for (int64_t k = 0; k < n; ++k) {
+      const T vkc = D.evec[(size_t)(k + c * n)];
+      D.QH[(size_t)(i + k * n)] = conj_(vkc) / wi;      // work[trunc[i]] /= w[trunc[i]]   (:194-195)
+      D.SymMul[(size_t)(i + k * n)] = conj_(vkc) * wi;  // work[trunc[i]] *= w[trunc[i]]   (:268-269)
+      D.Q[(size_t)(k + i * n)] = vkc;
+    }
+  }
+}
+
+template <class T>
+void dense_factorize_symm(HostDense<T> &D, const T *mat_colmajor, int64_t n, int spd) {
+  D.kind = 1;
+  D.spd = spd;
+  D.n = n;
+  D.mat.assign(mat_colmajor, mat_colmajor + n * n);
+  D.evec.assign(mat_colmajor, mat_colmajor + n * n);
+  herm_eig(n, D.evec, D.w);
+  D.trunc.resize((size_t)n);
+  for (int64_t i = 0; i < n; ++i) D.trunc[(size_t)i] = (int32_t)i;
+  const double EPS = std::pow(std::numeric_limits<double>::epsilon(), 2.0 / 3.0);
+  double wmax = 0.0;
+  for (double v : D.w) wmax = std::max(wmax, std::fabs(v));
+  const double thres = EPS * wmax;
+  int64_t rank = n;
+  if (spd > 0) {
+    for (int64_t i = n - 1; i >= 0; --i)
+      if (D.w[(size_t)i] <= 0.0 || std::fabs(D.w[(size_t)i]) <= thres)
+        --rank;
+      else
+        break;
+  } else if (spd < 0) {
+    std::reverse(D.trunc.begin(), D.trunc.end());
+    for (int64_t i = 0; i < n; ++i)
+      if (D.w[(size_t)i] >= 0.0 || std::fabs(D.w[(size_t)i]) <= thres)
+        --rank;
+      else
+        break;
+  } else {
+    std::stable_sort(D.trunc.begin(), D.trunc.end(),
+                     [&](int32_t a, int32_t b) { return std::fabs(D.w[(size_t)a]) > std::fabs(D.w[(size_t)b]); });
+    for (int64_t i = n - 1; i >= 0; --i)
+      if (std::fabs(D.w[(size_t)D.trunc[(size_t)i]]) <= thres)
+        --rank;
+      else
+        break;
+  }
+  D.rank = rank;
+  dense_symm_ops(D);
 }
 
 template <class T>

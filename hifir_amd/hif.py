@@ -64,7 +64,8 @@ class HIF:
     def from_levels(cls, levels, max_nrhs=64, rrqr_cond=0.0, device=-1, dtype=None):
         """levels: list of dicts with the fields of hif::Prec (alg/Prec.hpp:309-323), CCS matrices:
         m, n, {L,U,E,F}_{colptr,rowind,vals}, d, s, t, p, q_inv (+ p_inv, q), and on the last one
-        optionally dense_n, dense (unfactored column-major Schur complement)."""
+        optionally dense_n, dense (unfactored column-major Schur complement); dense_symm (+ spd) marks the block of
+        a hierarchy factorized with is_symm, whose last level is the reference's SYEIG solver."""
         if dtype is None:
             cplx = any(np.iscomplexobj(lv["L_vals"]) or np.iscomplexobj(lv["d"]) or np.iscomplexobj(lv["E_vals"])
                        for lv in levels)
@@ -74,7 +75,10 @@ class HIF:
             self.add_level(lv)
         last = levels[-1]
         if int(last.get("dense_n", 0)) > 0:
-            self.set_dense(last["dense"], rrqr_cond)
+            if int(last.get("dense_symm", 0)):
+                self.set_dense_symm(last["dense"], int(last.get("spd", 0)))
+            else:
+                self.set_dense(last["dense"], rrqr_cond)
         self.finalize(max_nrhs)
         return self
 
@@ -119,6 +123,12 @@ class HIF:
         mat = np.ascontiguousarray(mat_colmajor, dtype=self.dtype).ravel()
         nd = int(round(np.sqrt(mat.size)))
         _check(lib().hifamd_set_dense(self._h, nd, _p(mat), float(rrqr_cond)))
+
+    def set_dense_symm(self, mat_colmajor, spd=0):
+        """Last level of a symmetric factorization (Prec::symm_dense_solver, SYEIG): eigendecomposition on the host."""
+        mat = np.ascontiguousarray(mat_colmajor, dtype=self.dtype).ravel()
+        nd = int(round(np.sqrt(mat.size)))
+        _check(lib().hifamd_set_dense_symm(self._h, nd, _p(mat), int(spd)))
 
     def finalize(self, max_nrhs=64):
         _check(lib().hifamd_finalize(self._h, int(max_nrhs)))

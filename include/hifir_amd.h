@@ -85,6 +85,14 @@ HifAmdStatus hifamd_add_level(HifAmdHdl h, int64_t m, int64_t n,
  * QR with column pivoting + rank determination (QRCP::factorize, small_scale/QRCP.hpp:107-179);
  * rrqr_cond <= 0 selects the reference default eps^(-2/3) (QRCP.hpp:110-117). */
 HifAmdStatus hifamd_set_dense(HifAmdHdl h, int64_t nd, const void *mat_colmajor, double rrqr_cond);
+/* The same block of a hierarchy that the reference factorized with is_symm (symm_level_factorize,
+ * alg/symm_factor.hpp:654-657 fills Prec::symm_dense_solver instead of dense_solver; the export is the
+ * symmetric branch of Prec::inquire_or_export_dense, Prec.hpp:294-303).  Factorized here on the host by a
+ * symmetric / Hermitian eigendecomposition with the truncation rules of SYEIG::factorize
+ * (small_scale/SYEIG.hpp:107-175): spd > 0 positive definite, < 0 negative definite, 0 indefinite
+ * (Options::spd).  Only the lower triangle is read.  Solve, conjugate-transpose solve and product follow
+ * SYEIG::solve / multiply (SYEIG.hpp:181-200, 256-273), incl. the run-time `rank` argument. */
+HifAmdStatus hifamd_set_dense_symm(HifAmdHdl h, int64_t nd, const void *mat_colmajor, int spd);
 /* Converts CCS -> schedule-ordered CSR, level-schedules the triangular factors, ships everything to
  * HBM and sizes the work arena for batches of up to max_nrhs (the reference sizes its work buffer
  * on first use only, builder.hpp:414-416 -- not replicated). */

@@ -68,8 +68,9 @@ class HIF {
 
   /// Ship the hierarchy of a factorized hif::HIF (or anything with the same precs() interface,
   /// alg/Prec.hpp:309-357) to HBM.  max_nrhs sizes the device work arena (wider batches are tiled).
+  /// spd: Options::spd of the factorization (only read for is_symm hierarchies: truncation rule of SYEIG).
   template <class RefHif>
-  void attach(const RefHif &M, const size_type max_nrhs = 64) {
+  void attach(const RefHif &M, const size_type max_nrhs = 64, const int spd = 0) {
     clear();
     detail::check(hifamd_create(detail::value_tag<value_type>::value(), _device, &_h));
     try {
@@ -93,6 +94,9 @@ class HIF {
         if (!p.dense_solver.empty()) {  // the UNFACTORED block, Prec::inquire_or_export_dense (Prec.hpp:275-293)
           const auto &D = p.dense_solver.mat_backup();
           detail::check(hifamd_set_dense(_h, (std::int64_t)D.nrows(), D.data(), 0.0));
+        } else if (!p.symm_dense_solver.empty()) {  // is_symm factorizations (symm_factor.hpp:654-657): SYEIG
+          const auto &D = p.symm_dense_solver.mat_backup();
+          detail::check(hifamd_set_dense_symm(_h, (std::int64_t)D.nrows(), D.data(), spd));
         }
       }
       detail::check(hifamd_finalize(_h, (std::int64_t)max_nrhs));

@@ -36,6 +36,8 @@ extern "C" {
                           const int *q, const int *q_inv);                                          \
   /* unfactored column-major nd x nd block of the last level; factorizes by QRCP */                 \
   int orc_##P##_set_dense(void *h, int64_t nd, const T *mat, double rrqr_cond);                     \
+  /* the same block of an is_symm hierarchy (Prec::symm_dense_solver): SYEIG (small_scale/SYEIG.hpp) */ \
+  int orc_##P##_set_dense_symm(void *h, int64_t nd, const T *mat, int spd);                         \
   int64_t orc_##P##_dense_rank(void *h);                                                            \
   int64_t orc_##P##_work_size(void *h);                                                             \
   int orc_##P##_solve(void *h, const T *b, T *x, int64_t rank);                                     \
@@ -63,7 +65,10 @@ extern "C" {
   /* dense block alone: QRCP factor + (op 0) solve / (op 1) multiply / (op 2) solve with A^H /   */  \
   /* (op 3) multiply with A^H */                                                                    \
   int orc_##P##_qrcp(int64_t n, const T *mat, double rrqr_cond, int op, const T *b,                 \
-                     int64_t rank_in, T *x, int64_t *rank_out);
+                     int64_t rank_in, T *x, int64_t *rank_out);                                     \
+  /* symmetric dense block alone: SYEIG factor + (op 0) solve / (op 1) multiply */                  \
+  int orc_##P##_syeig(int64_t n, const T *mat, int spd, int op, const T *b, int64_t rank_in, T *x,  \
+                      int64_t *rank_out, double *w_out);
 
 ORC_DECL(d, double)
 #ifndef __cplusplus

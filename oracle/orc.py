@@ -37,6 +37,8 @@ def lib():
             g("destroy").argtypes = [vp]
             g("set_level").argtypes = [vp, C.c_int, C.c_int64, C.c_int64] + [vp] * 9 + [C.c_int64] + [vp] * 10
             g("set_dense").argtypes = [vp, C.c_int64, vp, C.c_double]
+            g("set_dense_symm").argtypes = [vp, C.c_int64, vp, C.c_int]
+            g("syeig").argtypes = [C.c_int64, vp, C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp]
             g("dense_rank").argtypes = [vp]
             g("dense_rank").restype = C.c_int64
             g("work_size").argtypes = [vp]
@@ -96,7 +98,10 @@ class Oracle:
         last = levels[-1]
         if int(last.get("dense_n", 0)) > 0:
             mat = np.ascontiguousarray(last["dense"], dtype=self.dtype).ravel()
-            self._f("set_dense")(self.h, int(last["dense_n"]), _p(mat), float(rrqr_cond))
+            if int(last.get("dense_symm", 0)):  # is_symm hierarchy: Prec::symm_dense_solver (SYEIG)
+                self._f("set_dense_symm")(self.h, int(last["dense_n"]), _p(mat), int(last.get("spd", 0)))
+            else:
+                self._f("set_dense")(self.h, int(last["dense_n"]), _p(mat), float(rrqr_cond))
 
     def _f(self, name):
         return getattr(lib(), f"orc_{self.k}_{name}")
@@ -186,6 +191,20 @@ def qrcp(mat_colmajor, b, op=0, rank=0, rrqr_cond=0.0):
     rk = np.zeros(1, dtype=np.int64)
     getattr(lib(), f"orc_{k}_qrcp")(len(b), _p(mat), rrqr_cond, op, _p(b), rank, _p(x), _p(rk))
     return x, int(rk[0])
+
+
+def syeig(mat_colmajor, b, op=0, rank=0, spd=0):
+    """SYEIG (small_scale/SYEIG.hpp) on one symmetric / Hermitian block: op 0 solve, 1 multiply.
+    Returns (x, numerical rank, eigenvalues)."""
+    k = _kind(mat_colmajor, b)
+    dt = np.complex128 if k == "z" else np.float64
+    mat = np.ascontiguousarray(mat_colmajor, dtype=dt).ravel()
+    b = np.ascontiguousarray(b, dtype=dt)
+    x = np.zeros_like(b)
+    rk = np.zeros(1, dtype=np.int64)
+    w = np.zeros(len(b))
+    getattr(lib(), f"orc_{k}_syeig")(len(b), _p(mat), int(spd), op, _p(b), rank, _p(x), _p(rk), _p(w))
+    return x, int(rk[0]), w
 
 
 def fgmres(O, indptr, indices, vals, b, restart=30, rtol=1e-6, maxit=500, full_rank=False):

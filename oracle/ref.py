@@ -55,9 +55,10 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def make_params(tau=0.0, kappa=0.0, alpha=0.0, dense_thres=0, rrqr_cond=0.0):
-    """0 keeps the reference default (Options.h:135-164). PDE-tuned set: tau=1e-2, kappa=5, alpha=3."""
-    return np.array([tau, kappa, alpha, dense_thres, rrqr_cond], dtype=np.float64)
+def make_params(tau=0.0, kappa=0.0, alpha=0.0, dense_thres=0, rrqr_cond=0.0, is_symm=0, spd=0):
+    """0 keeps the reference default (Options.h:135-164). PDE-tuned set: tau=1e-2, kappa=5, alpha=3.
+    is_symm: symmetric factorization (symm_factor.hpp; last level = SYEIG); spd: Options::spd (+1 / 0 / -1)."""
+    return np.array([tau, kappa, alpha, dense_thres, rrqr_cond, is_symm, spd], dtype=np.float64)
 
 
 class RefHIF:
@@ -72,6 +73,8 @@ class RefHIF:
         self.vals = vals.astype(self.dtype)
         self.n = len(self.indptr) - 1
         self.params = None if params is None else np.ascontiguousarray(params, dtype=np.float64)
+        if self.params is not None and len(self.params) < 7:  # (older 5-entry parameter arrays)
+            self.params = np.concatenate([self.params, np.zeros(7 - len(self.params))])
         L = lib()
         self.h = getattr(L, f"hifref_{self.k}_factorize")(self.n, _p(self.indptr), _p(self.indices), _p(self.vals), _p(self.params))
         if not self.h:
@@ -101,10 +104,12 @@ class RefHIF:
 
     def level(self, l):
         """All arrays of one hif::Prec (Prec.hpp:309-323), CCS exactly as stored."""
-        sz = np.zeros(10, dtype=np.int64)
+        sz = np.zeros(11, dtype=np.int64)
         self._f("level_sizes")(self.h, l, _p(sz))
-        m, n, nl, nu, ne, nf, nd, rk, enc, fnc = [int(v) for v in sz]
+        m, n, nl, nu, ne, nf, nd, rk, enc, fnc, symm = [int(v) for v in sz]
         out = dict(m=m, n=n, dense_n=nd, dense_rank=rk)
+        if symm:  # Prec::symm_dense_solver: the last level of an is_symm factorization (SYEIG)
+            out.update(dense_symm=1, spd=0 if self.params is None else int(self.params[6]))
         for which, (name, nz, nc) in enumerate([("L", nl, m), ("U", nu, m), ("E", ne, enc), ("F", nf, fnc)]):
             cp = np.zeros(nc + 1, dtype=np.int64)
             ri = np.zeros(nz, dtype=np.int32)

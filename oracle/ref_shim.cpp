@@ -49,7 +49,8 @@ struct Ref {
   size_t n = 0;
 };
 
-// params[]: 0 tau, 1 kappa(_d), 2 alpha, 3 dense_thres (<=0: keep default), 4 rrqr_cond
+// params[]: 0 tau, 1 kappa(_d), 2 alpha, 3 dense_thres (<=0: keep default), 4 rrqr_cond,
+//           5 is_symm (symm_level_factorize, builder.hpp:540-541), 6 spd (Options::spd, SYEIG truncation)
 hif::Params make_params(const double *params) {
   hif::Params p = hif::DEFAULT_PARAMS;
   p.verbose = hif::VERBOSE_NONE;
@@ -59,6 +60,8 @@ hif::Params make_params(const double *params) {
     if (params[2] > 0) p.alpha_L = p.alpha_U = params[2];
     if (params[3] > 0) p.dense_thres = (int)params[3];
     if (params[4] > 0) p.rrqr_cond = params[4];
+    p.is_symm = params[5] != 0.0 ? 1 : 0;
+    p.spd = (int)params[6];
   }
   return p;
 }
@@ -94,6 +97,12 @@ void level_sizes(void *h, int l, int64_t *out) {
   out[5] = p.F.nnz();
   out[6] = p.dense_solver.empty() ? 0 : (int64_t)p.dense_solver.mat_backup().nrows();
   out[7] = p.dense_solver.empty() ? 0 : (int64_t)p.dense_solver.rank();
+  out[10] = 0;
+  if (p.dense_solver.empty() && !p.symm_dense_solver.empty()) {  // is_symm: Prec::symm_dense_solver (SYEIG)
+    out[6] = (int64_t)p.symm_dense_solver.mat_backup().nrows();
+    out[7] = (int64_t)p.symm_dense_solver.rank();
+    out[10] = 1;
+  }
   out[8] = p.E.ncols();  // number of columns of E (== m when nm>0)
   out[9] = p.F.ncols();  // number of columns of F (== nm when present)
 }
@@ -146,6 +155,11 @@ template <class T>
 void level_dense(void *h, int l, T *mat) {
   auto *r = (Ref<T> *)h;
   const auto &pr = *r->lv[l];
+  if (pr.dense_solver.empty()) {  // symmetric branch of Prec::inquire_or_export_dense (Prec.hpp:294-303)
+    const auto &a = pr.symm_dense_solver.mat_backup().array();
+    for (size_t i = 0; i < a.size(); ++i) mat[i] = a[i];
+    return;
+  }
   const auto &a = pr.dense_solver.mat_backup().array();
   for (size_t i = 0; i < a.size(); ++i) mat[i] = a[i];
 }

@@ -124,6 +124,45 @@ int main() {
                 std::get<2>(g1));
     ++failures;
   }
+  // a symmetric factorization (Options::is_symm): the last level is the reference's SYEIG, which attach() ships
+  // through hifamd_set_dense_symm
+  {
+    std::vector<std::ptrdiff_t> ips(1, 0);
+    std::vector<int> cis;
+    std::vector<double> vs;
+    for (int j = 0; j < nx; ++j)
+      for (int i = 0; i < nx; ++i) {
+        const int r = j * nx + i;
+        if (j > 0) cis.push_back(r - nx), vs.push_back(-1.0);
+        if (i > 0) cis.push_back(r - 1), vs.push_back(-1.0);
+        cis.push_back(r), vs.push_back(4.0);
+        if (i + 1 < nx) cis.push_back(r + 1), vs.push_back(-1.0);
+        if (j + 1 < nx) cis.push_back(r + nx), vs.push_back(-1.0);
+        ips.push_back((std::ptrdiff_t)cis.size());
+      }
+    crs_t As(n, n, ips.data(), cis.data(), vs.data(), true);
+    hif::Params ps = hif::DEFAULT_PARAMS;
+    ps.verbose = hif::VERBOSE_NONE;
+    ps.is_symm = 1;
+    ref_t Ms;
+    Ms.factorize(As, ps);
+    hifamd::HIF<double> Gs;
+    Gs.attach(Ms, 64, ps.spd);
+    if (Gs.schur_rank() != Ms.schur_rank() || Gs.schur_size() != Ms.schur_size() || Gs.levels() != Ms.levels()) {
+      std::printf("symmetric hierarchy: queries differ\n");
+      ++failures;
+    }
+    Ms.solve(b, x0);
+    Gs.solve(b, x1);
+    report("is_symm: solve(b, x)", relerr(x1, x0), 1e-12);
+    Ms.solve(b, x0, true);
+    Gs.solve(b, x1, true);
+    report("is_symm: solve(b, x, true)", relerr(x1, x0), 1e-12);
+    Ms.solve(b, x0);
+    Ms.mmultiply(x0, y0);
+    Gs.mmultiply(x0, y1);
+    report("is_symm: mmultiply(x, y)", relerr(y1, y0), 1e-10);
+  }
   // error behaviour: an empty preconditioner throws like the reference does (builder.hpp:412)
   hifamd::HIF<double> E;
   bool threw = false;

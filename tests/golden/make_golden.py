@@ -92,6 +92,17 @@ def convdiff2d(nx, eps=0.05):
     return A
 
 
+def hermitian2d(nx, gamma=0.3):
+    """complex Hermitian: 2-D Laplacian + i*gamma*(skew-symmetric first difference in x)."""
+    I = sp.identity(nx, format="csr")
+    T = sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], shape=(nx, nx), format="csr")
+    S = sp.diags([-1.0, 1.0], [-1, 1], shape=(nx, nx), format="csr")
+    A = (sp.kron(I, T) + sp.kron(T, I)).astype(np.complex128) + 1j * gamma * sp.kron(I, S)
+    A = A.tocsr()
+    A.sort_indices()
+    return A
+
+
 def rhs(n, cplx=False):
     b = np.sin(0.001 * np.arange(n)) + 1.0
     if cplx:
@@ -116,7 +127,7 @@ def save_hier(name, A, params=None, cplx=False):
     XT = np.stack([M.solve(B[:, k].copy(), trans=True) for k in range(4)], axis=1)
     d = dict(nlevels=M.nlevels, A_indptr=A.indptr.astype(np.int64), A_indices=A.indices.astype(np.int32), A_vals=vals,
              b=b, x=x, b2=b2, x_ir4=x_ir4, x_irb=x_irb, irb_status=np.array(st, dtype=np.int32), B4=B, X4=X, xt=xt, XT4=XT,
-             params=np.zeros(5) if params is None else params)
+             params=np.zeros(7) if params is None else params)
     for l, lv in enumerate(M.levels()):
         for k, v in lv.items():
             d[f"L{l}_{k}"] = np.asarray(v)
@@ -138,6 +149,10 @@ def main():
     save_hier("p2d_100_tuned", poisson2d(100), ref.make_params(tau=1e-2, kappa=5.0, alpha=3.0, dense_thres=100))
     save_hier("p3d_12", poisson3d(12), ref.make_params(dense_thres=100))
     save_hier("cd2d_48", convdiff2d(48), ref.make_params(dense_thres=80))
+    # symmetric factorizations (Options::is_symm -> symm_level_factorize; the last level is SYEIG, not QRCP):
+    # a real symmetric multilevel hierarchy and a complex Hermitian one
+    save_hier("p2d_32_symm", poisson2d(32), ref.make_params(dense_thres=60, is_symm=1))
+    save_hier("herm_24_symm", hermitian2d(24), ref.make_params(dense_thres=60, is_symm=1), cplx=True)
     A = scipy.io.mmread(os.path.join(REF, "examples", "demo_inputs", "A.mm")).tocsr()
     save_hier("demo_A", A)  # libhifir/tests/test_real.c:88-146 input
     Z = scipy.io.mmread(os.path.join(REF, "examples", "demo_inputs", "young1c.mtx")).tocsr()

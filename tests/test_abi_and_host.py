@@ -62,11 +62,14 @@ def test_import_validation():
 @pytest.mark.parametrize("name", HIER_NAMES)
 def test_level_schedule_is_valid(name):
     levels, _ = load_hier(name)
-    M = hifir_amd.HIF(dtype=np.complex128 if name == "young1c" else np.float64)
+    M = hifir_amd.HIF(dtype=np.complex128 if np.iscomplexobj(levels[0]["d"]) else np.float64)
     for lv in levels:
         M.add_level(lv)
     if int(levels[-1].get("dense_n", 0)):
-        M.set_dense(levels[-1]["dense"])
+        if int(levels[-1].get("dense_symm", 0)):  # host-side SYEIG: rank as the reference's symm_dense_solver found it
+            M.set_dense_symm(levels[-1]["dense"], int(levels[-1].get("spd", 0)))
+        else:
+            M.set_dense(levels[-1]["dense"])
         assert M.schur_rank() == levels[-1]["dense_rank"]
     for l, lv in enumerate(levels):
         m = lv["m"]
@@ -105,7 +108,7 @@ struct MockCcs { std::vector<long> cs; std::vector<int> ri; std::vector<double> 
 struct MockDense { std::vector<double> a; size_t n = 0; bool empty() const { return true; }
   const MockDense& mat_backup() const { return *this; } size_t nrows() const { return n; } const double* data() const { return a.data(); } };
 struct MockPrec { size_t m = 0, n = 0; MockCcs L_B, U_B, E, F; std::vector<double> d_B, s, t; std::vector<int> p, p_inv, q, q_inv;
-  MockDense dense_solver; };
+  MockDense dense_solver, symm_dense_solver; };
 struct MockHif { std::vector<MockPrec> ps; const std::vector<MockPrec>& precs() const { return ps; } };
 int main() {
   hifamd::HIF<double> G;
@@ -121,7 +124,7 @@ int main() {
     subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-I", inc, str(src)])
 
 
-@pytest.mark.parametrize("name", ["p2d_64_deep", "young1c", "p2d_100_tuned"])
+@pytest.mark.parametrize("name", ["p2d_64_deep", "young1c", "p2d_100_tuned", "p2d_32_symm", "herm_24_symm"])
 def test_hierarchy_file_roundtrip(name, tmp_path):
     # hifamd_save / hifamd_load (host side only: no GPU needed before finalize): the reloaded handle holds
     # the same hierarchy -- same counts, same level schedules -- and a corrupt file is refused
@@ -150,3 +153,15 @@ def test_hierarchy_file_roundtrip(name, tmp_path):
     open(bad, "wb").write(b"garbage!" + raw[8:])
     with pytest.raises(hifir_amd.HifAmdError):
         hifir_amd.HIF.load(bad, max_nrhs=0)
+
+
+def test_host_eigensolver(tmp_path):
+    """herm_eig / dense_factorize_symm of host.hpp (the SYEIG last level's host side) as a plain C++ program."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "eig_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(root, "hifir_amd", "csrc"),
+                           os.path.join(root, "tests", "cpp", "eig_test.cpp"), "-o", exe])
+    out = subprocess.check_output([exe]).decode()
+    assert out.strip().endswith("OK"), out

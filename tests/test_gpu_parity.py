@@ -291,6 +291,29 @@ def test_rank_argument(cache):
         assert relerr(M.solve(d["b"], rank=rank), O.solve(d["b"], rank=rank)) <= TOL
 
 
+@pytest.mark.parametrize("name", ["p2d_32_symm", "herm_24_symm"])
+def test_symmetric_last_level(cache, name):
+    """is_symm hierarchies: the last level is the reference's SYEIG (eigendecomposition with truncation order), for
+    the solve, the conjugate-transpose solve (same operator) and the product, incl. the run-time rank (SYEIG.hpp:187,262)."""
+    levels, d, M, O = _get(cache, name)
+    assert int(levels[-1]["dense_symm"]) == 1 and M.schur_rank() == levels[-1]["dense_rank"] == O.dense_rank
+    b = d["b"]
+    assert relerr(M.solve(b), d["x"]) <= TOL          # the real reference's own x
+    assert relerr(M.solve(b, trans=True), d["xt"]) <= TOL
+    for rank in (0, -1, 5, 40, 10 ** 6):
+        assert relerr(M.solve(b, rank=rank), O.solve(b, rank=rank)) <= TOL
+        assert relerr(M.solve(b, rank=rank, trans=True), O.solve(b, rank=rank, trans=True)) <= TOL
+        assert relerr(M.mmultiply(d["x"], rank=rank), O.mmultiply(d["x"], rank=rank)) <= 1e-10
+        assert relerr(M.mmultiply(d["x"], rank=rank, trans=True), O.mmultiply(d["x"], rank=rank, trans=True)) <= 1e-10
+    # a definite block with the truncation rule of a definite factorization (Options::spd = -1 on the negated block)
+    lv2 = [dict(l) for l in levels]
+    lv2[-1]["dense"] = -np.asarray(lv2[-1]["dense"])
+    lv2[-1]["spd"] = -1
+    M2, O2 = hifir_amd.HIF.from_levels(lv2, max_nrhs=8), orc.Oracle(lv2)
+    assert M2.schur_rank() == O2.dense_rank
+    assert relerr(M2.solve(b), O2.solve(b)) <= TOL
+
+
 def test_error_paths(cache):
     levels, d, M, O = _get(cache, "p2d_5")
     with pytest.raises(hifir_amd.HifAmdError) as e:

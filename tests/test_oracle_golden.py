@@ -27,6 +27,15 @@ def test_dense_known_answer(kat):
     # multiply is the inverse map: A x = b
     bb, _ = orc.qrcp(np.asfortranarray(a).ravel(order="F"), x, op=1)
     assert np.abs(bb - b).max() <= 1e-10 * max(1.0, np.abs(xr).max())
+    # test_syev.cpp / test_heev.cpp drive hif::SYEIG itself (eig.solve): the same vectors pin the restatement of
+    # the symmetric last level (Jacobi eigensolver + truncation + Q f(w) Q^H)
+    if np.abs(a - a.conj().T).max() <= 1e-13:
+        xs, rks, w = orc.syeig(np.asfortranarray(a).ravel(order="F"), b)
+        assert rks == n
+        assert np.abs(xs - xr).max() <= kat["tol"]
+        assert np.abs(np.sort(w) - np.linalg.eigvalsh(a)).max() <= 1e-12 * np.abs(w).max()
+        bs, _, _ = orc.syeig(np.asfortranarray(a).ravel(order="F"), xs, op=1)
+        assert np.abs(bs - b).max() <= 1e-10 * max(1.0, np.abs(xr).max())
 
 
 @pytest.mark.parametrize("name", HIER_NAMES)

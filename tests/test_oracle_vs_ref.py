@@ -117,6 +117,40 @@ def test_fresh_hierarchies(nx, params):
         assert np.array_equal(t0, t1)
 
 
+@pytest.mark.parametrize("kind", ["real", "indefinite", "hermitian", "spd"])
+def test_fresh_symmetric_hierarchies(kind):
+    """is_symm factorizations of the real reference (symm_factor.hpp; last level = SYEIG, small_scale/SYEIG.hpp)
+    against the restatement: solve, conjugate-transpose solve (the same operator), product, run-time rank."""
+    import scipy.sparse as sp
+
+    A = poisson2d(40)
+    spd = 0
+    if kind == "indefinite":
+        A = (A - 1.3 * sp.identity(A.shape[0])).tocsr()
+    elif kind == "hermitian":
+        nx = 40
+        S = sp.diags([-1.0, 1.0], [-1, 1], shape=(nx, nx), format="csr")
+        A = (A.astype(np.complex128) + 0.3j * sp.kron(sp.identity(nx), S)).tocsr()
+    elif kind == "spd":
+        spd = 1
+    A.sort_indices()
+    M = ref.RefHIF(A.indptr, A.indices, A.data, ref.make_params(is_symm=1, spd=spd))
+    levels = M.levels()
+    assert levels[-1].get("dense_symm") == 1 and levels[-1]["dense_n"] > 0
+    O = orc.Oracle(levels)
+    assert O.dense_rank == levels[-1]["dense_rank"]
+    rng = np.random.default_rng(7)
+    b = rng.uniform(-1, 1, A.shape[0])
+    if kind == "hermitian":
+        b = b + 1j * rng.uniform(-1, 1, A.shape[0])
+    x0 = M.solve(b)
+    assert relerr(O.solve(b), x0) <= 1e-11
+    assert relerr(O.solve(b, trans=True), M.solve(b, trans=True)) <= 1e-11
+    assert relerr(O.mmultiply(x0), M.mmultiply(x0)) <= 1e-10
+    assert relerr(O.mmultiply(x0, trans=True), M.mmultiply(x0, trans=True)) <= 1e-10
+    assert relerr(O.solve(b, rank=7), M.solve(b, rank=7)) <= 1e-11
+
+
 @pytest.mark.parametrize("nx,params,rtol,maxit,restart", [(40, None, 1e-10, 200, 30), (100, (1e-2, 5.0, 3.0), 1e-8, 200, 10),
                                                          (100, (1e-2, 5.0, 3.0), 1e-12, 7, 30)])
 def test_gmres_restatement(nx, params, rtol, maxit, restart):

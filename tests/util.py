@@ -5,8 +5,9 @@ import numpy as np
 import scipy.sparse as sp
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-HIER_NAMES = ["p2d_5", "p2d_30", "p2d_64_deep", "p2d_100_tuned", "p3d_12", "cd2d_48", "demo_A", "young1c"]
-LEVEL_KEYS = ["m", "n", "dense_n", "dense_rank", "d", "s", "t", "p", "p_inv", "q", "q_inv", "dense"] + [
+HIER_NAMES = ["p2d_5", "p2d_30", "p2d_64_deep", "p2d_100_tuned", "p3d_12", "cd2d_48", "demo_A", "young1c",
+              "p2d_32_symm", "herm_24_symm"]  # the last two: is_symm factorizations (last level = SYEIG)
+LEVEL_KEYS = ["m", "n", "dense_n", "dense_rank", "dense_symm", "spd", "d", "s", "t", "p", "p_inv", "q", "q_inv", "dense"] + [
     f"{a}_{b}" for a in "LUEF" for b in ("colptr", "rowind", "vals")]
 
 
