@@ -864,16 +864,22 @@ class Engine : public EngineBase {
       const int32_t g0 = M.band_wg_ptr[b], g1 = M.band_wg_ptr[b + 1];
       // the kernel that touches a U row first starts it from w[i] / d[i] (the L kernels no longer write v)
       const int pre = M.band_prefix[b] ? 1 : 0;
+      // block-dense band at R = 64: the prefix pass delivers the rows of the band's first block straight into the
+      // block product's right-hand side (nothing else contributes to them), so that block needs no k_thin_update
+      const int32_t qb0 = M.band_dense[b] ? M.band_blk_ptr[b] : -1;
+      const bool direct = pre && M.band_dense[b] && logR == 6 && qb0 < M.band_blk_ptr[b + 1] &&
+                          M.blk_slot0[(size_t)qb0] == M.band_slot_ptr[b];
       if (pre) {
         const int64_t s0 = M.band_slot_ptr[b], s1 = M.band_slot_ptr[b + 1];
         hipLaunchKernelGGL((k_trsv_wide<D, LOWER, true>), dim3(grid_for(s1 - s0, logR)), dim3(256), 0, st, s0, s1,
                            M.ptr.as<int32_t>(), M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(),
-                           M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR, 1);
+                           M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR, 1, direct ? blk_tmp.as<D>() : (D *)nullptr,
+                           direct ? M.blk_slot1[(size_t)qb0] : 0);
         ++count;
       }
       if (M.band_dense[b]) {  // block by block: sparse update, then ONE dense product per block
         for (int32_t q = M.band_blk_ptr[b]; q < M.band_blk_ptr[b + 1]; ++q)
-          launch_dense_block<LOWER>(st, L, M, q, logR, count);
+          launch_dense_block<LOWER>(st, L, M, q, logR, count, direct && q == qb0);
         continue;
       }
       hipLaunchKernelGGL((k_trsv_band<D, LOWER>), dim3((unsigned)(g1 - g0)), dim3(1024), 0, st, g0,
@@ -890,7 +896,8 @@ class Engine : public EngineBase {
   }
 
   template <bool LOWER>
-  void launch_dense_block(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t q, int logR, int64_t &count);
+  void launch_dense_block(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t q, int logR, int64_t &count,
+                          bool rhs_ready = false);
 
   void launch_ldu(hipStream_t st, DevLevel &L, int logR, int64_t &count) {
     if (!L.m) return;
@@ -1970,13 +1977,14 @@ void Engine<zdouble>::launch_dense_mul(hipStream_t st, const cplx *cin, cplx *zo
 template <>
 template <bool LOWER>
 void Engine<double>::launch_dense_block(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t q, int logR,
-                                        int64_t &count) {
+                                        int64_t &count, bool rhs_ready) {
   const int32_t r0 = M.blk_slot0[(size_t)q], r1 = M.blk_slot1[(size_t)q], nb = r1 - r0;
   double *x = LOWER ? L.w.as<double>() : L.v.as<double>();
   double *tb = blk_tmp.as<double>();
-  hipLaunchKernelGGL((k_thin_update<double>), dim3(grid_for(nb, logR)), dim3(256), 0, st, r0, r1, M.ptr.as<int32_t>(),
-                     M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<double>(), M.srcslot.as<int32_t>(),
-                     M.rowid.as<int32_t>(), (const double *)x, tb, logR);
+  if (!rhs_ready)  // (the first block of a band gets its right-hand side from the prefix pass)
+    hipLaunchKernelGGL((k_thin_update<double>), dim3(grid_for(nb, logR)), dim3(256), 0, st, r0, r1, M.ptr.as<int32_t>(),
+                       M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<double>(), M.srcslot.as<int32_t>(),
+                       M.rowid.as<int32_t>(), (const double *)x, tb, logR);
   const unsigned g = (unsigned)((nb + 15) / 16);
 const unsigned pairs = (g + 1) / 2;
 #define HIFAMD_BLOCK_GEMM(NW)                                                                                   \
@@ -1991,20 +1999,22 @@ const unsigned pairs = (g + 1) / 2;
     HIFAMD_BLOCK_GEMM(4);
   }
 #undef HIFAMD_BLOCK_GEMM
-  count += 2;
+  count += rhs_ready ? 1 : 2;
 }
 
 template <>
 template <bool LOWER>
 void Engine<zdouble>::launch_dense_block(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t q, int logR,
-                                         int64_t &count) {
+                                         int64_t &count, bool rhs_ready) {
   const int32_t r0 = M.blk_slot0[(size_t)q], r1 = M.blk_slot1[(size_t)q], nb = r1 - r0;
   cplx *x = LOWER ? L.w.as<cplx>() : L.v.as<cplx>();
   cplx *tb = blk_tmp.as<cplx>();
-  hipLaunchKernelGGL((k_thin_update<cplx>), dim3(grid_for(nb, logR)), dim3(256), 0, st, r0, r1, M.ptr.as<int32_t>(),
-                     M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<cplx>(), M.srcslot.as<int32_t>(),
-                     M.rowid.as<int32_t>(), (const cplx *)x, tb, logR);
-  ++count;
+  if (!rhs_ready) {
+    hipLaunchKernelGGL((k_thin_update<cplx>), dim3(grid_for(nb, logR)), dim3(256), 0, st, r0, r1, M.ptr.as<int32_t>(),
+                       M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<cplx>(), M.srcslot.as<int32_t>(),
+                       M.rowid.as<int32_t>(), (const cplx *)x, tb, logR);
+    ++count;
+  }
   zgemm_tri(st, nb, M.tinv.as<double>() + M.blk_inv_off[(size_t)q], (const cplx *)tb, logR, M.rowid.as<int32_t>() + r0, x,
             (const cplx *)nullptr, (cplx *)nullptr, count);
 }

@@ -571,18 +571,51 @@ double build_dense_block(const BandPlan &P, const Csr<T> &A, size_t q, double *o
 }
 
 template <class T>
-void finish_band_plan(BandPlan &P, const Csr<T> &A /* rows in slot order */) {
+void finish_band_plan(BandPlan &P, Csr<T> &A /* rows in slot order */) {
   const int64_t m = A.nrows;
   std::vector<int32_t> slot_of((size_t)m);
   for (int64_t s = 0; s < m; ++s) slot_of[(size_t)A.rowid[(size_t)s]] = (int32_t)s;
   P.srcslot.resize(A.col.size());
   for (size_t k = 0; k < A.col.size(); ++k) P.srcslot[k] = slot_of[(size_t)A.col[k]];
   P.split.resize((size_t)m);
+  std::vector<int32_t> idx, tcol, tsrc;
+  std::vector<T> tval;
   for (int64_t b = 0; b < P.nbands(); ++b) {
     const int32_t band0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b]]];
     for (int32_t g = P.band_wg_ptr[(size_t)b]; g < P.band_wg_ptr[(size_t)b + 1]; ++g) {
       const int32_t s0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]], s1 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]];
       for (int32_t s = s0; s < s1; ++s) {
+        // Block-dense bands (fast mode only; their summation order differs from the reference's anyway):
+        // a row lists ALL nonzeros whose sources were finished before the band first (relative order kept),
+        // so that the chip-wide prefix pass folds every one of them in and [split, end) holds in-band
+        // sources only.  The rows of the band's first block then need nothing but that prefix before their
+        // block product (Engine::launch_trsv delivers it straight into the product's right-hand side).
+        if (P.band_dense[(size_t)b]) {
+          const int32_t k0 = A.ptr[(size_t)s], k1 = A.ptr[(size_t)s + 1];
+          idx.clear();
+          for (int32_t k = k0; k < k1; ++k)
+            if (P.srcslot[(size_t)k] < s0) idx.push_back(k);
+          const size_t npre = idx.size();
+          bool moved = false;
+          for (size_t q = 0; q < npre; ++q) moved = moved || idx[q] != k0 + (int32_t)q;
+          if (moved) {
+            for (int32_t k = k0; k < k1; ++k)
+              if (P.srcslot[(size_t)k] >= s0) idx.push_back(k);
+            tcol.resize(idx.size());
+            tsrc.resize(idx.size());
+            tval.resize(idx.size());
+            for (size_t q = 0; q < idx.size(); ++q) {
+              tcol[q] = A.col[(size_t)idx[q]];
+              tsrc[q] = P.srcslot[(size_t)idx[q]];
+              tval[q] = A.val[(size_t)idx[q]];
+            }
+            for (size_t q = 0; q < idx.size(); ++q) {
+              A.col[(size_t)k0 + q] = tcol[q];
+              P.srcslot[(size_t)k0 + q] = tsrc[q];
+              A.val[(size_t)k0 + q] = tval[q];
+            }
+          }
+        }
         int32_t kk = A.ptr[(size_t)s];
         if (P.band_prefix[(size_t)b])
           while (kk < A.ptr[(size_t)s + 1] && P.srcslot[(size_t)kk] < s0) ++kk;

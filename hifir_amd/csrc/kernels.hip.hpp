@@ -228,7 +228,8 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
                                                 const T *__restrict__ val, const int32_t *__restrict__ srcslot,
                                                 const int32_t *__restrict__ rowid, const T *__restrict__ d, T *x,
                                                 const T *__restrict__ rhs_u, int lane, int *flag, int32_t slot0,
-                                                unsigned *errflag, bool first_u HIFAMD_PROBE_ARG) {
+                                                unsigned *errflag, bool first_u, T *tb = nullptr, int32_t tb_s0 = 0,
+                                                int32_t tb_s1 = 0 HIFAMD_PROBE_ARG) {
   int32_t s = rfl(s_first);
   if (s >= s_end) return true;
 #ifdef HIFAMD_PROBE
@@ -356,7 +357,13 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
     }
     if (row_done) {
       HIFAMD_STAMP(2)
-      x[((int64_t)i_c << 6) + lane] = acc;
+      // PREFIX pass of a block-dense band: the rows of the band's FIRST block have no other contribution
+      // before their block product, so their partial sums go straight into the product's right-hand side
+      // (saves that block's k_thin_update launch)
+      if (PREFIX && tb && s < tb_s1)
+        tb[((int64_t)(s - tb_s0) << 6) + lane] = acc;
+      else
+        x[((int64_t)i_c << 6) + lane] = acc;
       if (MODE == 2) {  // release: the row's stores (all 64 lanes) are complete before its flag goes up
         if (lane == 0) __hip_atomic_store(&flag[s - slot0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
@@ -394,14 +401,15 @@ __global__ void __launch_bounds__(256) k_trsv_wide(int64_t s0, int64_t s1, const
                                                    const int32_t *__restrict__ col,
                                                    const T *__restrict__ val,
                                                    const int32_t *__restrict__ rowid,
-                                                   const T *__restrict__ d, T *w, T *v, int logR, int first_u) {
+                                                   const T *__restrict__ d, T *w, T *v, int logR, int first_u,
+                                                   T *tb, int32_t tb_s1) {
   const LaneMap lm = lane_map(logR);
   const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  if (logR == 6) {
+  if (logR == 6) {  // (tb: R = 64 only; rows [s0, tb_s1) deliver their result to tb, see trsv_stream_r64)
     trsv_stream_r64<T, 0, LOWER, PREFIX>((int32_t)(s0 + wave), (int32_t)s1, (int32_t)nwaves, ptr, split, col, val,
                                          nullptr, rowid, d, LOWER ? w : v, w, threadIdx.x & 63, nullptr, 0, nullptr,
-                                         first_u != 0);
+                                         first_u != 0, tb, (int32_t)s0, tb_s1);
     return;
   }
   for (int64_t slot = s0 + wave * lm.G + lm.g; slot < s1; slot += nwaves * lm.G)
@@ -455,7 +463,7 @@ __global__ void __launch_bounds__(1024) k_trsv_band(int32_t wg0, const int32_t *
 #ifdef HIFAMD_PROBE
     if (tsw && lane == 0) tsw[2] = wall_clock64();
     trsv_stream_r64<T, 2, LOWER, false>(slot0 + wave, slot1, nw, ptr, split, col, val, srcslot, rowid, d, x, w, lane,
-                                        flag, slot0, errflag, first_u != 0, tsw);
+                                        flag, slot0, errflag, first_u != 0, nullptr, 0, 0, tsw);
     if (tsw && lane == 0) tsw[3] = wall_clock64();
 #else
     trsv_stream_r64<T, 2, LOWER, false>(slot0 + wave, slot1, nw, ptr, split, col, val, srcslot, rowid, d, x, w, lane,
