@@ -24,6 +24,7 @@ SIGNATURES = {
     "hifamd_load": (_int, [C.c_char_p, _int, C.POINTER(_vp)]),
     "hifamd_set_dense": (_int, [_vp, _i64, _vp, _dbl]),
     "hifamd_set_dense_symm": (_int, [_vp, _i64, _vp, _int]),
+    "hifamd_set_dense_lup": (_int, [_vp, _i64, _vp]),
     "hifamd_finalize": (_int, [_vp, _i64]),
     "hifamd_nrows": (_i64, [_vp]),
     "hifamd_levels": (_i64, [_vp]),

@@ -208,6 +208,7 @@ struct DevLevel {
 struct DevDense {
   int64_t n = 0, rank = 0;
   bool symm = false;  // SYEIG last level: QH = diag(1/w) V^H, Qm = V (truncation order), Rm = diag(w) V^H
+  bool lup = false;   // LUP last level: QH = A^{-1} (adjoint engine: its transpose), Rm = A (adjoint: A^H)
   DevBuf QH, Rinv, jpvt0, tmp;
   DevBuf Qm, RinvH, tmp2;  // adjoint engine only: Q, (R^{-1})^H and the permuted input
   DevBuf Rm;               // product only: R (primary engine, upper) or R^H (adjoint engine, lower)
@@ -498,7 +499,16 @@ class Engine : public EngineBase {
       E->band_opt = band_opt;
       E->gemm_waves = gemm_waves;
       for (const auto &P : host.levels) E->add_level_adjoint(P);
-      if (host.has_dense && host.dense.kind == 1) {
+      if (host.has_dense && host.dense.kind == 2) {  // LUP: ?getrs 'T' / ?gemv 'C' (LUP.hpp:150,187)
+        E->host.dense.kind = 2;
+        E->host.dense.n = host.dense.n;
+        E->host.dense.rank = host.dense.rank;
+        E->host.dense.mat = host.dense.mat;
+        E->host.dense.qr = host.dense.qr;
+        E->host.dense.jpvt0 = host.dense.jpvt0;
+        dense_lup_ops(E->host.dense, true);
+        E->host.has_dense = true;
+      } else if (host.has_dense && host.dense.kind == 1) {
         // Hermitian last level: the conjugate-transpose solve IS the solve (prec_solve.hpp:583-584)
         E->host.dense.kind = 1;
         E->host.dense.spd = host.dense.spd;
@@ -563,6 +573,7 @@ class Engine : public EngineBase {
       E->dn.n = dn.n;
       E->dn.rank = dn.rank;
       E->dn.symm = dn.symm;
+      E->dn.lup = dn.lup;
       E->dn.QH.alias(dn.QH);
       E->dn.Rinv.alias(dn.Rinv);
       E->dn.jpvt0.alias(dn.jpvt0);
@@ -637,6 +648,17 @@ class Engine : public EngineBase {
     if (nd != last.n - last.m) throw Error(HIFAMD_MISMATCHED_SIZES, "dense block size must be n-m of the last level");
     if (!mat) throw Error(HIFAMD_NULL_OBJ, "NULL dense block");
     dense_factorize(host.dense, mat, nd, rrqr_cond);
+    host.has_dense = true;
+  }
+
+  // LU last level of a reference built with HIF_DENSE_MODE=0 (small_scale/LUP.hpp)
+  void set_dense_lup(int64_t nd, const T *mat) {
+    if (finalized) throw Error(HIFAMD_BAD_PREC, "hierarchy already finalized");
+    if (host.levels.empty()) throw Error(HIFAMD_BAD_PREC, "add the sparse levels before the dense block");
+    const auto &last = host.levels.back();
+    if (nd != last.n - last.m) throw Error(HIFAMD_MISMATCHED_SIZES, "dense block size must be n-m of the last level");
+    if (!mat) throw Error(HIFAMD_NULL_OBJ, "NULL dense block");
+    dense_factorize_lup(host.dense, mat, nd);
     host.has_dense = true;
   }
 
@@ -722,7 +744,14 @@ class Engine : public EngineBase {
 
       lv.push_back(std::move(Lp));
     }
-    if (host.has_dense && host.dense.kind == 1) {
+    if (host.has_dense && host.dense.kind == 2) {
+      dn.n = host.dense.n;
+      dn.rank = host.dense.rank;
+      dn.lup = true;
+      dn.QH.upload(mfma_operand(host.dense.QH.data(), dn.n, dn.n));
+      std::vector<T>().swap(host.dense.QH);
+      std::vector<T>().swap(host.dense.SymMul);
+    } else if (host.has_dense && host.dense.kind == 1) {
       dn.n = host.dense.n;
       dn.rank = host.dense.rank;
       dn.symm = true;
@@ -1010,7 +1039,13 @@ class Engine : public EngineBase {
       L.pc.alloc(bytes);
       L.pr.alloc(bytes);
     }
-    if (host.has_dense && host.dense.kind == 1) {  // SYEIG::multiply: V diag(w) V^H (SYEIG.hpp:256-273), either engine
+    if (host.has_dense && host.dense.kind == 2) {  // LUP::multiply: the unfactored block itself (LUP.hpp:181-188)
+      HostDense<T> &Dn = host.dense;
+      dense_lup_ops(Dn, adjoint);
+      dn.Rm.upload(mfma_operand(Dn.SymMul.data(), Dn.n, Dn.n));
+      std::vector<T>().swap(Dn.QH);
+      std::vector<T>().swap(Dn.SymMul);
+    } else if (host.has_dense && host.dense.kind == 1) {  // SYEIG::multiply: V diag(w) V^H (SYEIG.hpp:256-273), either engine
       HostDense<T> &Dn = host.dense;
       dense_symm_ops(Dn);
       dn.Rm.upload(mfma_operand(Dn.SymMul.data(), Dn.n, Dn.n));
@@ -1671,7 +1706,7 @@ class Engine : public EngineBase {
   }
   void save(std::FILE *f) const {
     if (adjoint || is_twin) throw Error(HIFAMD_HIFIR_ERROR, "internal engines are not saved");
-    const int64_t nl = (int64_t)host.levels.size(), hd = host.has_dense ? (host.dense.kind == 1 ? 2 : 1) : 0;
+    const int64_t nl = (int64_t)host.levels.size(), hd = host.has_dense ? (host.dense.kind == 2 ? 3 : host.dense.kind == 1 ? 2 : 1) : 0;
     if (std::fwrite(&nl, 8, 1, f) != 1 || std::fwrite(&hd, 8, 1, f) != 1) throw Error(HIFAMD_HIFIR_ERROR, "short write");
     for (const auto &H : host.levels) {
       const int64_t hdr[3] = {H.m, H.n, H.F_ncols};
@@ -1733,7 +1768,9 @@ class Engine : public EngineBase {
       std::vector<T> mat;
       get_vec(f, mat);
       if ((int64_t)mat.size() != nd * nd) throw Error(HIFAMD_BAD_PREC, "inconsistent hierarchy file");
-      if (hd == 2)
+      if (hd == 3)
+        set_dense_lup(nd, mat.data());
+      else if (hd == 2)
         set_dense_symm(nd, mat.data(), (int)cond);
       else
         set_dense(nd, mat.data(), cond);
@@ -1861,6 +1898,13 @@ void Engine<double>::launch_dense(hipStream_t st, const double *cin, double *zou
   const int nd = (int)dn.n, rk = (int)eff_rank(rank);
   const unsigned g = (unsigned)((nd + 15) / 16);  // one workgroup per 16-row strip (4 waves split K)
   double *tmp = dn.tmp.as<double>();
+  if (dn.lup) {  // LUP::solve (LUP.hpp:141-152): ?getrs, here one product with the explicit inverse; rank is ignored
+    hipLaunchKernelGGL(k_dense_gemm_d<4>, dim3(g, ((1u << logR) + 15) / 16), dim3(256), 0, st, nd, nd, nd, 0,
+                       dn.QH.as<double>(), nd, cin, logR, (const int32_t *)nullptr, zout, (const double *)nullptr,
+                       (double *)nullptr);
+    ++count;
+    return;
+  }
   if (dn.symm) {  // SYEIG::solve (SYEIG.hpp:181-200): z = V(:,to(1:rk)) diag(1/w) V(:,to(1:rk))^H c
     hipLaunchKernelGGL(k_dense_gemm_d<4>, dim3(g, ((1u << logR) + 15) / 16), dim3(256), 0, st, nd, rk, nd, 0,
                        dn.QH.as<double>(), nd, cin, logR, (const int32_t *)nullptr, tmp, (const double *)nullptr,
@@ -1898,6 +1942,10 @@ template <>
 void Engine<zdouble>::launch_dense(hipStream_t st, const cplx *cin, cplx *zout, int logR, int64_t rank, int64_t &count) {
   const int nd = (int)dn.n, rk = (int)eff_rank(rank);
   cplx *tmp = dn.tmp.as<cplx>();
+  if (dn.lup) {
+    zgemm(st, nd, nd, nd, 0, dn.QH, nd, cin, logR, nullptr, zout, nullptr, nullptr, count);
+    return;
+  }
   if (dn.symm) {
     zgemm(st, nd, rk, nd, 0, dn.QH, nd, cin, logR, nullptr, tmp, nullptr, nullptr, count);
     zgemm(st, nd, nd, rk, 0, dn.Qm, nd, tmp, logR, nullptr, zout, nullptr, nullptr, count);
@@ -1924,6 +1972,12 @@ void Engine<double>::launch_dense_mul(hipStream_t st, const double *cin, double 
   const unsigned g = (unsigned)((nd + 15) / 16);
   const dim3 grid(g, ((1u << logR) + 15) / 16);
   double *tmp = dn.tmp.as<double>();
+  if (dn.lup) {  // LUP::multiply (LUP.hpp:181-188): z = A c (adjoint engine: A^H c)
+    hipLaunchKernelGGL(k_dense_gemm_d<4>, grid, dim3(256), 0, st, nd, nd, nd, 0, dn.Rm.as<double>(), nd, cin, logR,
+                       (const int32_t *)nullptr, zout, (const double *)nullptr, (double *)nullptr);
+    ++count;
+    return;
+  }
   if (dn.symm) {  // SYEIG::multiply (SYEIG.hpp:256-273): z = V(:,to(1:rk)) diag(w) V(:,to(1:rk))^H c
     hipLaunchKernelGGL(k_dense_gemm_d<4>, grid, dim3(256), 0, st, nd, rk, nd, 0, dn.Rm.as<double>(), nd, cin, logR,
                        (const int32_t *)nullptr, tmp, (const double *)nullptr, (double *)nullptr);
@@ -1954,6 +2008,10 @@ template <>
 void Engine<zdouble>::launch_dense_mul(hipStream_t st, const cplx *cin, cplx *zout, int logR, int64_t rank, int64_t &count) {
   const int nd = (int)dn.n, rk = (int)eff_rank(rank);
   cplx *tmp = dn.tmp.as<cplx>();
+  if (dn.lup) {
+    zgemm(st, nd, nd, nd, 0, dn.Rm, nd, cin, logR, nullptr, zout, nullptr, nullptr, count);
+    return;
+  }
   if (dn.symm) {
     zgemm(st, nd, rk, nd, 0, dn.Rm, nd, cin, logR, nullptr, tmp, nullptr, nullptr, count);
     zgemm(st, nd, nd, rk, 0, dn.Qm, nd, tmp, logR, nullptr, zout, nullptr, nullptr, count);
@@ -2270,6 +2328,12 @@ HifAmdStatus hifamd_set_dense(HifAmdHdl h, int64_t nd, const void *mat, double r
 HifAmdStatus hifamd_set_dense_symm(HifAmdHdl h, int64_t nd, const void *mat, int spd) {
   API_BEGIN
   DISPATCH(ENG_D->set_dense_symm(nd, (const double *)mat, spd), ENG_Z->set_dense_symm(nd, (const zdouble *)mat, spd))
+  API_END
+}
+
+HifAmdStatus hifamd_set_dense_lup(HifAmdHdl h, int64_t nd, const void *mat) {
+  API_BEGIN
+  DISPATCH(ENG_D->set_dense_lup(nd, (const double *)mat), ENG_Z->set_dense_lup(nd, (const zdouble *)mat))
   API_END
 }
 

@@ -67,6 +67,8 @@ inline double abs_(double x) { return std::fabs(x); }
 inline double abs_(const zdouble &x) { return std::abs(x); }
 inline double conj_(double x) { return x; }
 inline zdouble conj_(const zdouble &x) { return std::conj(x); }
+inline double abs1_(double x) { return std::fabs(x); }
+inline double abs1_(const zdouble &x) { return std::fabs(x.real()) + std::fabs(x.imag()); }  // BLAS i?amax measure
 inline double real_(double x) { return x; }
 inline double real_(const zdouble &x) { return x.real(); }
 
@@ -691,6 +693,9 @@ struct HostDense {
   // A = V diag(w) V^H, truncated in the order `trunc`.  The device then reuses the two dense operators:
   //   QH := diag(1/w) V^H with rows in truncation order,  Q := V with columns in truncation order
   // (solve = Q(:,1:rk) * (QH(1:rk,:) c)); SymMul := diag(w) V^H (rows in truncation order) for the product.
+  // kind = 2: the reference built with HIF_DENSE_MODE=0 uses LU with partial pivoting (small_scale/LUP.hpp)
+  // for the last level: QH := A^{-1} (on the adjoint engine its plain transpose: LUP::solve passes 'T' to
+  // ?getrs also for complex data, LUP.hpp:150), SymMul := A (adjoint: A^H, ?gemv 'C', LUP.hpp:187) for the product.
   int kind = 0, spd = 0;
   std::vector<double> w;
   std::vector<int32_t> trunc;
@@ -1188,6 +1193,90 @@ void dense_factorize_symm(HostDense<T> &D, const T *mat_colmajor, int64_t n, int
   }
   D.rank = rank;
   dense_symm_ops(D);
+}
+
+// LUP::factorize (LUP.hpp:100-119: ?getrf) followed by the explicit inverse (column j = solution of A x = e_j by
+// the ?getrs sequence: row interchanges, unit-lower forward sweep, upper backward sweep).  A: column-major n x n,
+// overwritten by its LU factors; ipiv 0-based.  Returns the 1-based index of the first exactly zero pivot, else 0.
+template <class T>
+int64_t lu_partial_pivot(int64_t n, std::vector<T> &A, std::vector<int32_t> &ipiv) {
+  ipiv.assign((size_t)n, 0);
+  int64_t info = 0;
+  for (int64_t k = 0; k < n; ++k) {
+    int64_t pv = k;
+    double best = abs1_(A[(size_t)(k + k * n)]);
+    for (int64_t i = k + 1; i < n; ++i) {  // ?getf2 / i?amax: largest |re| + |im| (complex) or |x| (real)
+      const double a = abs1_(A[(size_t)(i + k * n)]);
+      if (a > best) best = a, pv = i;
+    }
+    ipiv[(size_t)k] = (int32_t)pv;
+    if (A[(size_t)(pv + k * n)] == T(0)) {
+      if (!info) info = k + 1;
+      continue;
+    }
+    if (pv != k)
+      for (int64_t j = 0; j < n; ++j) std::swap(A[(size_t)(k + j * n)], A[(size_t)(pv + j * n)]);
+    const T piv = A[(size_t)(k + k * n)];
+    for (int64_t i = k + 1; i < n; ++i) A[(size_t)(i + k * n)] /= piv;
+    parallel_for(n - k - 1, 32, [&](int64_t j0, int64_t j1) {
+      for (int64_t jj = j0; jj < j1; ++jj) {
+        const int64_t j = k + 1 + jj;
+        const T ukj = A[(size_t)(k + j * n)];
+        if (ukj == T(0)) continue;
+        T *c = &A[(size_t)(j * n)];
+        const T *l = &A[(size_t)(k * n)];
+        for (int64_t i = k + 1; i < n; ++i) c[i] -= l[i] * ukj;
+      }
+    });
+  }
+  return info;
+}
+
+template <class T>
+void dense_lup_ops(HostDense<T> &D, bool adjoint) {
+  const int64_t n = D.n;
+  const T *LU = D.qr.data();
+  std::vector<T> inv((size_t)(n * n), T(0));
+  parallel_for(n, 8, [&](int64_t j0, int64_t j1) {
+    for (int64_t j = j0; j < j1; ++j) {
+      T *x = &inv[(size_t)(j * n)];
+      x[j] = T(1);
+      for (int64_t k = 0; k < n; ++k)
+        if (D.jpvt0[(size_t)k] != k) std::swap(x[k], x[D.jpvt0[(size_t)k]]);
+      for (int64_t k = 0; k < n; ++k) {  // L y = P e_j
+        const T xk = x[k];
+        if (xk == T(0)) continue;
+        const T *l = LU + k * n;
+        for (int64_t i = k + 1; i < n; ++i) x[i] -= l[i] * xk;
+      }
+      for (int64_t k = n - 1; k >= 0; --k) {  // U x = y
+        x[k] /= LU[k + k * n];
+        const T xk = x[k];
+        const T *u = LU + k * n;
+        for (int64_t i = 0; i < k; ++i) x[i] -= u[i] * xk;
+      }
+    }
+  });
+  D.QH.assign((size_t)(n * n), T(0));
+  D.SymMul.assign((size_t)(n * n), T(0));
+  for (int64_t j = 0; j < n; ++j)
+    for (int64_t i = 0; i < n; ++i) {
+      D.QH[(size_t)(i + j * n)] = adjoint ? inv[(size_t)(j + i * n)] : inv[(size_t)(i + j * n)];  // 'T', not 'C'
+      D.SymMul[(size_t)(i + j * n)] = adjoint ? conj_(D.mat[(size_t)(j + i * n)]) : D.mat[(size_t)(i + j * n)];
+    }
+}
+
+template <class T>
+void dense_factorize_lup(HostDense<T> &D, const T *mat_colmajor, int64_t n) {
+  D.kind = 2;
+  D.n = n;
+  D.mat.assign(mat_colmajor, mat_colmajor + n * n);
+  D.qr.assign(mat_colmajor, mat_colmajor + n * n);
+  const int64_t info = lu_partial_pivot(n, D.qr, D.jpvt0);
+  if (info)  // LUP::factorize only warns (rank = info - 1) and ?getrs would then divide by zero (LUP.hpp:108-116)
+    throw Error(3, "dense block is exactly singular (zero pivot in the LU factorization): use the QRCP last level");
+  D.rank = n;
+  dense_lup_ops(D, false);
 }
 
 template <class T>

@@ -75,7 +75,9 @@ class HIF:
             self.add_level(lv)
         last = levels[-1]
         if int(last.get("dense_n", 0)) > 0:
-            if int(last.get("dense_symm", 0)):
+            if int(last.get("dense_lup", 0)):
+                self.set_dense_lup(last["dense"])
+            elif int(last.get("dense_symm", 0)):
                 self.set_dense_symm(last["dense"], int(last.get("spd", 0)))
             else:
                 self.set_dense(last["dense"], rrqr_cond)
@@ -129,6 +131,12 @@ class HIF:
         mat = np.ascontiguousarray(mat_colmajor, dtype=self.dtype).ravel()
         nd = int(round(np.sqrt(mat.size)))
         _check(lib().hifamd_set_dense_symm(self._h, nd, _p(mat), int(spd)))
+
+    def set_dense_lup(self, mat_colmajor):
+        """Last level of a reference built with HIF_DENSE_MODE=0 (LU with partial pivoting, small_scale/LUP.hpp)."""
+        mat = np.ascontiguousarray(mat_colmajor, dtype=self.dtype).ravel()
+        nd = int(round(np.sqrt(mat.size)))
+        _check(lib().hifamd_set_dense_lup(self._h, nd, _p(mat)))
 
     def finalize(self, max_nrhs=64):
         _check(lib().hifamd_finalize(self._h, int(max_nrhs)))

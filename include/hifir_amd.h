@@ -93,6 +93,12 @@ HifAmdStatus hifamd_set_dense(HifAmdHdl h, int64_t nd, const void *mat_colmajor,
  * (Options::spd).  Only the lower triangle is read.  Solve, conjugate-transpose solve and product follow
  * SYEIG::solve / multiply (SYEIG.hpp:181-200, 256-273), incl. the run-time `rank` argument. */
 HifAmdStatus hifamd_set_dense_symm(HifAmdHdl h, int64_t nd, const void *mat_colmajor, int spd);
+/* The same block when the reference was built with HIF_DENSE_MODE=0 (macros.hpp:100-105, small_scale/solver.hpp:49):
+ * its last level is then LU with partial pivoting (small_scale/LUP.hpp).  Factorized here on the host
+ * (?getrf semantics, LUP::factorize :100-119) and applied as one product with the explicit inverse; the `rank`
+ * argument is ignored as in LUP::solve (:141), the conjugate-transpose apply passes 'T' to the solve and 'C' to the
+ * product exactly like LUP.hpp:150,187.  An exactly singular block is refused (HIFAMD_BAD_PREC). */
+HifAmdStatus hifamd_set_dense_lup(HifAmdHdl h, int64_t nd, const void *mat_colmajor);
 /* Converts CCS -> schedule-ordered CSR, level-schedules the triangular factors, ships everything to
  * HBM and sizes the work arena for batches of up to max_nrhs (the reference sizes its work buffer
  * on first use only, builder.hpp:414-416 -- not replicated). */

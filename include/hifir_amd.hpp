@@ -22,6 +22,7 @@
 #include <complex>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -93,7 +94,10 @@ class HIF {
                                        p.d_B.data(), ss.data(), tt.data(), pp.data(), pi.data(), qq.data(), qi.data()));
         if (!p.dense_solver.empty()) {  // the UNFACTORED block, Prec::inquire_or_export_dense (Prec.hpp:275-293)
           const auto &D = p.dense_solver.mat_backup();
-          detail::check(hifamd_set_dense(_h, (std::int64_t)D.nrows(), D.data(), 0.0));
+          if (std::strcmp(p.dense_solver.method(), "LUP") == 0)  // reference built with HIF_DENSE_MODE=0
+            detail::check(hifamd_set_dense_lup(_h, (std::int64_t)D.nrows(), D.data()));
+          else
+            detail::check(hifamd_set_dense(_h, (std::int64_t)D.nrows(), D.data(), 0.0));
         } else if (!p.symm_dense_solver.empty()) {  // is_symm factorizations (symm_factor.hpp:654-657): SYEIG
           const auto &D = p.symm_dense_solver.mat_backup();
           detail::check(hifamd_set_dense_symm(_h, (std::int64_t)D.nrows(), D.data(), spd));

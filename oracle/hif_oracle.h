@@ -38,6 +38,8 @@ extern "C" {
   int orc_##P##_set_dense(void *h, int64_t nd, const T *mat, double rrqr_cond);                     \
   /* the same block of an is_symm hierarchy (Prec::symm_dense_solver): SYEIG (small_scale/SYEIG.hpp) */ \
   int orc_##P##_set_dense_symm(void *h, int64_t nd, const T *mat, int spd);                         \
+  /* ... and of a reference built with HIF_DENSE_MODE=0: LU with partial pivoting (small_scale/LUP.hpp) */ \
+  int orc_##P##_set_dense_lup(void *h, int64_t nd, const T *mat);                                   \
   int64_t orc_##P##_dense_rank(void *h);                                                            \
   int64_t orc_##P##_work_size(void *h);                                                             \
   int orc_##P##_solve(void *h, const T *b, T *x, int64_t rank);                                     \
@@ -68,7 +70,9 @@ extern "C" {
                      int64_t rank_in, T *x, int64_t *rank_out);                                     \
   /* symmetric dense block alone: SYEIG factor + (op 0) solve / (op 1) multiply */                  \
   int orc_##P##_syeig(int64_t n, const T *mat, int spd, int op, const T *b, int64_t rank_in, T *x,  \
-                      int64_t *rank_out, double *w_out);
+                      int64_t *rank_out, double *w_out);                                            \
+  /* LU block alone: (op 0) solve / (op 1) multiply / (op 2) solve 'T' / (op 3) multiply 'C' */     \
+  int orc_##P##_lup(int64_t n, const T *mat, int op, const T *b, T *x);
 
 ORC_DECL(d, double)
 #ifndef __cplusplus

@@ -38,6 +38,8 @@ def lib():
             g("set_level").argtypes = [vp, C.c_int, C.c_int64, C.c_int64] + [vp] * 9 + [C.c_int64] + [vp] * 10
             g("set_dense").argtypes = [vp, C.c_int64, vp, C.c_double]
             g("set_dense_symm").argtypes = [vp, C.c_int64, vp, C.c_int]
+            g("set_dense_lup").argtypes = [vp, C.c_int64, vp]
+            g("lup").argtypes = [C.c_int64, vp, C.c_int, vp, vp]
             g("syeig").argtypes = [C.c_int64, vp, C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp]
             g("dense_rank").argtypes = [vp]
             g("dense_rank").restype = C.c_int64
@@ -98,7 +100,9 @@ class Oracle:
         last = levels[-1]
         if int(last.get("dense_n", 0)) > 0:
             mat = np.ascontiguousarray(last["dense"], dtype=self.dtype).ravel()
-            if int(last.get("dense_symm", 0)):  # is_symm hierarchy: Prec::symm_dense_solver (SYEIG)
+            if int(last.get("dense_lup", 0)):  # reference built with HIF_DENSE_MODE=0: LUP last level
+                self._f("set_dense_lup")(self.h, int(last["dense_n"]), _p(mat))
+            elif int(last.get("dense_symm", 0)):  # is_symm hierarchy: Prec::symm_dense_solver (SYEIG)
                 self._f("set_dense_symm")(self.h, int(last["dense_n"]), _p(mat), int(last.get("spd", 0)))
             else:
                 self._f("set_dense")(self.h, int(last["dense_n"]), _p(mat), float(rrqr_cond))
@@ -191,6 +195,17 @@ def qrcp(mat_colmajor, b, op=0, rank=0, rrqr_cond=0.0):
     rk = np.zeros(1, dtype=np.int64)
     getattr(lib(), f"orc_{k}_qrcp")(len(b), _p(mat), rrqr_cond, op, _p(b), rank, _p(x), _p(rk))
     return x, int(rk[0])
+
+
+def lup(mat_colmajor, b, op=0):
+    """LUP (small_scale/LUP.hpp) on one block: op 0 solve, 1 multiply, 2 solve 'T', 3 multiply 'C'. Returns (x, info)."""
+    k = _kind(mat_colmajor, b)
+    dt = np.complex128 if k == "z" else np.float64
+    mat = np.ascontiguousarray(mat_colmajor, dtype=dt).ravel()
+    b = np.ascontiguousarray(b, dtype=dt)
+    x = np.zeros_like(b)
+    info = getattr(lib(), f"orc_{k}_lup")(len(b), _p(mat), op, _p(b), _p(x))
+    return x, int(info)
 
 
 def syeig(mat_colmajor, b, op=0, rank=0, spd=0):

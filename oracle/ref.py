@@ -11,17 +11,35 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PATH = os.path.join(_HERE, "_ref", "libhifref.so")
+_PATH_LUP = os.path.join(_HERE, "_ref", "libhifref_lup.so")  # the same reference built with HIF_DENSE_MODE=0
 
 
 def available():
     return os.path.exists(_PATH)
 
 
+def available_lup():
+    return os.path.exists(_PATH_LUP)
+
+
 _lib = None
+_lib_lup = None
 
 
-def lib():
-    global _lib
+def lib(lup=False):
+    """lup=True: the reference compiled with -DHIF_DENSE_MODE=0, whose last level is LU with partial pivoting
+    (small_scale/LUP.hpp) instead of QRCP."""
+    global _lib, _lib_lup
+    if lup:
+        if _lib_lup is None:
+            keep, _lib = _lib, None
+            globals()["_PATH"], path0 = _PATH_LUP, _PATH
+            try:
+                _lib_lup = lib()
+            finally:
+                globals()["_PATH"] = path0
+                _lib = keep
+        return _lib_lup
     if _lib is None:
         _lib = C.CDLL(_PATH)
         vp, i64p, i32p, dp = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p
@@ -64,7 +82,8 @@ def make_params(tau=0.0, kappa=0.0, alpha=0.0, dense_thres=0, rrqr_cond=0.0, is_
 class RefHIF:
     """The reference's hif::HIF<double|complex<double>, int> behind ctypes."""
 
-    def __init__(self, indptr, indices, vals, params=None):
+    def __init__(self, indptr, indices, vals, params=None, lup=False):
+        self.lup = bool(lup)
         vals = np.ascontiguousarray(vals)
         self.k = "z" if np.iscomplexobj(vals) else "d"
         self.dtype = np.complex128 if self.k == "z" else np.float64
@@ -75,13 +94,13 @@ class RefHIF:
         self.params = None if params is None else np.ascontiguousarray(params, dtype=np.float64)
         if self.params is not None and len(self.params) < 7:  # (older 5-entry parameter arrays)
             self.params = np.concatenate([self.params, np.zeros(7 - len(self.params))])
-        L = lib()
+        L = lib(self.lup)
         self.h = getattr(L, f"hifref_{self.k}_factorize")(self.n, _p(self.indptr), _p(self.indices), _p(self.vals), _p(self.params))
         if not self.h:
             raise RuntimeError("reference factorize failed: " + L.hifref_error().decode())
 
     def _f(self, name):
-        return getattr(lib(), f"hifref_{self.k}_{name}")
+        return getattr(lib(self.lup), f"hifref_{self.k}_{name}")
 
     def close(self):
         if self.h:
@@ -108,8 +127,10 @@ class RefHIF:
         self._f("level_sizes")(self.h, l, _p(sz))
         m, n, nl, nu, ne, nf, nd, rk, enc, fnc, symm = [int(v) for v in sz]
         out = dict(m=m, n=n, dense_n=nd, dense_rank=rk)
-        if symm:  # Prec::symm_dense_solver: the last level of an is_symm factorization (SYEIG)
+        if symm == 1:  # Prec::symm_dense_solver: the last level of an is_symm factorization (SYEIG)
             out.update(dense_symm=1, spd=0 if self.params is None else int(self.params[6]))
+        elif symm == 2:  # built with HIF_DENSE_MODE=0: the last level is LUP
+            out.update(dense_lup=1)
         for which, (name, nz, nc) in enumerate([("L", nl, m), ("U", nu, m), ("E", ne, enc), ("F", nf, fnc)]):
             cp = np.zeros(nc + 1, dtype=np.int64)
             ri = np.zeros(nz, dtype=np.int32)

@@ -98,6 +98,7 @@ void level_sizes(void *h, int l, int64_t *out) {
   out[6] = p.dense_solver.empty() ? 0 : (int64_t)p.dense_solver.mat_backup().nrows();
   out[7] = p.dense_solver.empty() ? 0 : (int64_t)p.dense_solver.rank();
   out[10] = 0;
+  if (!p.dense_solver.empty() && std::strcmp(p.dense_solver.method(), "LUP") == 0) out[10] = 2;  // HIF_DENSE_MODE=0 build
   if (p.dense_solver.empty() && !p.symm_dense_solver.empty()) {  // is_symm: Prec::symm_dense_solver (SYEIG)
     out[6] = (int64_t)p.symm_dense_solver.mat_backup().nrows();
     out[7] = (int64_t)p.symm_dense_solver.rank();
@@ -180,6 +181,13 @@ int do_solve(void *h, const T *b, T *x, int64_t rank, bool tran = false) {
 template <class T>
 int do_mmultiply(void *h, const T *x, T *y, int64_t rank, bool tran = false) {
   auto *r = (Ref<T> *)h;
+#ifdef HIFREF_LUP_BUILD
+  // With HIF_DENSE_MODE=0 the reference's product does not compile: prec_prod calls dense_solver.multiply(y, r)
+  // (alg/prec_prod.hpp:85) but LUP only has multiply(x, y, r, tran) (small_scale/LUP.hpp:181-200).
+  (void)r, (void)x, (void)y, (void)rank, (void)tran;
+  g_err = "HIF::mmultiply is not instantiable when the reference is built with HIF_DENSE_MODE=0";
+  return 1;
+#else
   try {
     hif::Array<T> xx(r->n, const_cast<T *>(x), true), yy(r->n, y, true);
     r->M.mmultiply(xx, yy, tran, (size_t)rank);  // tran: prec_prod_tran, alg/prec_prod.hpp:148-235
@@ -188,6 +196,7 @@ int do_mmultiply(void *h, const T *x, T *y, int64_t rank, bool tran = false) {
     g_err = e.what();
     return 1;
   }
+#endif
 }
 
 template <class T>

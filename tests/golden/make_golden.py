@@ -110,15 +110,17 @@ def rhs(n, cplx=False):
     return b
 
 
-def save_hier(name, A, params=None, cplx=False):
+def save_hier(name, A, params=None, cplx=False, lup=False):
     A = A.tocsr()
     A.sort_indices()
     n = A.shape[0]
     vals = A.data.astype(np.complex128 if cplx else np.float64)
-    M = ref.RefHIF(A.indptr, A.indices, vals, params)
+    M = ref.RefHIF(A.indptr, A.indices, vals, params, lup=lup)
     b = rhs(n, cplx)
     x = M.solve(b)
-    b2 = M.mmultiply(x)
+    # (a reference built with HIF_DENSE_MODE=0 cannot instantiate HIF::mmultiply, LUP.hpp:181 vs prec_prod.hpp:85:
+    #  the fixture then stores b itself, the value the round trip M (M^-1 b) has to return)
+    b2 = b.copy() if lup else M.mmultiply(x)
     x_ir4, _ = M.hifir(b, 4)
     x_irb, st = M.hifir(b, 16, [1e-10, 1e3])
     B = np.stack([b + 0.01 * k for k in range(4)], axis=1)  # (n, 4) row-interleaved
@@ -153,6 +155,8 @@ def main():
     # a real symmetric multilevel hierarchy and a complex Hermitian one
     save_hier("p2d_32_symm", poisson2d(32), ref.make_params(dense_thres=60, is_symm=1))
     save_hier("herm_24_symm", hermitian2d(24), ref.make_params(dense_thres=60, is_symm=1), cplx=True)
+    # the reference compiled with HIF_DENSE_MODE=0 (oracle/_ref/libhifref_lup.so): the last level is LUP, not QRCP
+    save_hier("p2d_30_lup", poisson2d(30), lup=True)
     A = scipy.io.mmread(os.path.join(REF, "examples", "demo_inputs", "A.mm")).tocsr()
     save_hier("demo_A", A)  # libhifir/tests/test_real.c:88-146 input
     Z = scipy.io.mmread(os.path.join(REF, "examples", "demo_inputs", "young1c.mtx")).tocsr()

@@ -66,7 +66,9 @@ def test_level_schedule_is_valid(name):
     for lv in levels:
         M.add_level(lv)
     if int(levels[-1].get("dense_n", 0)):
-        if int(levels[-1].get("dense_symm", 0)):  # host-side SYEIG: rank as the reference's symm_dense_solver found it
+        if int(levels[-1].get("dense_lup", 0)):
+            M.set_dense_lup(levels[-1]["dense"])
+        elif int(levels[-1].get("dense_symm", 0)):  # host-side SYEIG: rank as the reference's symm_dense_solver found it
             M.set_dense_symm(levels[-1]["dense"], int(levels[-1].get("spd", 0)))
         else:
             M.set_dense(levels[-1]["dense"])
@@ -106,6 +108,7 @@ struct MockCcs { std::vector<long> cs; std::vector<int> ri; std::vector<double> 
   const std::vector<long>& col_start() const { return cs; } const std::vector<int>& row_ind() const { return ri; }
   const std::vector<double>& vals() const { return v; } size_t ncols() const { return nc; } };
 struct MockDense { std::vector<double> a; size_t n = 0; bool empty() const { return true; }
+  static const char* method() { return "QRCP"; }
   const MockDense& mat_backup() const { return *this; } size_t nrows() const { return n; } const double* data() const { return a.data(); } };
 struct MockPrec { size_t m = 0, n = 0; MockCcs L_B, U_B, E, F; std::vector<double> d_B, s, t; std::vector<int> p, p_inv, q, q_inv;
   MockDense dense_solver, symm_dense_solver; };
@@ -124,7 +127,7 @@ int main() {
     subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-I", inc, str(src)])
 
 
-@pytest.mark.parametrize("name", ["p2d_64_deep", "young1c", "p2d_100_tuned", "p2d_32_symm", "herm_24_symm"])
+@pytest.mark.parametrize("name", ["p2d_64_deep", "young1c", "p2d_100_tuned", "p2d_32_symm", "herm_24_symm", "p2d_30_lup"])
 def test_hierarchy_file_roundtrip(name, tmp_path):
     # hifamd_save / hifamd_load (host side only: no GPU needed before finalize): the reloaded handle holds
     # the same hierarchy -- same counts, same level schedules -- and a corrupt file is refused

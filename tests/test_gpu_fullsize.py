@@ -220,3 +220,27 @@ def test_1m_complex_stand_in_for_config5():
     assert relerr(XH[:, 7], R.solve(B[:, 7].copy(), trans=True)) <= 1e-12
     Y = M.mmultiply(X)
     assert (np.linalg.norm(Y - B, axis=0) / np.linalg.norm(B, axis=0)).max() <= 1e-10
+
+
+def test_1m_symmetric_factorization():
+    """Full size, Options::is_symm: the 1M-row Poisson matrix factorized symmetrically by the compiled reference
+    (its last level is SYEIG) and applied on the device: columns against the real reference, the conjugate-transpose
+    apply (same operator for a symmetric hierarchy), the product round trip, a truncated rank."""
+    A = poisson2d(1000)
+    R = ref.RefHIF(A.indptr, A.indices, A.data, ref.make_params(is_symm=1))
+    levels = R.levels()
+    assert int(levels[-1].get("dense_symm", 0)) == 1
+    M = hifir_amd.HIF.from_levels(levels, max_nrhs=8)
+    assert M.schur_rank() == levels[-1]["dense_rank"]
+    n = A.shape[0]
+    rng = np.random.default_rng(11)
+    B = rng.uniform(-1, 1, size=(n, 8))
+    X = M.solve_mrhs(B)
+    for k in (0, 7):
+        assert relerr(X[:, k], R.solve(B[:, k].copy())) <= 1e-12
+    xt = M.solve(B[:, 3].copy(), trans=True)
+    assert relerr(xt, R.solve(B[:, 3].copy(), trans=True)) <= 1e-12
+    y = M.mmultiply(X[:, 0].copy())
+    assert relerr(y, B[:, 0]) <= 1e-10                    # M (M^-1 b) = b
+    assert relerr(y, R.mmultiply(X[:, 0].copy(), rank=-1)) <= 1e-10
+    assert relerr(M.solve(B[:, 1].copy(), rank=50), R.solve(B[:, 1].copy(), rank=50)) <= 1e-11

@@ -314,6 +314,35 @@ def test_symmetric_last_level(cache, name):
     assert relerr(M2.solve(b), O2.solve(b)) <= TOL
 
 
+def test_lup_last_level(cache):
+    """Hierarchies of a reference built with HIF_DENSE_MODE=0: the last level is LU with partial pivoting (LUP.hpp).
+    Real fixture from that build; complex: the young1c hierarchy with its block handed over as an LUP block (the
+    conjugate-transpose apply then uses A^-T for the solve and A^H for the product, LUP.hpp:150,187)."""
+    levels, d, M, O = _get(cache, "p2d_30_lup")
+    assert int(levels[-1]["dense_lup"]) == 1
+    for rank in (0, 7):  # ignored
+        assert relerr(M.solve(d["b"], rank=rank), d["x"]) <= TOL
+    assert relerr(M.solve(d["b"], trans=True), d["xt"]) <= TOL
+    lz, dz = load_hier("young1c")
+    lz = [dict(l) for l in lz]
+    lz[-1]["dense_lup"] = 1
+    Mz, Oz = hifir_amd.HIF.from_levels(lz, max_nrhs=8), orc.Oracle(lz)
+    b = dz["b"]
+    x = Mz.solve(b)
+    assert relerr(x, Oz.solve(b)) <= TOL
+    assert relerr(Mz.solve(b, trans=True), Oz.solve(b, trans=True)) <= TOL
+    assert relerr(Mz.mmultiply(x), Oz.mmultiply(x)) <= 1e-10
+    assert relerr(Mz.mmultiply(x, trans=True), Oz.mmultiply(x, trans=True)) <= 1e-10
+    assert relerr(Mz.mmultiply(x), b) <= 1e-10
+    # an exactly singular block is refused (the reference only warns and would divide by zero)
+    ls = [dict(l) for l in levels]
+    sing = np.array(ls[-1]["dense"], dtype=np.float64).reshape(ls[-1]["dense_n"], -1).copy()
+    sing[:, 0] = 0.0
+    ls[-1]["dense"] = sing.ravel()
+    with pytest.raises(hifir_amd.HifAmdError):
+        hifir_amd.HIF.from_levels(ls, max_nrhs=8)
+
+
 def test_error_paths(cache):
     levels, d, M, O = _get(cache, "p2d_5")
     with pytest.raises(hifir_amd.HifAmdError) as e:

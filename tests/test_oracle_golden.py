@@ -36,6 +36,12 @@ def test_dense_known_answer(kat):
         assert np.abs(np.sort(w) - np.linalg.eigvalsh(a)).max() <= 1e-12 * np.abs(w).max()
         bs, _, _ = orc.syeig(np.asfortranarray(a).ravel(order="F"), xs, op=1)
         assert np.abs(bs - b).max() <= 1e-10 * max(1.0, np.abs(xr).max())
+    # test_sss_lup.cpp / test_lup_cmplx.cpp drive hif::LUP itself; every vector is a linear system, so all of them pin
+    # the ?getrf / ?getrs restatement of the LUP last level
+    xl, info = orc.lup(np.asfortranarray(a).ravel(order="F"), b)
+    assert info == 0 and np.abs(xl - xr).max() <= kat["tol"]
+    bl, _ = orc.lup(np.asfortranarray(a).ravel(order="F"), xl, op=1)
+    assert np.abs(bl - b).max() <= 1e-10 * max(1.0, np.abs(xr).max())
 
 
 @pytest.mark.parametrize("name", HIER_NAMES)

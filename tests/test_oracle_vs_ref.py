@@ -117,6 +117,29 @@ def test_fresh_hierarchies(nx, params):
         assert np.array_equal(t0, t1)
 
 
+@pytest.mark.skipif(not ref.available_lup(), reason="reference build with HIF_DENSE_MODE=0 not present")
+@pytest.mark.parametrize("cplx", [False, True])
+def test_fresh_lup_hierarchies(cplx):
+    """The reference compiled with HIF_DENSE_MODE=0 (last level = LU with partial pivoting, small_scale/LUP.hpp) against
+    the restatement: solve and conjugate-transpose solve (LUP passes 'T' to ?getrs also for complex data, LUP.hpp:150).
+    That build cannot instantiate HIF::mmultiply (LUP.hpp:181 vs prec_prod.hpp:85), so the product is not pinned."""
+    import scipy.sparse as sp
+
+    A = poisson2d(40)
+    if cplx:
+        A = (A.astype(np.complex128) - (0.3 + 0.2j) * sp.identity(A.shape[0])).tocsr()
+        A.sort_indices()
+    M = ref.RefHIF(A.indptr, A.indices, A.data, None, lup=True)
+    levels = M.levels()
+    assert levels[-1].get("dense_lup") == 1 and levels[-1]["dense_n"] > 0
+    O = orc.Oracle(levels)
+    rng = np.random.default_rng(3)
+    b = rng.uniform(-1, 1, A.shape[0]) + (1j * rng.uniform(-1, 1, A.shape[0]) if cplx else 0)
+    assert relerr(O.solve(b), M.solve(b)) <= 1e-12
+    assert relerr(O.solve(b, trans=True), M.solve(b, trans=True)) <= 1e-12
+    assert relerr(O.solve(b, rank=5), M.solve(b, rank=5)) <= 1e-12  # the rank is ignored (LUP.hpp:141)
+
+
 @pytest.mark.parametrize("kind", ["real", "indefinite", "hermitian", "spd"])
 def test_fresh_symmetric_hierarchies(kind):
     """is_symm factorizations of the real reference (symm_factor.hpp; last level = SYEIG, small_scale/SYEIG.hpp)

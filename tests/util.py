@@ -6,8 +6,9 @@ import scipy.sparse as sp
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 HIER_NAMES = ["p2d_5", "p2d_30", "p2d_64_deep", "p2d_100_tuned", "p3d_12", "cd2d_48", "demo_A", "young1c",
-              "p2d_32_symm", "herm_24_symm"]  # the last two: is_symm factorizations (last level = SYEIG)
-LEVEL_KEYS = ["m", "n", "dense_n", "dense_rank", "dense_symm", "spd", "d", "s", "t", "p", "p_inv", "q", "q_inv", "dense"] + [
+              "p2d_32_symm", "herm_24_symm",  # is_symm factorizations (last level = SYEIG)
+              "p2d_30_lup"]  # the reference built with HIF_DENSE_MODE=0 (last level = LUP)
+LEVEL_KEYS = ["m", "n", "dense_n", "dense_rank", "dense_symm", "spd", "dense_lup", "d", "s", "t", "p", "p_inv", "q", "q_inv", "dense"] + [
     f"{a}_{b}" for a in "LUEF" for b in ("colptr", "rowind", "vals")]
 
 
