@@ -275,6 +275,7 @@ class Engine : public EngineBase {
   bool use_graph = true;
   int min_logR = 6;
   int gemm_waves = 16;   // split-K width of the block-inverse GEMM
+  int band_pipe = 1;     // 1: k_trsv_band_p (next row's head behind the last gathers), 0: k_trsv_band at R = 64 too
   BandOptions band_opt;  // how triangles are cut into bands (host.hpp)
   DevBuf errflag;        // sticky error word: a bounded spin of k_trsv_band expired
 #ifdef HIFAMD_PROBE
@@ -297,6 +298,7 @@ class Engine : public EngineBase {
     use_graph = env_int("HIFIR_AMD_NO_GRAPH", 0) == 0;
     min_logR = std::min(6, std::max(0, env_int("HIFIR_AMD_MIN_LOGR", 6)));
     gemm_waves = env_int("HIFIR_AMD_GEMM_WAVES", 16);
+    band_pipe = env_int("HIFIR_AMD_BAND_PIPE", 1);
     use_twin = env_int("HIFIR_AMD_TWIN", 1);
     band_opt.thin_rows = env_int("HIFIR_AMD_THIN_ROWS", 96);
     band_opt.band_depth = env_int("HIFIR_AMD_BAND_DEPTH", 32);
@@ -909,6 +911,14 @@ class Engine : public EngineBase {
       if (M.band_dense[b]) {  // block by block: sparse update, then ONE dense product per block
         for (int32_t q = M.band_blk_ptr[b]; q < M.band_blk_ptr[b + 1]; ++q)
           launch_dense_block<LOWER>(st, L, M, q, logR, count, direct && q == qb0);
+        continue;
+      }
+      if (logR == 6 && band_pipe) {  // the overlapped pipeline (trsv_band_r64); HIFIR_AMD_BAND_PIPE=0: the first version
+        hipLaunchKernelGGL((k_trsv_band_p<D, LOWER>), dim3((unsigned)(g1 - g0)), dim3(1024), 0, st, g0,
+                           M.wg_grp_ptr.as<int32_t>(), M.grp_slot_ptr.as<int32_t>(), M.ptr.as<int32_t>(),
+                           M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(), M.srcslot.as<int32_t>(),
+                           M.rowid.as<int32_t>(), L.d.as<D>(), w, v, errflag.as<unsigned>(), pre ? 0 : 1);
+        ++count;
         continue;
       }
       hipLaunchKernelGGL((k_trsv_band<D, LOWER>), dim3((unsigned)(g1 - g0)), dim3(1024), 0, st, g0,

@@ -204,6 +204,9 @@ __device__ __forceinline__ double rl64(double v, int idx) {
 __device__ __forceinline__ double rlv(double v, int idx) { return rl64(v, idx); }
 __device__ __forceinline__ cplx rlv(cplx v, int idx) { return cplx{rl64(v.x, idx), rl64(v.y, idx)}; }
 __device__ __forceinline__ int32_t rfl(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// compiler barrier that "touches" a value: nothing that depends on it is scheduled above this point
+__device__ __forceinline__ void pin_here(double &v) { asm volatile("" : "+v"(v)::"memory"); }
+__device__ __forceinline__ void pin_here(cplx &v) { asm volatile("" : "+v"(v.x), "+v"(v.y)::"memory"); }
 
 // Development probe (make PROBE=1): wall_clock64 stamps of every wave of k_trsv_band -- kernel entry, start
 // of work, exit, and per row (the wave's first two) start / first gather / last accumulation / flag, number
@@ -531,6 +534,220 @@ __global__ void __launch_bounds__(1024) k_trsv_band(int32_t wg0, const int32_t *
         __hip_atomic_store(&flag[slot - slot0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The band form of the R = 64 pipeline (k_trsv_band_p, the default at R = 64): dependencies with srcslot >= slot0 are
+// acquired through LDS flags.  Per row and wave the first version (trsv_stream_r64 MODE 2, still selectable with
+// HIFIR_AMD_BAND_PIPE=0) pays two serial memory round trips -- the row's gathers, then, behind the row's flag, the head
+// of the wave's next row -- plus scalar-memory waits for the row headers.  This version overlaps them:
+//  * row headers (row id, nonzero range, pivot) of the wave's next 64 rows sit one per lane in registers (one vector
+//    load per array and 64 rows, the following block is requested half a block ahead) and are broadcast with
+//    v_readlane: no scalar-memory wait inside the loop;
+//  * the head of the wave's NEXT row (first item, right-hand side) goes out right BEHIND the last gathers of the
+//    current row.  Loads return in order: issued in front of the gathers these cold loads would delay them and with
+//    them the row's flag; issued after the flag they add a full memory round trip to every row;
+//  * that last batch, the trailing loads, the accumulation, the row's store and its flag are ONE basic block of
+//    straight-line code per batch size (1, 2, 3, 4, 6 or 8 gathers; slots beyond the row's end read one valid word
+//    that is ignored, addresses are selected instead of branched on).  The compiler then counts its waits exactly
+//    (e.g. s_waitcnt vmcnt(11) ... vmcnt(4) in front of eight accumulations: only the gathers are waited for) and has
+//    no block boundary at which to copy a register that a trailing load is still going to write.  The next row's
+//    data is first touched behind the flag (pin_here).  The batch sizes matter: with eight gathers always, the
+//    padding loads of the one- and two-nonzero rows of the wide first bands cost more gather slots of the compute
+//    unit than the overlap saves (measured: 10.92 -> 11.16 ms; with the sizes above 10.04 -> 9.65 ms).
+// Longer rows run their leading full batches through plain loops in front of that block.
+// Accumulation order is the reference's (exact mode stays bit-exact).  In place: x[i] holds the rhs on entry, the
+// solution on exit; UPPER rows start from rhs_u[i] / d[i] when this kernel is the first to touch them (first_u).
+// ---------------------------------------------------------------------------------------------
+template <class T, bool LOWER>
+__device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int32_t s_end, const int32_t stride,
+                                              const int32_t *__restrict__ ptr, const int32_t *__restrict__ split,
+                                              const int32_t *__restrict__ col, const T *__restrict__ val,
+                                              const int32_t *__restrict__ srcslot,
+                                              const int32_t *__restrict__ rowid, const T *__restrict__ d, T *x,
+                                              const T *__restrict__ rhs_u, const int lane, int *flag,
+                                              const int32_t slot0, unsigned *errflag, const bool first_u) {
+  const int32_t s_first = rfl(s_first_);  // (wave-uniform, which the compiler cannot see from threadIdx.x >> 6)
+  if (s_first >= s_end) return true;
+  const bool div_u = !LOWER && first_u;
+  const T *rhs = div_u ? rhs_u : (const T *)x;
+  // header blocks: lane l holds the header of the wave's row number (64 * block + l)
+  int32_t h_i = 0, h_k = 0, h_e = 0, g_i = 0, g_k = 0, g_e = 0;
+  T h_d = vzero(T()), g_d = vzero(T());
+#define HIFAMD_LOAD_HDR(hi, hk, he, hd, base)            \
+  {                                                      \
+    const int32_t sl_ = (base) + lane * stride;          \
+    if (sl_ < s_end) {                                   \
+      hi = rowid[sl_];                                   \
+      hk = split[sl_];                                   \
+      he = ptr[sl_ + 1];                                 \
+      if (div_u) hd = d[hi];                             \
+    }                                                    \
+  }
+  // all lanes lo <= lane < hi of the current item whose source row belongs to this band: wait for their flags
+#define HIFAMD_BAND_POLL(lo, hi)                                                                                 \
+  {                                                                                                              \
+    const bool mine_ = lane >= (lo) && lane < (hi) && ssv >= slot0;                                              \
+    unsigned spins_ = 0;                                                                                         \
+    for (;;) {                                                                                                   \
+      bool rdy_ = true;                                                                                          \
+      if (mine_) rdy_ = __hip_atomic_load(&flag[ssv - slot0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; \
+      if (__all(rdy_)) break;                                                                                    \
+      __builtin_amdgcn_s_sleep(1);                                                                               \
+      if ((++spins_ & 4095u) == 0 && spins_ > (1u << 24)) {                                                      \
+        if (lane == 0) __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);              \
+        return false;                                                                                            \
+      }                                                                                                          \
+    }                                                                                                            \
+  }
+  // a full batch of eight nonzeros starting at lane t of the current item (plain: leading part of longer rows)
+#define HIFAMD_BAND_FULL8(t)                                                                 \
+  {                                                                                          \
+    int32_t j_[8];                                                                           \
+    T a_[8], xv_[8];                                                                         \
+    _Pragma("unroll") for (int b = 0; b < 8; ++b) {                                          \
+      j_[b] = rl32(colv, (t) + b);                                                           \
+      a_[b] = rlv(valv, (t) + b);                                                            \
+    }                                                                                        \
+    _Pragma("unroll") for (int b = 0; b < 8; ++b) xv_[b] = x[((int64_t)j_[b] << 6) + lane];  \
+    _Pragma("unroll") for (int b = 0; b < 8; ++b) acc = vsub(acc, vmul(a_[b], xv_[b]));      \
+  }
+  HIFAMD_LOAD_HDR(h_i, h_k, h_e, h_d, s_first)
+  int hidx = 0;
+  int32_t s = s_first;
+  int32_t i_c = rl32(h_i, 0), k_c = rl32(h_k, 0), e_c = rl32(h_e, 0);
+  int32_t colv = col[k_c + lane], ssv = srcslot[k_c + lane];  // (80 padding elements: DevCsr::upload)
+  T valv = val[k_c + lane];
+  T acc = rhs[((int64_t)i_c << 6) + lane];
+  if (div_u) acc = vdiv(acc, rlv(h_d, 0));
+  for (;;) {  // one row per iteration
+    // header of the wave's next row: registers only.  Without a next row the trailing loads re-read
+    // the current row (valid, ignored).
+    const int32_t s_n = s + stride;
+    const bool has_n = s_n < s_end;
+    int32_t i_n = i_c, k_n = k_c, e_n = e_c;
+    T d_n = vzero(T());
+    if (has_n) {
+      if (hidx < 63) {
+        i_n = rl32(h_i, hidx + 1);
+        k_n = rl32(h_k, hidx + 1);
+        e_n = rl32(h_e, hidx + 1);
+        if (div_u) d_n = rlv(h_d, hidx + 1);
+      } else {
+        i_n = rl32(g_i, 0);
+        k_n = rl32(g_k, 0);
+        e_n = rl32(g_e, 0);
+        if (div_u) d_n = rlv(g_d, 0);
+      }
+    }
+    // the following header block is requested half a block ahead
+    if (hidx == 32 && s + 32 * stride < s_end) HIFAMD_LOAD_HDR(g_i, g_k, g_e, g_d, s + 32 * stride)
+    // ---- long rows: full 64-nonzero items in front of the row's last item
+    while (e_c - k_c > 64) {
+      const int32_t c2 = col[k_c + 64 + lane], s2 = srcslot[k_c + 64 + lane];
+      const T v2 = val[k_c + 64 + lane];
+      for (int t = 0; t < 64; t += 8) {
+        HIFAMD_BAND_POLL(t, t + 8)
+        HIFAMD_BAND_FULL8(t)
+      }
+      colv = c2;
+      valv = v2;
+      ssv = s2;
+      k_c += 64;
+    }
+    // ---- the row's last item: leading full batches ...
+    const int32_t cnt = e_c - k_c;  // <= 64, <= 0 for a row without nonzeros in this band
+    int32_t t = 0;
+    while (cnt - t > 8) {
+      HIFAMD_BAND_POLL(t, t + 8)
+      HIFAMD_BAND_FULL8(t)
+      t += 8;
+    }
+    // ---- ... and the last batch (0..8 nonzeros) with everything behind it, one basic block per batch size
+    // (1, 2, 4 or 8 gathers issued: the rows of the wide first bands have one or two nonzeros, and every padding
+    // load costs a slot of the compute unit's gather rate)
+    const int nb = max(cnt - t, 0);
+    HIFAMD_BAND_POLL(t, t + nb)
+    {
+      const T *xrow = x + lane;
+      const T *xdummy = x + ((int64_t)i_c << 6);  // one valid word for the slots beyond nb
+#define HIFAMD_BAND_FINAL(NBT)                                                                            \
+  {                                                                                                       \
+    const T *pj[NBT];                                                                                     \
+    T a[NBT], xv[NBT];                                                                                    \
+    _Pragma("unroll") for (int b = 0; b < NBT; ++b) {                                                     \
+      const int idx = min(t + b, 63);                                                                     \
+      const int32_t jb = rl32(colv, idx);                                                                 \
+      a[b] = rlv(valv, idx);                                                                              \
+      pj[b] = (b < nb) ? xrow + ((int64_t)jb << 6) : xdummy;                                              \
+    }                                                                                                     \
+    _Pragma("unroll") for (int b = 0; b < NBT; ++b) xv[b] = *pj[b];                                       \
+    colv = col[k_n + lane];                                                                               \
+    valv = val[k_n + lane];                                                                               \
+    ssv = srcslot[k_n + lane];                                                                            \
+    T acc2 = rhs[((int64_t)i_n << 6) + lane];                                                             \
+    asm volatile("" ::: "memory"); /* pins the trailing loads HERE */                                     \
+    _Pragma("unroll") for (int b = 0; b < NBT; ++b) {                                                     \
+      const T pr = vmul(a[b], xv[b]);                                                                     \
+      if (b < nb) acc = vsub(acc, pr);                                                                    \
+    }                                                                                                     \
+    x[((int64_t)i_c << 6) + lane] = acc;                                                                  \
+    /* release: the row's stores (all 64 lanes) are ordered before its flag */                            \
+    if (lane == 0) __hip_atomic_store(&flag[s - slot0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    pin_here(acc2); /* the next row's data is first touched HERE, behind the flag */                      \
+    acc = div_u ? vdiv(acc2, d_n) : acc2;                                                                 \
+  }
+      if (nb <= 1)
+        HIFAMD_BAND_FINAL(1)
+      else if (nb <= 2)
+        HIFAMD_BAND_FINAL(2)
+      else if (nb <= 3)
+        HIFAMD_BAND_FINAL(3)
+      else if (nb <= 4)
+        HIFAMD_BAND_FINAL(4)
+      else if (nb <= 6)
+        HIFAMD_BAND_FINAL(6)
+      else
+        HIFAMD_BAND_FINAL(8)
+#undef HIFAMD_BAND_FINAL
+    }
+    if (!has_n) break;
+    s = s_n;
+    i_c = i_n;
+    k_c = k_n;
+    e_c = e_n;
+    if (++hidx == 64) {
+      hidx = 0;
+      h_i = g_i;
+      h_k = g_k;
+      h_e = g_e;
+      h_d = g_d;
+    }
+  }
+#undef HIFAMD_LOAD_HDR
+#undef HIFAMD_BAND_POLL
+#undef HIFAMD_BAND_FULL8
+  return true;
+}
+
+template <class T, bool LOWER>
+__global__ void __launch_bounds__(1024) k_trsv_band_p(int32_t wg0, const int32_t *__restrict__ wg_grp_ptr,
+                                                      const int32_t *__restrict__ grp_slot_ptr,
+                                                      const int32_t *__restrict__ ptr,
+                                                      const int32_t *__restrict__ split,
+                                                      const int32_t *__restrict__ col, const T *__restrict__ val,
+                                                      const int32_t *__restrict__ srcslot,
+                                                      const int32_t *__restrict__ rowid, const T *__restrict__ d,
+                                                      T *w, T *v, unsigned *errflag, int first_u) {
+  __shared__ int flag[HIFAMD_TAIL_MAX];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int32_t wf0 = wg_grp_ptr[wg0 + blockIdx.x], wf1 = wg_grp_ptr[wg0 + blockIdx.x + 1];
+  const int32_t slot0 = grp_slot_ptr[wf0], slot1 = grp_slot_ptr[wf1];
+  for (int t = threadIdx.x; t < slot1 - slot0; t += blockDim.x) flag[t] = 0;
+  __syncthreads();
+  trsv_band_r64<T, LOWER>(slot0 + wave, slot1, nw, ptr, split, col, val, srcslot, rowid, d, LOWER ? w : v, w, lane, flag,
+                          slot0, errflag, first_u != 0);
 }
 
 // ---------------------------------------------------------------------------------------------
