@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(1024) k_trsv_band(int32_t wg0, const int32_t *
 //    current row.  Loads return in order: issued in front of the gathers these cold loads would delay them and with
 //    them the row's flag; issued after the flag they add a full memory round trip to every row;
 //  * that last batch, the trailing loads, the accumulation, the row's store and its flag are ONE basic block of
-//    straight-line code per batch size (1, 2, 3, 4, 6 or 8 gathers; slots beyond the row's end read one valid word
+//    straight-line code per batch size (0, 1, 2, 3, 4, 6 or 8 gathers; slots beyond the row's end read one valid word
 //    that is ignored, addresses are selected instead of branched on).  The compiler then counts its waits exactly
 //    (e.g. s_waitcnt vmcnt(11) ... vmcnt(4) in front of eight accumulations: only the gathers are waited for) and has
 //    no block boundary at which to copy a register that a trailing load is still going to write.  The next row's
@@ -673,8 +673,8 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
       const T *xdummy = x + ((int64_t)i_c << 6);  // one valid word for the slots beyond nb
 #define HIFAMD_BAND_FINAL(NBT)                                                                            \
   {                                                                                                       \
-    const T *pj[NBT];                                                                                     \
-    T a[NBT], xv[NBT];                                                                                    \
+    const T *pj[NBT ? NBT : 1];                                                                           \
+    T a[NBT ? NBT : 1], xv[NBT ? NBT : 1];                                                                                    \
     _Pragma("unroll") for (int b = 0; b < NBT; ++b) {                                                     \
       const int idx = min(t + b, 63);                                                                     \
       const int32_t jb = rl32(colv, idx);                                                                 \
@@ -697,7 +697,9 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
     pin_here(acc2); /* the next row's data is first touched HERE, behind the flag */                      \
     acc = div_u ? vdiv(acc2, d_n) : acc2;                                                                 \
   }
-      if (nb <= 1)
+      if (nb <= 0)
+        HIFAMD_BAND_FINAL(0)
+      else if (nb <= 1)
         HIFAMD_BAND_FINAL(1)
       else if (nb <= 2)
         HIFAMD_BAND_FINAL(2)
