@@ -139,6 +139,7 @@ struct DevCsr {
   DevBuf ptr, col, val, rowid;
   // band plan of a triangle (host.hpp BandPlan); empty for E, F, A
   DevBuf srcslot, split, wg_grp_ptr, grp_slot_ptr;
+  DevBuf wg_slot;  // first slot of every workgroup (+ end): grp_slot_ptr[wg_grp_ptr[g]], one load level less at kernel start
   std::vector<int32_t> band_wg_ptr, band_slot_ptr;
   std::vector<uint8_t> band_prefix, band_dense;
   std::vector<int32_t> band_blk_ptr, blk_slot0, blk_slot1;
@@ -157,6 +158,7 @@ struct DevCsr {
     split.alias(o.split);
     wg_grp_ptr.alias(o.wg_grp_ptr);
     grp_slot_ptr.alias(o.grp_slot_ptr);
+    wg_slot.alias(o.wg_slot);
     tinv.alias(o.tinv);
     band_wg_ptr = o.band_wg_ptr;
     band_slot_ptr = o.band_slot_ptr;
@@ -181,6 +183,11 @@ struct DevCsr {
       split.upload(P->split);
       wg_grp_ptr.upload(P->wg_grp_ptr);
       grp_slot_ptr.upload(P->grp_slot_ptr);
+      {
+        std::vector<int32_t> ws(P->wg_grp_ptr.size());
+        for (size_t g = 0; g < ws.size(); ++g) ws[g] = P->grp_slot_ptr[(size_t)P->wg_grp_ptr[g]];
+        wg_slot.upload(ws);
+      }
       band_wg_ptr = P->band_wg_ptr;
       band_prefix = P->band_prefix;
       band_dense = P->band_dense;
@@ -915,7 +922,7 @@ class Engine : public EngineBase {
       }
       if (logR == 6 && band_pipe) {  // the overlapped pipeline (trsv_band_r64); HIFIR_AMD_BAND_PIPE=0: the first version
         hipLaunchKernelGGL((k_trsv_band_p<D, LOWER>), dim3((unsigned)(g1 - g0)), dim3(1024), 0, st, g0,
-                           M.wg_grp_ptr.as<int32_t>(), M.grp_slot_ptr.as<int32_t>(), M.ptr.as<int32_t>(),
+                           M.wg_slot.as<int32_t>(), M.ptr.as<int32_t>(),
                            M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(), M.srcslot.as<int32_t>(),
                            M.rowid.as<int32_t>(), L.d.as<D>(), w, v, errflag.as<unsigned>(), pre ? 0 : 1);
         ++count;

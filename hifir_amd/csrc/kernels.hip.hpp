@@ -568,7 +568,6 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
                                               const T *__restrict__ rhs_u, const int lane, int *flag,
                                               const int32_t slot0, unsigned *errflag, const bool first_u) {
   const int32_t s_first = rfl(s_first_);  // (wave-uniform, which the compiler cannot see from threadIdx.x >> 6)
-  if (s_first >= s_end) return true;
   const bool div_u = !LOWER && first_u;
   const T *rhs = div_u ? rhs_u : (const T *)x;
   // header blocks: lane l holds the header of the wave's row number (64 * block + l)
@@ -612,7 +611,11 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
     _Pragma("unroll") for (int b = 0; b < 8; ++b) xv_[b] = x[((int64_t)j_[b] << 6) + lane];  \
     _Pragma("unroll") for (int b = 0; b < 8; ++b) acc = vsub(acc, vmul(a_[b], xv_[b]));      \
   }
-  HIFAMD_LOAD_HDR(h_i, h_k, h_e, h_d, s_first)
+  HIFAMD_LOAD_HDR(h_i, h_k, h_e, h_d, s_first)  // (requested first: in flight while the flags are cleared)
+  // the workgroup's flags: one per slot of its range [slot0, s_end)
+  for (int t_ = (int)threadIdx.x; t_ < s_end - slot0; t_ += (int)blockDim.x) flag[t_] = 0;
+  __syncthreads();
+  if (s_first >= s_end) return true;
   int hidx = 0;
   int32_t s = s_first;
   int32_t i_c = rl32(h_i, 0), k_c = rl32(h_k, 0), e_c = rl32(h_e, 0);
@@ -733,8 +736,7 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
 }
 
 template <class T, bool LOWER>
-__global__ void __launch_bounds__(1024) k_trsv_band_p(int32_t wg0, const int32_t *__restrict__ wg_grp_ptr,
-                                                      const int32_t *__restrict__ grp_slot_ptr,
+__global__ void __launch_bounds__(1024) k_trsv_band_p(int32_t wg0, const int32_t *__restrict__ wg_slot,
                                                       const int32_t *__restrict__ ptr,
                                                       const int32_t *__restrict__ split,
                                                       const int32_t *__restrict__ col, const T *__restrict__ val,
@@ -744,10 +746,8 @@ __global__ void __launch_bounds__(1024) k_trsv_band_p(int32_t wg0, const int32_t
   __shared__ int flag[HIFAMD_TAIL_MAX];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int32_t wf0 = wg_grp_ptr[wg0 + blockIdx.x], wf1 = wg_grp_ptr[wg0 + blockIdx.x + 1];
-  const int32_t slot0 = grp_slot_ptr[wf0], slot1 = grp_slot_ptr[wf1];
-  for (int t = threadIdx.x; t < slot1 - slot0; t += blockDim.x) flag[t] = 0;
-  __syncthreads();
+  // the workgroup's slot range in ONE load level (wg_slot[g] = grp_slot_ptr[wg_grp_ptr[g]])
+  const int32_t slot0 = wg_slot[wg0 + blockIdx.x], slot1 = wg_slot[wg0 + blockIdx.x + 1];
   trsv_band_r64<T, LOWER>(slot0 + wave, slot1, nw, ptr, split, col, val, srcslot, rowid, d, LOWER ? w : v, w, lane, flag,
                           slot0, errflag, first_u != 0);
 }
