@@ -583,21 +583,26 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
       if (div_u) hd = d[hi];                             \
     }                                                    \
   }
-  // all lanes lo <= lane < hi of the current item whose source row belongs to this band: wait for their flags
-#define HIFAMD_BAND_POLL(lo, hi)                                                                                 \
-  {                                                                                                              \
-    const bool mine_ = lane >= (lo) && lane < (hi) && ssv >= slot0;                                              \
-    unsigned spins_ = 0;                                                                                         \
-    for (;;) {                                                                                                   \
-      bool rdy_ = true;                                                                                          \
-      if (mine_) rdy_ = __hip_atomic_load(&flag[ssv - slot0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; \
-      if (__all(rdy_)) break;                                                                                    \
-      __builtin_amdgcn_s_sleep(1);                                                                               \
-      if ((++spins_ & 4095u) == 0 && spins_ > (1u << 24)) {                                                      \
-        if (lane == 0) __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);              \
-        return false;                                                                                            \
-      }                                                                                                          \
-    }                                                                                                            \
+  // wait until the leading `hi` nonzeros of the current item (item_cnt of them valid) have their in-band sources
+  // finished.  ONE LDS instruction polls the flags of the whole item (source slots sit one per lane) and `ready`
+  // remembers how many leading nonzeros were found ready, so that a row whose sources all finished before the
+  // band -- phase 1 of every band -- polls once, not once per batch.
+#define HIFAMD_BAND_POLL(hi)                                                                                      \
+  if (ready < (hi)) {                                                                                             \
+    unsigned spins_ = 0;                                                                                          \
+    for (;;) {                                                                                                    \
+      bool rdy_ = true;                                                                                           \
+      if (lane < item_cnt && ssv >= slot0)                                                                        \
+        rdy_ = __hip_atomic_load(&flag[ssv - slot0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;        \
+      const unsigned long long pend_ = ~__ballot(rdy_);                                                           \
+      ready = pend_ ? (int32_t)__builtin_ctzll(pend_) : 64;                                                       \
+      if (ready >= (hi)) break;                                                                                   \
+      __builtin_amdgcn_s_sleep(1);                                                                                \
+      if ((++spins_ & 4095u) == 0 && spins_ > (1u << 24)) {                                                       \
+        if (lane == 0) __hip_atomic_store(errflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               \
+        return false;                                                                                             \
+      }                                                                                                           \
+    }                                                                                                             \
   }
   // a full batch of eight nonzeros starting at lane t of the current item (plain: leading part of longer rows)
 #define HIFAMD_BAND_FULL8(t)                                                                 \
@@ -649,9 +654,13 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
     while (e_c - k_c > 64) {
       const int32_t c2 = col[k_c + 64 + lane], s2 = srcslot[k_c + 64 + lane];
       const T v2 = val[k_c + 64 + lane];
-      for (int t = 0; t < 64; t += 8) {
-        HIFAMD_BAND_POLL(t, t + 8)
-        HIFAMD_BAND_FULL8(t)
+      {
+        const int32_t item_cnt = 64;
+        int32_t ready = 0;
+        for (int t = 0; t < 64; t += 8) {
+          HIFAMD_BAND_POLL(t + 8)
+          HIFAMD_BAND_FULL8(t)
+        }
       }
       colv = c2;
       valv = v2;
@@ -660,9 +669,10 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
     }
     // ---- the row's last item: leading full batches ...
     const int32_t cnt = e_c - k_c;  // <= 64, <= 0 for a row without nonzeros in this band
-    int32_t t = 0;
+    const int32_t item_cnt = cnt;
+    int32_t ready = 0, t = 0;
     while (cnt - t > 8) {
-      HIFAMD_BAND_POLL(t, t + 8)
+      HIFAMD_BAND_POLL(t + 8)
       HIFAMD_BAND_FULL8(t)
       t += 8;
     }
@@ -670,7 +680,7 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
     // (1, 2, 4 or 8 gathers issued: the rows of the wide first bands have one or two nonzeros, and every padding
     // load costs a slot of the compute unit's gather rate)
     const int nb = max(cnt - t, 0);
-    HIFAMD_BAND_POLL(t, t + nb)
+    HIFAMD_BAND_POLL(t + nb)
     {
       const T *xrow = x + lane;
       const T *xdummy = x + ((int64_t)i_c << 6);  // one valid word for the slots beyond nb
