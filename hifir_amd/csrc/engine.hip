@@ -924,7 +924,12 @@ class Engine : public EngineBase {
         hipLaunchKernelGGL((k_trsv_band_p<D, LOWER>), dim3((unsigned)(g1 - g0)), dim3(1024), 0, st, g0,
                            M.wg_slot.as<int32_t>(), M.ptr.as<int32_t>(),
                            M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(), M.srcslot.as<int32_t>(),
-                           M.rowid.as<int32_t>(), L.d.as<D>(), w, v, errflag.as<unsigned>(), pre ? 0 : 1);
+                           M.rowid.as<int32_t>(), L.d.as<D>(), w, v, errflag.as<unsigned>(), pre ? 0 : 1
+#ifdef HIFAMD_PROBE
+                           ,
+                           probe.as<unsigned long long>(), (int)count
+#endif
+        );
         ++count;
         continue;
       }

@@ -566,7 +566,11 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
                                               const int32_t *__restrict__ srcslot,
                                               const int32_t *__restrict__ rowid, const T *__restrict__ d, T *x,
                                               const T *__restrict__ rhs_u, const int lane, int *flag,
-                                              const int32_t slot0, unsigned *errflag, const bool first_u) {
+                                              const int32_t slot0, unsigned *errflag,
+                                              const bool first_u HIFAMD_PROBE_ARG) {
+#ifdef HIFAMD_PROBE
+  int prow = 0;
+#endif
   const int32_t s_first = rfl(s_first_);  // (wave-uniform, which the compiler cannot see from threadIdx.x >> 6)
   const bool div_u = !LOWER && first_u;
   const T *rhs = div_u ? rhs_u : (const T *)x;
@@ -671,6 +675,8 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
     const int32_t cnt = e_c - k_c;  // <= 64, <= 0 for a row without nonzeros in this band
     const int32_t item_cnt = cnt;
     int32_t ready = 0, t = 0;
+    HIFAMD_STAMP(0)
+    HIFAMD_STAMP_VAL(4, cnt)
     while (cnt - t > 8) {
       HIFAMD_BAND_POLL(t + 8)
       HIFAMD_BAND_FULL8(t)
@@ -680,7 +686,9 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
     // (1, 2, 4 or 8 gathers issued: the rows of the wide first bands have one or two nonzeros, and every padding
     // load costs a slot of the compute unit's gather rate)
     const int nb = max(cnt - t, 0);
+    HIFAMD_STAMP(1)  // (leading batches done)
     HIFAMD_BAND_POLL(t + nb)
+    HIFAMD_STAMP(2)  // (the last batch's sources are finished)
     {
       const T *xrow = x + lane;
       const T *xdummy = x + ((int64_t)i_c << 6);  // one valid word for the slots beyond nb
@@ -726,6 +734,10 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
         HIFAMD_BAND_FINAL(8)
 #undef HIFAMD_BAND_FINAL
     }
+    HIFAMD_STAMP(3)  // (row stored, flag raised, next row's head has arrived)
+#ifdef HIFAMD_PROBE
+    ++prow;
+#endif
     if (!has_n) break;
     s = s_n;
     i_c = i_n;
@@ -752,14 +764,30 @@ __global__ void __launch_bounds__(1024) k_trsv_band_p(int32_t wg0, const int32_t
                                                       const int32_t *__restrict__ col, const T *__restrict__ val,
                                                       const int32_t *__restrict__ srcslot,
                                                       const int32_t *__restrict__ rowid, const T *__restrict__ d,
-                                                      T *w, T *v, unsigned *errflag, int first_u) {
+                                                      T *w, T *v, unsigned *errflag, int first_u
+#ifdef HIFAMD_PROBE
+                                                      ,
+                                                      unsigned long long *ts, int probe_id
+#endif
+) {
   __shared__ int flag[HIFAMD_TAIL_MAX];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#ifdef HIFAMD_PROBE  // same record layout as k_trsv_band: 0 entry, 2 start of work, 3 exit, 4.. two rows x 6
+  unsigned long long *tsw =
+      (ts && blockIdx.x < 256) ? ts + (((size_t)probe_id * 256 + blockIdx.x) * 16 + wave) * 16 : nullptr;
+  if (tsw && lane == 0) tsw[0] = tsw[2] = wall_clock64();
+#endif
   // the workgroup's slot range in ONE load level (wg_slot[g] = grp_slot_ptr[wg_grp_ptr[g]])
   const int32_t slot0 = wg_slot[wg0 + blockIdx.x], slot1 = wg_slot[wg0 + blockIdx.x + 1];
+#ifdef HIFAMD_PROBE
+  trsv_band_r64<T, LOWER>(slot0 + wave, slot1, nw, ptr, split, col, val, srcslot, rowid, d, LOWER ? w : v, w, lane, flag,
+                          slot0, errflag, first_u != 0, tsw);
+  if (tsw && lane == 0) tsw[3] = wall_clock64();
+#else
   trsv_band_r64<T, LOWER>(slot0 + wave, slot1, nw, ptr, split, col, val, srcslot, rowid, d, LOWER ? w : v, w, lane, flag,
                           slot0, errflag, first_u != 0);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
