@@ -223,6 +223,21 @@ __device__ __forceinline__ void pin_here(cplx &v) { asm volatile("" : "+v"(v.x),
 #define HIFAMD_STAMP(k)
 #define HIFAMD_STAMP_VAL(k, v)
 #endif
+// make PROBE=2 (-DHIFAMD_PROBE -DHIFAMD_PROBE_BATCH): instead of the per-row stamps, the wave's FIRST row records the
+// timeline of its leading full batches in words 4..15 of its record: (gathers issued, accumulated) x up to six batches
+#if defined(HIFAMD_PROBE) && defined(HIFAMD_PROBE_BATCH)
+#undef HIFAMD_STAMP
+#undef HIFAMD_STAMP_VAL
+#define HIFAMD_STAMP(k)
+#define HIFAMD_STAMP_VAL(k, v)
+#define HIFAMD_STAMP_BATCH(e)                                                                   \
+  if (tsw && lane == 0 && prow == 0 && pbatch < 6) {                                            \
+    tsw[4 + 2 * pbatch + (e)] = wall_clock64();                                                 \
+    pbatch += (e);                                                                              \
+  }
+#else
+#define HIFAMD_STAMP_BATCH(e)
+#endif
 
 template <class T, int MODE, bool LOWER, bool PREFIX>
 __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, int32_t stride,
@@ -570,6 +585,8 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
                                               const bool first_u HIFAMD_PROBE_ARG) {
 #ifdef HIFAMD_PROBE
   int prow = 0;
+  int pbatch = 0;
+  (void)pbatch;
 #endif
   const int32_t s_first = rfl(s_first_);  // (wave-uniform, which the compiler cannot see from threadIdx.x >> 6)
   const bool div_u = !LOWER && first_u;
@@ -618,7 +635,9 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
       a_[b] = rlv(valv, (t) + b);                                                            \
     }                                                                                        \
     _Pragma("unroll") for (int b = 0; b < 8; ++b) xv_[b] = x[((int64_t)j_[b] << 6) + lane];  \
+    HIFAMD_STAMP_BATCH(0) /* (all eight gathers issued) */                                   \
     _Pragma("unroll") for (int b = 0; b < 8; ++b) acc = vsub(acc, vmul(a_[b], xv_[b]));      \
+    HIFAMD_STAMP_BATCH(1) /* (all eight accumulated) */                                      \
   }
   HIFAMD_LOAD_HDR(h_i, h_k, h_e, h_d, s_first)  // (requested first: in flight while the flags are cleared)
   // the workgroup's flags: one per slot of its range [slot0, s_end)
