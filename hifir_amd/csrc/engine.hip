@@ -141,7 +141,7 @@ struct DevCsr {
   DevBuf srcslot, split, wg_grp_ptr, grp_slot_ptr;
   DevBuf wg_slot;  // first slot of every workgroup (+ end): grp_slot_ptr[wg_grp_ptr[g]], one load level less at kernel start
   std::vector<int32_t> band_wg_ptr, band_slot_ptr;
-  std::vector<uint8_t> band_prefix, band_dense;
+  std::vector<uint8_t> band_prefix, band_dense, band_fused;
   std::vector<int32_t> band_blk_ptr, blk_slot0, blk_slot1;
   std::vector<int64_t> blk_inv_off;
   DevBuf tinv;  // explicit inverses of the diagonal blocks of block-dense thin bands
@@ -163,6 +163,7 @@ struct DevCsr {
     band_wg_ptr = o.band_wg_ptr;
     band_slot_ptr = o.band_slot_ptr;
     band_prefix = o.band_prefix;
+    band_fused = o.band_fused;
     band_dense = o.band_dense;
     band_blk_ptr = o.band_blk_ptr;
     blk_slot0 = o.blk_slot0;
@@ -190,6 +191,7 @@ struct DevCsr {
       }
       band_wg_ptr = P->band_wg_ptr;
       band_prefix = P->band_prefix;
+      band_fused = P->band_fused;
       band_dense = P->band_dense;
       band_blk_ptr = P->band_blk_ptr;
       blk_slot0 = P->blk_slot0;
@@ -313,6 +315,11 @@ class Engine : public EngineBase {
     band_opt.max_comp_weight = env_int("HIFIR_AMD_BAND_WEIGHT", 1024);
     band_opt.max_wg_rows = HIFAMD_TAIL_MAX;
     band_opt.dense_block = env_int("HIFIR_AMD_DENSE_BLOCK", 2048);  // 0: exact sequential thin bands
+    // carried prefixes (host.hpp finish_band_plan): real data only -- measured on the complex 1M-row case (one
+    // workgroup per compute unit, rows of 1 KB) they lose at every threshold (18.8 ms without, 19.7 ... 20.6 ms with)
+    band_opt.fuse = env_int("HIFIR_AMD_BAND_FUSE", sizeof(T) == sizeof(double) ? 1 : 0) != 0;
+    band_opt.fuse_reorder = band_opt.dense_block > 0;                  // exact mode keeps the reference's order
+    band_opt.fuse_max_wgs = env_int("HIFIR_AMD_BAND_FUSE_WGS", 512);
   }
 
   void bind_device() {
@@ -431,8 +438,8 @@ class Engine : public EngineBase {
     double t2 = now();
     H.Lr = permute_rows(H.Lr, H.Lp.order);
     H.Ur = permute_rows(H.Ur, H.Up.order);
-    finish_band_plan(H.Lp, H.Lr);
-    finish_band_plan(H.Up, H.Ur);
+    finish_band_plan(H.Lp, H.Lr, band_opt);
+    finish_band_plan(H.Up, H.Ur, band_opt);
     double t3 = now();
     H.Ltinv_elems = plan_dense_blocks<T>(H.Lp, band_opt);
     H.Utinv_elems = plan_dense_blocks<T>(H.Up, band_opt);
@@ -898,16 +905,22 @@ class Engine : public EngineBase {
     if (M.nrows == 0) return;
     D *w = L.w.as<D>(), *v = L.v.as<D>();
     const size_t nb = M.band_wg_ptr.size() - 1;
+    bool carried = false;  // the previous band's launch ran this band's carried prefix (host.hpp finish_band_plan)
     for (size_t b = 0; b < nb; ++b) {
       const int32_t g0 = M.band_wg_ptr[b], g1 = M.band_wg_ptr[b + 1];
-      // the kernel that touches a U row first starts it from w[i] / d[i] (the L kernels no longer write v)
-      const int pre = M.band_prefix[b] ? 1 : 0;
+      const bool fused = !M.band_fused.empty() && M.band_fused[b];
+      const bool have_carried = carried;
+      carried = false;
+      // the kernel that touches a U row first starts it from w[i] / d[i] (the L kernels no longer write v).
+      // pre: the band's rows start at split[] and [ptr, split) is folded in by a prefix pass first -- its own launch,
+      // unless the previous band's launch carried it
+      const int pre = (M.band_prefix[b] || fused) ? 1 : 0;
       // block-dense band at R = 64: the prefix pass delivers the rows of the band's first block straight into the
       // block product's right-hand side (nothing else contributes to them), so that block needs no k_thin_update
       const int32_t qb0 = M.band_dense[b] ? M.band_blk_ptr[b] : -1;
       const bool direct = pre && M.band_dense[b] && logR == 6 && qb0 < M.band_blk_ptr[b + 1] &&
                           M.blk_slot0[(size_t)qb0] == M.band_slot_ptr[b];
-      if (pre) {
+      if (pre && !(fused && have_carried)) {
         const int64_t s0 = M.band_slot_ptr[b], s1 = M.band_slot_ptr[b + 1];
         hipLaunchKernelGGL((k_trsv_wide<D, LOWER, true>), dim3(grid_for(s1 - s0, logR)), dim3(256), 0, st, s0, s1,
                            M.ptr.as<int32_t>(), M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(),
@@ -921,10 +934,20 @@ class Engine : public EngineBase {
         continue;
       }
       if (logR == 6 && band_pipe) {  // the overlapped pipeline (trsv_band_r64); HIFIR_AMD_BAND_PIPE=0: the first version
-        hipLaunchKernelGGL((k_trsv_band_p<D, LOWER>), dim3((unsigned)(g1 - g0)), dim3(1024), 0, st, g0,
+        // extra workgroups for the carried prefix of the NEXT band (they run on the units this band leaves idle)
+        int32_t ps0 = 0, ps1 = 0;
+        unsigned extra = 0;
+        if (b + 1 < nb && !M.band_fused.empty() && M.band_fused[b + 1]) {
+          ps0 = M.band_slot_ptr[b + 1];
+          ps1 = M.band_slot_ptr[b + 2];
+          extra = (unsigned)std::min<int64_t>(256, std::max<int64_t>(1, ((int64_t)ps1 - ps0 + 15) / 16));
+          carried = true;
+        }
+        hipLaunchKernelGGL((k_trsv_band_p<D, LOWER>), dim3((unsigned)(g1 - g0) + extra), dim3(1024), 0, st, g0,
                            M.wg_slot.as<int32_t>(), M.ptr.as<int32_t>(),
                            M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(), M.srcslot.as<int32_t>(),
-                           M.rowid.as<int32_t>(), L.d.as<D>(), w, v, errflag.as<unsigned>(), pre ? 0 : 1
+                           M.rowid.as<int32_t>(), L.d.as<D>(), w, v, errflag.as<unsigned>(), pre ? 0 : 1,
+                           (int32_t)(g1 - g0), ps0, ps1
 #ifdef HIFAMD_PROBE
                            ,
                            probe.as<unsigned long long>(), (int)count
@@ -945,7 +968,6 @@ class Engine : public EngineBase {
       ++count;
     }
   }
-
   template <bool LOWER>
   void launch_dense_block(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t q, int logR, int64_t &count,
                           bool rhs_ready = false);

@@ -246,6 +246,7 @@ struct BandPlan {
   std::vector<int32_t> wg_grp_ptr;    // workgroup w owns groups [wg_grp_ptr[w], wg_grp_ptr[w+1])
   std::vector<int32_t> band_wg_ptr;   // band b owns workgroups [band_wg_ptr[b], band_wg_ptr[b+1])
   std::vector<uint8_t> band_prefix;   // band b is preceded by the exact prefix pass
+  std::vector<uint8_t> band_fused;    // the prefix of band b over sources older than band b-1 rides on band b-1's launch
   // Thin bands solved block by block with explicit inverses of the diagonal blocks (see below):
   std::vector<uint8_t> band_dense;    // band b uses the block-dense scheme
   std::vector<int32_t> band_blk_ptr;  // band b owns blocks [band_blk_ptr[b], band_blk_ptr[b+1])
@@ -265,6 +266,9 @@ struct BandOptions {
   int64_t max_wg_rows = 16384;  // LDS flags per workgroup
   int64_t max_wgs = 1024;    // workgroups per band
   int64_t dense_block = 2048; // rows per diagonal block of a block-dense thin band (0 = scheme off)
+  bool fuse = true;            // carried prefixes (band_fused), see finish_band_plan
+  bool fuse_reorder = true;    // ... with the rows' nonzeros reordered so that the prefix covers ALL old sources (fast mode)
+  int64_t fuse_max_wgs = 512;  // band b-1 must leave compute units idle (96 / 192 / 256 / 512 / 1024: 9.23 / 8.87 / 8.86 / 8.81 / 9.28 ms)
   int64_t dense_min_rows = 96;   // thin bands shorter than this stay on the sequential workgroup
   double dense_max_growth = 1e4; // ... and so do bands whose block inverses grow beyond this
 };
@@ -573,17 +577,35 @@ double build_dense_block(const BandPlan &P, const Csr<T> &A, size_t q, double *o
 }
 
 template <class T>
-void finish_band_plan(BandPlan &P, Csr<T> &A /* rows in slot order */) {
+void finish_band_plan(BandPlan &P, Csr<T> &A /* rows in slot order */, const BandOptions &opt = BandOptions()) {
   const int64_t m = A.nrows;
   std::vector<int32_t> slot_of((size_t)m);
   for (int64_t s = 0; s < m; ++s) slot_of[(size_t)A.rowid[(size_t)s]] = (int32_t)s;
   P.srcslot.resize(A.col.size());
   for (size_t k = 0; k < A.col.size(); ++k) P.srcslot[k] = slot_of[(size_t)A.col[k]];
   P.split.resize((size_t)m);
+  // Carried prefixes.  A narrow band keeps 20-100 of the 256 compute units busy, and what bounds it is the rate at
+  // which ONE unit gets the gathers of its heaviest component issued.  Most of those gathers read rows
+  // that were finished long ago.  So when band b-1 is narrow, its LAUNCH carries extra workgroups that run, on the
+  // idle units, the exact prefix pass of band b over the sources older than band b-1 (they depend on nothing band
+  // b-1 computes); band b then starts every row at split[] and gathers only the sources inside band b-1 and inside
+  // itself.  No launch is added.  Fast mode lists the old sources first in every row of such a band (relative order
+  // kept; the summation order of the row changes, tolerance-level like the block-dense bands); exact mode keeps the
+  // reference's order and carries only the leading run of old sources.
+  const int64_t nb_ = P.nbands();
+  P.band_fused.assign((size_t)nb_, 0);
+  auto band_first_slot = [&](int64_t b) { return P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b]]]; };
+  if (opt.fuse)
+    for (int64_t b = 1; b < nb_; ++b) {
+      const int64_t wgs_prev = P.band_wg_ptr[(size_t)b] - P.band_wg_ptr[(size_t)b - 1];
+      if (!P.band_dense[(size_t)b] && !P.band_prefix[(size_t)b] && !P.band_dense[(size_t)b - 1] && wgs_prev <= opt.fuse_max_wgs)
+        P.band_fused[(size_t)b] = 1;
+    }
   std::vector<int32_t> idx, tcol, tsrc;
   std::vector<T> tval;
-  for (int64_t b = 0; b < P.nbands(); ++b) {
-    const int32_t band0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b]]];
+  for (int64_t b = 0; b < nb_; ++b) {
+    const int32_t band0 = band_first_slot(b);
+    const int32_t prev0 = b > 0 ? band_first_slot(b - 1) : 0;
     for (int32_t g = P.band_wg_ptr[(size_t)b]; g < P.band_wg_ptr[(size_t)b + 1]; ++g) {
       const int32_t s0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]], s1 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]];
       for (int32_t s = s0; s < s1; ++s) {
@@ -592,17 +614,20 @@ void finish_band_plan(BandPlan &P, Csr<T> &A /* rows in slot order */) {
         // so that the chip-wide prefix pass folds every one of them in and [split, end) holds in-band
         // sources only.  The rows of the band's first block then need nothing but that prefix before their
         // block product (Engine::launch_trsv delivers it straight into the product's right-hand side).
-        if (P.band_dense[(size_t)b]) {
+        // Bands with a carried prefix (fast mode): the same with "older than band b-1" as the criterion.
+        const bool reorder = P.band_dense[(size_t)b] || (P.band_fused[(size_t)b] && opt.fuse_reorder);
+        const int32_t thr = P.band_dense[(size_t)b] ? s0 : prev0;
+        if (reorder) {
           const int32_t k0 = A.ptr[(size_t)s], k1 = A.ptr[(size_t)s + 1];
           idx.clear();
           for (int32_t k = k0; k < k1; ++k)
-            if (P.srcslot[(size_t)k] < s0) idx.push_back(k);
+            if (P.srcslot[(size_t)k] < thr) idx.push_back(k);
           const size_t npre = idx.size();
           bool moved = false;
           for (size_t q = 0; q < npre; ++q) moved = moved || idx[q] != k0 + (int32_t)q;
           if (moved) {
             for (int32_t k = k0; k < k1; ++k)
-              if (P.srcslot[(size_t)k] >= s0) idx.push_back(k);
+              if (P.srcslot[(size_t)k] >= thr) idx.push_back(k);
             tcol.resize(idx.size());
             tsrc.resize(idx.size());
             tval.resize(idx.size());
@@ -621,6 +646,8 @@ void finish_band_plan(BandPlan &P, Csr<T> &A /* rows in slot order */) {
         int32_t kk = A.ptr[(size_t)s];
         if (P.band_prefix[(size_t)b])
           while (kk < A.ptr[(size_t)s + 1] && P.srcslot[(size_t)kk] < s0) ++kk;
+        else if (P.band_fused[(size_t)b])
+          while (kk < A.ptr[(size_t)s + 1] && P.srcslot[(size_t)kk] < prev0) ++kk;
         P.split[(size_t)s] = kk;
         for (int32_t k = A.ptr[(size_t)s]; k < A.ptr[(size_t)s + 1]; ++k) {
           const int32_t q = P.srcslot[(size_t)k];  // either before the band, or earlier in this workgroup

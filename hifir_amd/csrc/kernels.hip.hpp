@@ -783,7 +783,8 @@ __global__ void __launch_bounds__(1024) k_trsv_band_p(int32_t wg0, const int32_t
                                                       const int32_t *__restrict__ col, const T *__restrict__ val,
                                                       const int32_t *__restrict__ srcslot,
                                                       const int32_t *__restrict__ rowid, const T *__restrict__ d,
-                                                      T *w, T *v, unsigned *errflag, int first_u
+                                                      T *w, T *v, unsigned *errflag, int first_u, int32_t n_band,
+                                                      int32_t ps0, int32_t ps1
 #ifdef HIFAMD_PROBE
                                                       ,
                                                       unsigned long long *ts, int probe_id
@@ -792,6 +793,14 @@ __global__ void __launch_bounds__(1024) k_trsv_band_p(int32_t wg0, const int32_t
   __shared__ int flag[HIFAMD_TAIL_MAX];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  // workgroups beyond the band's own: the carried prefix of the NEXT band, slots [ps0, ps1), over the sources older than
+  // this band (host.hpp finish_band_plan) -- independent of everything this launch computes, on otherwise idle units
+  if ((int32_t)blockIdx.x >= n_band) {
+    const int32_t pw = __builtin_amdgcn_readfirstlane(((int32_t)blockIdx.x - n_band) * nw + wave);
+    trsv_stream_r64<T, 0, LOWER, true>(ps0 + pw, ps1, ((int32_t)gridDim.x - n_band) * nw, ptr, split, col, val, nullptr, rowid,
+                                       d, LOWER ? w : v, w, lane, nullptr, 0, nullptr, true);
+    return;
+  }
 #ifdef HIFAMD_PROBE  // same record layout as k_trsv_band: 0 entry, 2 start of work, 3 exit, 4.. two rows x 6
   unsigned long long *tsw =
       (ts && blockIdx.x < 256) ? ts + (((size_t)probe_id * 256 + blockIdx.x) * 16 + wave) * 16 : nullptr;

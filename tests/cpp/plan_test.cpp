@@ -70,6 +70,22 @@ static int run(int64_t m, int fan, int64_t dense_block) {
         if (P.srcslot[(size_t)k] < s0) ++bad;
     }
   }
+  // bands with a carried prefix: [ptr, split) holds only sources older than the previous band, and after the
+  // reordering (fast mode) [split, end) holds none of them
+  int64_t nfused = 0;
+  for (int64_t b = 1; b < P.nbands(); ++b) {
+    if (!P.band_fused[(size_t)b]) continue;
+    ++nfused;
+    const int32_t prev0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b - 1]]];
+    for (int32_t g = P.band_wg_ptr[(size_t)b]; g < P.band_wg_ptr[(size_t)b + 1]; ++g)
+      for (int32_t s = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]]; s < P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]]; ++s) {
+        for (int32_t k = Ls.ptr[(size_t)s]; k < P.split[(size_t)s]; ++k)
+          if (P.srcslot[(size_t)k] >= prev0) ++bad;
+        for (int32_t k = P.split[(size_t)s]; k < Ls.ptr[(size_t)s + 1]; ++k)
+          if (P.srcslot[(size_t)k] < prev0) ++bad;
+      }
+  }
+  std::printf("(%ld bands with a carried prefix) ", (long)nfused);
   std::printf("m=%ld fan=%d cplx=%d: %ld wavefronts, %ld bands, %ld dense blocks (%ld operand doubles), bad=%d\n", (long)m, fan,
               (int)(sizeof(T) != sizeof(double)), (long)S.nwf(), (long)P.nbands(), (long)ndense, (long)elems, bad);
   return bad;
@@ -82,6 +98,7 @@ int main() {
   bad += run<double>(9000, 3, 512);
   bad += run<zdouble>(4000, 2, 1024);
   bad += run<double>(500, 1, 0);
+  bad += run<double>(60000, 6, 2048);
   std::printf(bad ? "FAIL\n" : "OK\n");
   return bad ? 1 : 0;
 }
