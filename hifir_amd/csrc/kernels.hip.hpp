@@ -13,7 +13,10 @@
 //   k_trsv_*  L: CCS::solve_as_strict_lower   ds/CompressedStorage.hpp:2268-2279 (+ mrhs :2287)
 //             D: y[i] /= d[i]                 alg/prec_solve.hpp:219 (fused into the first U kernel that touches a row)
 //             U: CCS::solve_as_strict_upper   ds/CompressedStorage.hpp:2357-2369 (+ mrhs :2377)
+//   k_trsv_band_p the band form at R = 64 (trsv_band_r64): next row's head behind the last gathers, one poll per item,
+//                 carried prefixes of the next band on the idle compute units (host.hpp finish_band_plan)
 //   k_spmm_epi    CCS::multiply_nt_low :2079 fused with  y = s[p]*b[p] - y  prec_solve.hpp:366-368,397-399
+//                 (R = 64: spmm_stream_r64, the same item/batch pipeline)
 //   k_gather_scale   work[i] = s[p[i]]*b[p[i]]           alg/prec_solve.hpp:359,402
 //   k_scatter_scale  y[i] = t[i]*work[q_inv[i]]          alg/prec_solve.hpp:411
 //   k_dense_gemm     QRCP::_solve_nt (ormqr, trsv, perm) small_scale/QRCP.hpp:371-411 on f64 MFMA
