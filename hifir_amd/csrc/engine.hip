@@ -16,6 +16,7 @@
 
 #include "../../include/hifir_amd.h"
 #include "host.hpp"
+#include "import.hpp"
 #include "kernels.hip.hpp"
 
 namespace hifamd {
@@ -364,25 +365,7 @@ class Engine : public EngineBase {
     io_ring = nullptr;
   }
 
-  // ---- import ------------------------------------------------------------------------------
-  static Ccs<T> make_ccs(int64_t nrows, int64_t ncols, const int64_t *cp, const int32_t *ri, const T *v) {
-    Ccs<T> A;
-    A.nrows = nrows;
-    A.ncols = ncols;
-    A.colptr.assign((size_t)ncols + 1, 0);
-    if (ncols > 0 && cp) {
-      if (cp[0] != 0) throw Error(HIFAMD_MISMATCHED_SIZES, "CCS column pointer must start at 0");
-      for (int64_t j = 0; j < ncols; ++j)
-        if (cp[j + 1] < cp[j]) throw Error(HIFAMD_MISMATCHED_SIZES, "CCS column pointer not monotone");
-      A.colptr.assign(cp, cp + ncols + 1);
-      const int64_t nz = cp[ncols];
-      if (nz > 0 && (!ri || !v)) throw Error(HIFAMD_NULL_OBJ, "NULL index/value array with nnz > 0");
-      A.rowind.assign(ri, ri + nz);
-      A.vals.assign(v, v + nz);
-    }
-    return A;
-  }
-
+  // ---- import (validation, conversion and analysis live in import.hpp: host-only, sanitizer-tested) ----------
   void add_level(int64_t m, int64_t n, const int64_t *Lcp, const int32_t *Lri, const T *Lv,
                  const int64_t *Ucp, const int32_t *Uri, const T *Uv, const int64_t *Ecp,
                  const int32_t *Eri, const T *Ev, int64_t F_ncols, const int64_t *Fcp,
@@ -390,115 +373,17 @@ class Engine : public EngineBase {
                  const int32_t *p, const int32_t *p_inv, const int32_t *q, const int32_t *q_inv) {
     if (finalized) throw Error(HIFAMD_BAD_PREC, "hierarchy already finalized");
     if (host.has_dense) throw Error(HIFAMD_BAD_PREC, "the dense block must come after the last level");
-    if (m < 0 || n < m || n <= 0) throw Error(HIFAMD_MISMATCHED_SIZES, "need 0 <= m <= n, n > 0");
-    if (!host.levels.empty()) {
-      const auto &prev = host.levels.back();
-      if (prev.n - prev.m != n)
-        throw Error(HIFAMD_MISMATCHED_SIZES, "level size must equal the parent's Schur complement size n-m");
-    }
-    if (!s || !t || !p || !q_inv || (m > 0 && !d)) throw Error(HIFAMD_NULL_OBJ, "NULL level vector");
-    const int64_t nm = n - m;
-    if (F_ncols != 0 && F_ncols != nm) throw Error(HIFAMD_MISMATCHED_SIZES, "F must have n-m columns (or 0)");
-    HostLevel<T> H;
-    H.m = m;
-    H.n = n;
-    H.F_ncols = F_ncols;
-    H.L = make_ccs(m, m, Lcp, Lri, Lv);
-    H.U = make_ccs(m, m, Ucp, Uri, Uv);
-    H.E = make_ccs(nm, nm ? m : 0, nm ? Ecp : nullptr, Eri, Ev);
-    H.F = make_ccs(m, F_ncols, F_ncols ? Fcp : nullptr, Fri, Fv);
-    H.d.assign(d, d + m);
-    H.s.assign(s, s + n);
-    H.t.assign(t, t + n);
-    H.p.assign(p, p + n);
-    H.q_inv.assign(q_inv, q_inv + n);
-    if (p_inv) H.p_inv.assign(p_inv, p_inv + n);
-    if (q) H.q.assign(q, q + n);
-    for (int64_t i = 0; i < n; ++i)
-      if (H.p[(size_t)i] < 0 || H.p[(size_t)i] >= n || H.q_inv[(size_t)i] < 0 || H.q_inv[(size_t)i] >= n)
-        throw Error(HIFAMD_MISMATCHED_SIZES, "permutation entry out of range");
-    H.Lr = ccs_to_csr(H.L, false);
-    H.Ur = ccs_to_csr(H.U, true);
-    H.Er = ccs_to_csr(H.E, false);
-    H.Fr = ccs_to_csr(H.F, false);
-    analyze_level(H);
+    const int64_t parent_nm = host.levels.empty() ? -1 : host.levels.back().n - host.levels.back().m;
+    HostLevel<T> H = import_level<T>(parent_nm, m, n, Lcp, Lri, Lv, Ucp, Uri, Uv, Ecp, Eri, Ev, F_ncols, Fcp, Fri, Fv, d, s,
+                                     t, p, p_inv, q, q_inv);
+    analyze_level(H, band_opt, env_int("HIFIR_AMD_PLAN_DUMP", 0) != 0, host.levels.size());
     host.levels.push_back(std::move(H));
-  }
-
-  // schedules, band plans, slot-ordered matrices and block inverses of one level (H.Lr .. H.Fr given)
-  void analyze_level(HostLevel<T> &H) {
-    const bool dump = env_int("HIFIR_AMD_PLAN_DUMP", 0) != 0;
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t0 = now();
-    H.Ls = level_schedule(H.Lr, true);
-    H.Us = level_schedule(H.Ur, false);
-    double t1 = now();
-    H.Lp = plan_bands(H.Lr, H.Ls, true, band_opt);
-    H.Up = plan_bands(H.Ur, H.Us, false, band_opt);
-    double t2 = now();
-    H.Lr = permute_rows(H.Lr, H.Lp.order);
-    H.Ur = permute_rows(H.Ur, H.Up.order);
-    finish_band_plan(H.Lp, H.Lr, band_opt);
-    finish_band_plan(H.Up, H.Ur, band_opt);
-    double t3 = now();
-    H.Ltinv_elems = plan_dense_blocks<T>(H.Lp, band_opt);
-    H.Utinv_elems = plan_dense_blocks<T>(H.Up, band_opt);
-    if (dump)
-      std::fprintf(stderr, "ANALYZE m=%ld: schedule %.2f s, band plan %.2f s, permute+finish %.2f s, block inverses %.2f s\n",
-                   (long)H.m, t1 - t0, t2 - t1, t3 - t2, now() - t3);
-    if (dump) {  // development aid: one line per band
-      for (int tri = 0; tri < 2; ++tri) {
-        const BandPlan &P = tri ? H.Up : H.Lp;
-        const Csr<T> &A = tri ? H.Ur : H.Lr;
-        for (int64_t b = 0; b < P.nbands(); ++b) {
-          const int32_t g0 = P.band_wg_ptr[(size_t)b], g1 = P.band_wg_ptr[(size_t)b + 1];
-          const int32_t s0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g0]], s1 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g1]];
-          int64_t maxnnz = 0, maxdepth = 0, maxrows = 0;
-          for (int32_t g = g0; g < g1; ++g) {
-            const int32_t a = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]], e = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]];
-            maxnnz = std::max<int64_t>(maxnnz, A.ptr[(size_t)e] - A.ptr[(size_t)a]);
-            maxrows = std::max<int64_t>(maxrows, e - a);
-            maxdepth = std::max<int64_t>(maxdepth, P.wg_grp_ptr[(size_t)g + 1] - P.wg_grp_ptr[(size_t)g]);
-          }
-          std::fprintf(stderr, "PLAN level=%zu tri=%c band=%ld rows=%d nnz=%d wgs=%d prefix=%d dense=%d maxwg_nnz=%ld maxwg_rows=%ld maxdepth=%ld\n",
-                       host.levels.size(), tri ? 'U' : 'L', (long)b, s1 - s0, A.ptr[(size_t)s1] - A.ptr[(size_t)s0], g1 - g0,
-                       (int)P.band_prefix[(size_t)b], (int)P.band_dense[(size_t)b], (long)maxnnz, (long)maxrows, (long)maxdepth);
-        }
-      }
-    }
   }
 
   // the adjoint of one imported level (see `adj` above)
   void add_level_adjoint(const HostLevel<T> &P) {
-    if (P.q.empty() || P.p_inv.empty())
-      throw Error(HIFAMD_BAD_PREC, "the transpose apply needs the q and p_inv permutations (hifamd_add_level)");
-    HostLevel<T> H;
-    H.m = P.m;
-    H.n = P.n;
-    const int64_t nm = P.n - P.m;
-    H.F_ncols = nm;  // E^H prolongs whenever there is a Schur complement (prec_solve.hpp:602)
-    H.Lr = adjoint_rows(P.U);  // U^H: strict lower
-    H.Ur = adjoint_rows(P.L);  // L^H: strict upper
-    if (P.F_ncols) {
-      H.Er = adjoint_rows(P.F);  // F^H: nm x m
-    } else {                     // no F: y[m:n] = t[q] b[q] (:574) -- an empty restriction
-      H.E_void = true;
-      H.Er.nrows = nm;
-      H.Er.ncols = nm ? P.m : 0;
-      H.Er.ptr.assign((size_t)nm + 1, 0);
-      H.Er.rowid.resize((size_t)nm);
-      for (int64_t i = 0; i < nm; ++i) H.Er.rowid[(size_t)i] = (int32_t)i;
-    }
-    H.Fr = adjoint_rows(P.E);  // E^H: m x nm
-    H.d.resize(P.d.size());
-    for (size_t i = 0; i < P.d.size(); ++i) H.d[i] = conj_(P.d[i]);
-    H.s = P.t;
-    H.t = P.s;
-    H.p = P.q;
-    H.q_inv = P.p_inv;
-    H.q = P.p;          // product on the adjoint hierarchy = prec_prod_tran: (s, p) in, (t, q_inv) out
-    H.p_inv = P.q_inv;
-    analyze_level(H);
+    HostLevel<T> H = adjoint_level(P);
+    analyze_level(H, band_opt, env_int("HIFIR_AMD_PLAN_DUMP", 0) != 0, host.levels.size());
     host.levels.push_back(std::move(H));
   }
 
@@ -637,26 +522,6 @@ class Engine : public EngineBase {
     prod_ready = true;
   }
 
-  // conjugate transpose of the user's CRS matrix (for iterative refinement with A^H, IterRefine.hpp:96)
-  static Csr<T> adjoint_of_csr(const Csr<T> &A) {
-    Csr<T> B;
-    B.nrows = A.ncols;
-    B.ncols = A.nrows;
-    B.ptr.assign((size_t)A.ncols + 1, 0);
-    for (size_t k = 0; k < A.col.size(); ++k) ++B.ptr[(size_t)A.col[k] + 1];
-    for (int64_t j = 0; j < A.ncols; ++j) B.ptr[(size_t)j + 1] += B.ptr[(size_t)j];
-    B.col.resize(A.col.size());
-    B.val.resize(A.val.size());
-    std::vector<int32_t> fill(B.ptr.begin(), B.ptr.end() - 1);
-    for (int64_t i = 0; i < A.nrows; ++i)
-      for (int32_t k = A.ptr[(size_t)i]; k < A.ptr[(size_t)i + 1]; ++k) {
-        const int32_t pos = fill[(size_t)A.col[(size_t)k]]++;
-        B.col[(size_t)pos] = (int32_t)i;
-        B.val[(size_t)pos] = conj_(A.val[(size_t)k]);
-      }
-    return B;
-  }
-
   void set_dense(int64_t nd, const T *mat, double rrqr_cond) {
     if (finalized) throw Error(HIFAMD_BAD_PREC, "hierarchy already finalized");
     if (host.levels.empty()) throw Error(HIFAMD_BAD_PREC, "add the sparse levels before the dense block");
@@ -736,6 +601,9 @@ class Engine : public EngineBase {
     Rmax = 1;
     while (Rmax < max_nrhs && Rmax < 64) Rmax <<= 1;
     Rmax = std::max<int64_t>(Rmax, 1LL << min_logR);
+    // every array the kernels index with is re-validated right before it is shipped (import.hpp): a host copy that
+    // is not what the conversion must have produced is refused here instead of hanging or mis-solving on the device
+    for (size_t l = 0; l < host.levels.size(); ++l) check_level_invariants(host.levels[l], l, adjoint);
     bind_device();
     for (auto &H : host.levels) {
       std::unique_ptr<DevLevel> Lp(new DevLevel());
@@ -1710,116 +1578,12 @@ class Engine : public EngineBase {
     HIP_OK(hipStreamSynchronize(stream));
   }
 
-  // ---- on-disk form of the imported hierarchy (exactly the hifamd_add_level / hifamd_set_dense arguments) ---
-  // so that a hierarchy factorized once on a host with the reference can be applied on GPU nodes that do
-  // not have it.  Little-endian, 8-byte aligned records: see hifir_amd.h.
-  template <class V>
-  static void put_vec(std::FILE *f, const std::vector<V> &v) {
-    const int64_t cnt = (int64_t)v.size();
-    if (std::fwrite(&cnt, sizeof(cnt), 1, f) != 1) throw Error(HIFAMD_HIFIR_ERROR, "short write");
-    if (cnt && std::fwrite(v.data(), sizeof(V), (size_t)cnt, f) != (size_t)cnt) throw Error(HIFAMD_HIFIR_ERROR, "short write");
-    const size_t padb = (8 - (cnt * sizeof(V)) % 8) % 8;
-    const char zeros[8] = {0};
-    if (padb && std::fwrite(zeros, 1, padb, f) != padb) throw Error(HIFAMD_HIFIR_ERROR, "short write");
-  }
-  template <class V>
-  static void get_vec(std::FILE *f, std::vector<V> &v) {
-    int64_t cnt = 0;
-    if (std::fread(&cnt, sizeof(cnt), 1, f) != 1 || cnt < 0 || cnt > (int64_t)1 << 40) throw Error(HIFAMD_BAD_PREC, "corrupt hierarchy file");
-    v.resize((size_t)cnt);
-    if (cnt && std::fread(v.data(), sizeof(V), (size_t)cnt, f) != (size_t)cnt) throw Error(HIFAMD_BAD_PREC, "truncated hierarchy file");
-    const size_t padb = (8 - (cnt * sizeof(V)) % 8) % 8;
-    char skip[8];
-    if (padb && std::fread(skip, 1, padb, f) != padb) throw Error(HIFAMD_BAD_PREC, "truncated hierarchy file");
-  }
-  static void put_ccs(std::FILE *f, const Ccs<T> &A) {
-    const int64_t hdr[2] = {A.nrows, A.ncols};
-    if (std::fwrite(hdr, sizeof(hdr), 1, f) != 1) throw Error(HIFAMD_HIFIR_ERROR, "short write");
-    put_vec(f, A.colptr);
-    put_vec(f, A.rowind);
-    put_vec(f, A.vals);
-  }
-  static void get_ccs(std::FILE *f, Ccs<T> &A) {
-    int64_t hdr[2];
-    if (std::fread(hdr, sizeof(hdr), 1, f) != 1) throw Error(HIFAMD_BAD_PREC, "truncated hierarchy file");
-    A.nrows = hdr[0];
-    A.ncols = hdr[1];
-    get_vec(f, A.colptr);
-    get_vec(f, A.rowind);
-    get_vec(f, A.vals);
-  }
+  // ---- on-disk form of the imported hierarchy (import.hpp save_hierarchy / load_hierarchy) -----------------
   void save(std::FILE *f) const {
     if (adjoint || is_twin) throw Error(HIFAMD_HIFIR_ERROR, "internal engines are not saved");
-    const int64_t nl = (int64_t)host.levels.size(), hd = host.has_dense ? (host.dense.kind == 2 ? 3 : host.dense.kind == 1 ? 2 : 1) : 0;
-    if (std::fwrite(&nl, 8, 1, f) != 1 || std::fwrite(&hd, 8, 1, f) != 1) throw Error(HIFAMD_HIFIR_ERROR, "short write");
-    for (const auto &H : host.levels) {
-      const int64_t hdr[3] = {H.m, H.n, H.F_ncols};
-      if (std::fwrite(hdr, sizeof(hdr), 1, f) != 1) throw Error(HIFAMD_HIFIR_ERROR, "short write");
-      put_ccs(f, H.L);
-      put_ccs(f, H.U);
-      put_ccs(f, H.E);
-      put_ccs(f, H.F);
-      put_vec(f, H.d);
-      put_vec(f, H.s);
-      put_vec(f, H.t);
-      put_vec(f, H.p);
-      put_vec(f, H.p_inv);
-      put_vec(f, H.q);
-      put_vec(f, H.q_inv);
-    }
-    if (hd) {
-      const int64_t nd = host.dense.n;
-      const double par = host.dense.kind == 1 ? (double)host.dense.spd : host.dense.rrqr_cond;  // (hd == 2: spd)
-      if (std::fwrite(&nd, 8, 1, f) != 1 || std::fwrite(&par, 8, 1, f) != 1)
-        throw Error(HIFAMD_HIFIR_ERROR, "short write");
-      put_vec(f, host.dense.mat);
-    }
+    save_hierarchy(f, host);
   }
-  void load(std::FILE *f) {
-    int64_t nl = 0, hd = 0;
-    if (std::fread(&nl, 8, 1, f) != 1 || std::fread(&hd, 8, 1, f) != 1 || nl < 1 || nl > 4096) throw Error(HIFAMD_BAD_PREC, "corrupt hierarchy file");
-    for (int64_t l = 0; l < nl; ++l) {
-      int64_t hdr[3];
-      if (std::fread(hdr, sizeof(hdr), 1, f) != 1) throw Error(HIFAMD_BAD_PREC, "truncated hierarchy file");
-      Ccs<T> L, U, E, F;
-      std::vector<T> d;
-      std::vector<double> s, t;
-      std::vector<int32_t> p, p_inv, q, q_inv;
-      get_ccs(f, L);
-      get_ccs(f, U);
-      get_ccs(f, E);
-      get_ccs(f, F);
-      get_vec(f, d);
-      get_vec(f, s);
-      get_vec(f, t);
-      get_vec(f, p);
-      get_vec(f, p_inv);
-      get_vec(f, q);
-      get_vec(f, q_inv);
-      const int64_t m = hdr[0], n = hdr[1];
-      if ((int64_t)d.size() != m || (int64_t)s.size() != n || (int64_t)t.size() != n || (int64_t)p.size() != n ||
-          (int64_t)q_inv.size() != n || (int64_t)L.colptr.size() != m + 1 || (int64_t)U.colptr.size() != m + 1)
-        throw Error(HIFAMD_BAD_PREC, "inconsistent hierarchy file");
-      add_level(m, n, L.colptr.data(), L.rowind.data(), L.vals.data(), U.colptr.data(), U.rowind.data(), U.vals.data(),
-                E.colptr.data(), E.rowind.data(), E.vals.data(), hdr[2], hdr[2] ? F.colptr.data() : nullptr,
-                F.rowind.data(), F.vals.data(), d.data(), s.data(), t.data(), p.data(),
-                p_inv.empty() ? nullptr : p_inv.data(), q.empty() ? nullptr : q.data(), q_inv.data());
-    }
-    if (hd) {
-      int64_t nd = 0;
-      double cond = 0.0;
-      if (std::fread(&nd, 8, 1, f) != 1 || std::fread(&cond, 8, 1, f) != 1) throw Error(HIFAMD_BAD_PREC, "truncated hierarchy file");
-      std::vector<T> mat;
-      get_vec(f, mat);
-      if ((int64_t)mat.size() != nd * nd) throw Error(HIFAMD_BAD_PREC, "inconsistent hierarchy file");
-      if (hd == 3)
-        set_dense_lup(nd, mat.data());
-      else if (hd == 2)
-        set_dense_symm(nd, mat.data(), (int)cond);
-      else
-        set_dense(nd, mat.data(), cond);
-    }
-  }
+  void load(std::FILE *f) { load_hierarchy<T>(f, *this); }
 
   // development aid: one checksum per device-resident array (order documented in tests), to tell which
   // upload differs when two handles built from the same hierarchy disagree
@@ -2392,6 +2156,7 @@ HifAmdStatus hifamd_finalize(HifAmdHdl h, int64_t max_nrhs) {
   return h->vt == HIFAMD_D ? (expr_d) : (expr_z);
 
 
+int hifamd_value_type(HifAmdHdl h) { return (h && h->eng) ? h->vt : -1; }
 int64_t hifamd_nrows(HifAmdHdl h) { QUERY(q_nrows(ENG_D), q_nrows(ENG_Z)) }
 int64_t hifamd_levels(HifAmdHdl h) { QUERY(q_levels(ENG_D), q_levels(ENG_Z)) }
 int64_t hifamd_nnz(HifAmdHdl h) { QUERY(ENG_D->nnz_total(), ENG_Z->nnz_total()) }

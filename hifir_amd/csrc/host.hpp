@@ -31,6 +31,14 @@ template <class F>
 inline void parallel_for(int64_t n, int64_t chunk, F f) {
   if (n <= 0) return;
   if (chunk < 1) chunk = 1;
+#ifdef HIFAMD_TEST_OPENMP  // tests/cpp/import_san_test.cpp only: the OpenMP loops the library had before it went thread-only
+  {
+    const int64_t nchunks_ = (n + chunk - 1) / chunk;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t c = 0; c < nchunks_; ++c) f(c * chunk, std::min(n, (c + 1) * chunk));
+    return;
+  }
+#endif
   unsigned hw = std::thread::hardware_concurrency();
   if (hw == 0) hw = 4;
   if (const char *e = std::getenv("HIFIR_AMD_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));

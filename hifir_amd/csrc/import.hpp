@@ -1,0 +1,395 @@
+// import.hpp -- host-only half of the hierarchy import: argument validation of hifamd_add_level, CCS -> CSR,
+// the band analysis of one level, the adjoint level, the on-disk format (hifamd_save / hifamd_load) and the
+// invariant check that hifamd_finalize runs before anything is shipped to HBM.
+//
+// Pure C++17, no HIP: engine.hip uses it for the product, and tests/cpp/import_san_test.cpp compiles the very same
+// code with g++ / clang++ under -fsanitize=address,undefined and -fsanitize=thread (the GPU pool has no sanitizers).
+// Reference data contract: hif::Prec, src/hif/alg/Prec.hpp:82-334.
+#pragma once
+#include "host.hpp"
+
+namespace hifamd {
+
+// status codes of include/hifir_amd.h (== LhfStatus, libhifir/include/libhifir.h:148-154), usable without that header
+enum : int { kNullObj = 1, kMismatchedSizes = 2, kBadPrec = 3, kHifirError = 4 };
+
+template <class T>
+Ccs<T> make_ccs(int64_t nrows, int64_t ncols, const int64_t *cp, const int32_t *ri, const T *v) {
+  Ccs<T> A;
+  A.nrows = nrows;
+  A.ncols = ncols;
+  A.colptr.assign((size_t)ncols + 1, 0);
+  if (ncols > 0 && cp) {
+    if (cp[0] != 0) throw Error(kMismatchedSizes, "CCS column pointer must start at 0");
+    for (int64_t j = 0; j < ncols; ++j)
+      if (cp[j + 1] < cp[j]) throw Error(kMismatchedSizes, "CCS column pointer not monotone");
+    A.colptr.assign(cp, cp + ncols + 1);
+    const int64_t nz = cp[ncols];
+    if (nz > 0 && (!ri || !v)) throw Error(kNullObj, "NULL index/value array with nnz > 0");
+    A.rowind.assign(ri, ri + nz);
+    A.vals.assign(v, v + nz);
+  }
+  return A;
+}
+
+// every entry in [0, n) exactly once
+inline bool is_permutation(const std::vector<int32_t> &p, int64_t n) {
+  if ((int64_t)p.size() != n) return false;
+  std::vector<uint8_t> seen((size_t)n, 0);
+  for (int32_t v : p) {
+    if (v < 0 || v >= n || seen[(size_t)v]) return false;
+    seen[(size_t)v] = 1;
+  }
+  return true;
+}
+
+// The arguments of hifamd_add_level -> one HostLevel with its four matrices in row-gather form (no analysis yet).
+// parent_nm: n - m of the previous level, or -1 for the first one.
+template <class T>
+HostLevel<T> import_level(int64_t parent_nm, int64_t m, int64_t n, const int64_t *Lcp, const int32_t *Lri, const T *Lv,
+                          const int64_t *Ucp, const int32_t *Uri, const T *Uv, const int64_t *Ecp, const int32_t *Eri,
+                          const T *Ev, int64_t F_ncols, const int64_t *Fcp, const int32_t *Fri, const T *Fv, const T *d,
+                          const double *s, const double *t, const int32_t *p, const int32_t *p_inv, const int32_t *q,
+                          const int32_t *q_inv) {
+  if (m < 0 || n < m || n <= 0) throw Error(kMismatchedSizes, "need 0 <= m <= n, n > 0");
+  if (n > (int64_t)std::numeric_limits<int32_t>::max()) throw Error(kMismatchedSizes, "level size exceeds int32 indices");
+  if (parent_nm >= 0 && parent_nm != n)
+    throw Error(kMismatchedSizes, "level size must equal the parent's Schur complement size n-m");
+  if (!s || !t || !p || !q_inv || (m > 0 && !d)) throw Error(kNullObj, "NULL level vector");
+  const int64_t nm = n - m;
+  if (F_ncols != 0 && F_ncols != nm) throw Error(kMismatchedSizes, "F must have n-m columns (or 0)");
+  HostLevel<T> H;
+  H.m = m;
+  H.n = n;
+  H.F_ncols = F_ncols;
+  H.L = make_ccs(m, m, Lcp, Lri, Lv);
+  H.U = make_ccs(m, m, Ucp, Uri, Uv);
+  H.E = make_ccs(nm, nm ? m : 0, nm ? Ecp : nullptr, Eri, Ev);
+  H.F = make_ccs(m, F_ncols, F_ncols ? Fcp : nullptr, Fri, Fv);
+  H.d.assign(d, d + m);
+  H.s.assign(s, s + n);
+  H.t.assign(t, t + n);
+  H.p.assign(p, p + n);
+  H.q_inv.assign(q_inv, q_inv + n);
+  if (p_inv) H.p_inv.assign(p_inv, p_inv + n);
+  if (q) H.q.assign(q, q + n);
+  // all four are gather indices on the device (p, q_inv: solve; q, p_inv: transpose solve and products)
+  if (!is_permutation(H.p, n) || !is_permutation(H.q_inv, n) || (p_inv && !is_permutation(H.p_inv, n)) ||
+      (q && !is_permutation(H.q, n)))
+    throw Error(kMismatchedSizes, "p, q_inv (and p_inv, q when given) must be permutations of [0, n)");
+  H.Lr = ccs_to_csr(H.L, false);  // (row indices are range-checked there)
+  H.Ur = ccs_to_csr(H.U, true);
+  H.Er = ccs_to_csr(H.E, false);
+  H.Fr = ccs_to_csr(H.F, false);
+  return H;
+}
+
+// schedules, band plans, slot-ordered matrices and the block cutting of one level (H.Lr .. H.Fr given)
+template <class T>
+void analyze_level(HostLevel<T> &H, const BandOptions &band_opt, bool dump = false, size_t level_no = 0) {
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t0 = now();
+  H.Ls = level_schedule(H.Lr, true);
+  H.Us = level_schedule(H.Ur, false);
+  double t1 = now();
+  H.Lp = plan_bands(H.Lr, H.Ls, true, band_opt);
+  H.Up = plan_bands(H.Ur, H.Us, false, band_opt);
+  double t2 = now();
+  H.Lr = permute_rows(H.Lr, H.Lp.order);
+  H.Ur = permute_rows(H.Ur, H.Up.order);
+  finish_band_plan(H.Lp, H.Lr, band_opt);
+  finish_band_plan(H.Up, H.Ur, band_opt);
+  double t3 = now();
+  H.Ltinv_elems = plan_dense_blocks<T>(H.Lp, band_opt);
+  H.Utinv_elems = plan_dense_blocks<T>(H.Up, band_opt);
+  if (!dump) return;
+  std::fprintf(stderr, "ANALYZE m=%ld: schedule %.2f s, band plan %.2f s, permute+finish %.2f s, block cutting %.2f s\n",
+               (long)H.m, t1 - t0, t2 - t1, t3 - t2, now() - t3);
+  for (int tri = 0; tri < 2; ++tri) {  // development aid: one line per band
+    const BandPlan &P = tri ? H.Up : H.Lp;
+    const Csr<T> &A = tri ? H.Ur : H.Lr;
+    for (int64_t b = 0; b < P.nbands(); ++b) {
+      const int32_t g0 = P.band_wg_ptr[(size_t)b], g1 = P.band_wg_ptr[(size_t)b + 1];
+      const int32_t s0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g0]], s1 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g1]];
+      int64_t maxnnz = 0, maxdepth = 0, maxrows = 0;
+      for (int32_t g = g0; g < g1; ++g) {
+        const int32_t a = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]], e = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]];
+        maxnnz = std::max<int64_t>(maxnnz, A.ptr[(size_t)e] - A.ptr[(size_t)a]);
+        maxrows = std::max<int64_t>(maxrows, e - a);
+        maxdepth = std::max<int64_t>(maxdepth, P.wg_grp_ptr[(size_t)g + 1] - P.wg_grp_ptr[(size_t)g]);
+      }
+      std::fprintf(stderr, "PLAN level=%zu tri=%c band=%ld rows=%d nnz=%d wgs=%d prefix=%d dense=%d fused=%d maxwg_nnz=%ld maxwg_rows=%ld maxdepth=%ld\n",
+                   level_no, tri ? 'U' : 'L', (long)b, s1 - s0, A.ptr[(size_t)s1] - A.ptr[(size_t)s0], g1 - g0,
+                   (int)P.band_prefix[(size_t)b], (int)P.band_dense[(size_t)b], (int)P.band_fused[(size_t)b], (long)maxnnz,
+                   (long)maxrows, (long)maxdepth);
+    }
+  }
+}
+
+// x = M^{-H} b (prec_solve_tran, alg/prec_solve.hpp:542-612) is the SAME machinery on the adjoint hierarchy:
+// L' = U^H, U' = L^H, E' = F^H, F' = E^H, d' = conj(d), (s', p') = (t, q), (t', q_inv') = (s, p_inv).
+template <class T>
+HostLevel<T> adjoint_level(const HostLevel<T> &P) {
+  if (P.q.empty() || P.p_inv.empty())
+    throw Error(kBadPrec, "the transpose apply needs the q and p_inv permutations (hifamd_add_level)");
+  HostLevel<T> H;
+  H.m = P.m;
+  H.n = P.n;
+  const int64_t nm = P.n - P.m;
+  H.F_ncols = nm;  // E^H prolongs whenever there is a Schur complement (prec_solve.hpp:602)
+  H.Lr = adjoint_rows(P.U);  // U^H: strict lower
+  H.Ur = adjoint_rows(P.L);  // L^H: strict upper
+  if (P.F_ncols) {
+    H.Er = adjoint_rows(P.F);  // F^H: nm x m
+  } else {                     // no F: y[m:n] = t[q] b[q] (:574) -- an empty restriction
+    H.E_void = true;
+    H.Er.nrows = nm;
+    H.Er.ncols = nm ? P.m : 0;
+    H.Er.ptr.assign((size_t)nm + 1, 0);
+    H.Er.rowid.resize((size_t)nm);
+    for (int64_t i = 0; i < nm; ++i) H.Er.rowid[(size_t)i] = (int32_t)i;
+  }
+  H.Fr = adjoint_rows(P.E);  // E^H: m x nm
+  H.d.resize(P.d.size());
+  for (size_t i = 0; i < P.d.size(); ++i) H.d[i] = conj_(P.d[i]);
+  H.s = P.t;
+  H.t = P.s;
+  H.p = P.q;
+  H.q_inv = P.p_inv;
+  H.q = P.p;  // product on the adjoint hierarchy = prec_prod_tran: (s, p) in, (t, q_inv) out
+  H.p_inv = P.q_inv;
+  return H;
+}
+
+// conjugate transpose of the user's CRS matrix (for iterative refinement with A^H, IterRefine.hpp:96)
+template <class T>
+Csr<T> adjoint_of_csr(const Csr<T> &A) {
+  Csr<T> B;
+  B.nrows = A.ncols;
+  B.ncols = A.nrows;
+  B.ptr.assign((size_t)A.ncols + 1, 0);
+  for (size_t k = 0; k < A.col.size(); ++k) ++B.ptr[(size_t)A.col[k] + 1];
+  for (int64_t j = 0; j < A.ncols; ++j) B.ptr[(size_t)j + 1] += B.ptr[(size_t)j];
+  B.col.resize(A.col.size());
+  B.val.resize(A.val.size());
+  std::vector<int32_t> fill(B.ptr.begin(), B.ptr.end() - 1);
+  for (int64_t i = 0; i < A.nrows; ++i)
+    for (int32_t k = A.ptr[(size_t)i]; k < A.ptr[(size_t)i + 1]; ++k) {
+      const int32_t pos = fill[(size_t)A.col[(size_t)k]]++;
+      B.col[(size_t)pos] = (int32_t)i;
+      B.val[(size_t)pos] = conj_(A.val[(size_t)k]);
+    }
+  return B;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Invariants of everything the kernels index with.  hifamd_finalize runs this right before the upload: a hierarchy
+// whose converted arrays are not what the conversion must have produced (whatever the cause) is refused with
+// HIFAMD_HIFIR_ERROR instead of being applied -- a wrong row pointer on the device is a hang or a wrong answer.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+void check_csr(const Csr<T> &A, int64_t nnz_expected, const char *what, size_t level_no) {
+  auto fail = [&](const char *why, int64_t at) {
+    throw Error(kHifirError, std::string("internal error: ") + what + " of level " + std::to_string(level_no) + ": " + why +
+                                 " at " + std::to_string(at) + " (host copy of the hierarchy is corrupt)");
+  };
+  if ((int64_t)A.ptr.size() != A.nrows + 1) fail("row pointer length", (int64_t)A.ptr.size());
+  if (A.ptr[0] != 0) fail("row pointer does not start at 0", 0);
+  for (int64_t i = 0; i < A.nrows; ++i)
+    if (A.ptr[(size_t)i + 1] < A.ptr[(size_t)i]) fail("row pointer not monotone", i);
+  const int64_t nz = A.ptr[(size_t)A.nrows];
+  if (nz != nnz_expected || (int64_t)A.col.size() != nz || (int64_t)A.val.size() != nz) fail("nonzero count", nz);
+  for (int64_t k = 0; k < nz; ++k)
+    if (A.col[(size_t)k] < 0 || A.col[(size_t)k] >= A.ncols) fail("column index out of range", k);
+  if ((int64_t)A.rowid.size() != A.nrows) fail("row id length", (int64_t)A.rowid.size());
+  if (!is_permutation(A.rowid, A.nrows)) fail("row ids are not a permutation", 0);
+}
+
+template <class T>
+void check_band_plan(const BandPlan &P, const Csr<T> &A, const char *what, size_t level_no) {
+  auto fail = [&](const char *why, int64_t at) {
+    throw Error(kHifirError, std::string("internal error: band plan of ") + what + " of level " + std::to_string(level_no) +
+                                 ": " + why + " at " + std::to_string(at));
+  };
+  const int64_t m = A.nrows, nz = (int64_t)A.col.size();
+  if ((int64_t)P.split.size() != m || (int64_t)P.srcslot.size() != nz) fail("array length", m);
+  for (int64_t s = 0; s < m; ++s)
+    if (P.split[(size_t)s] < A.ptr[(size_t)s] || P.split[(size_t)s] > A.ptr[(size_t)s + 1]) fail("split outside its row", s);
+  for (int64_t k = 0; k < nz; ++k)
+    if (P.srcslot[(size_t)k] < 0 || P.srcslot[(size_t)k] >= m) fail("source slot out of range", k);
+  auto monotone = [&](const std::vector<int32_t> &v, int64_t last, const char *name) {
+    if (v.empty() || v[0] != 0 || v.back() != last) fail(name, (int64_t)v.size());
+    for (size_t i = 0; i + 1 < v.size(); ++i)
+      if (v[i + 1] < v[i]) fail(name, (int64_t)i);
+  };
+  monotone(P.grp_slot_ptr, (int32_t)m, "group pointer");
+  monotone(P.wg_grp_ptr, (int32_t)P.grp_slot_ptr.size() - 1, "workgroup pointer");
+  monotone(P.band_wg_ptr, (int32_t)P.wg_grp_ptr.size() - 1, "band pointer");
+  for (int32_t g = 0; g + 1 < (int32_t)P.wg_grp_ptr.size(); ++g)
+    if (P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]] - P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]] > 16384)
+      fail("workgroup owns more rows than it has LDS flags", g);
+  for (size_t q = 0; q < P.blk_slot0.size(); ++q)
+    if (P.blk_slot0[q] < 0 || P.blk_slot1[q] <= P.blk_slot0[q] || P.blk_slot1[q] > m) fail("block range", (int64_t)q);
+}
+
+template <class T>
+void check_level_invariants(const HostLevel<T> &H, size_t level_no, bool adjoint = false) {
+  const int64_t m = H.m, n = H.n, nm = n - m;
+  auto fail = [&](const char *why) {
+    throw Error(kHifirError, std::string("internal error: level ") + std::to_string(level_no) + ": " + why +
+                                 " (host copy of the hierarchy is corrupt)");
+  };
+  if (H.Lr.nrows != m || H.Ur.nrows != m || H.Er.nrows != nm || H.Fr.nrows != m) fail("matrix shapes");
+  if (H.Lr.ncols != m || H.Ur.ncols != m || (nm && H.Er.ncols != m)) fail("matrix shapes");
+  if (H.F_ncols && H.Fr.ncols != nm) fail("matrix shapes");
+  // (the adjoint level keeps no CCS copies: its row forms ARE the CCS arrays of the primary level)
+  check_csr(H.Lr, adjoint ? (int64_t)H.Lr.col.size() : H.L.nnz(), "L", level_no);
+  check_csr(H.Ur, adjoint ? (int64_t)H.Ur.col.size() : H.U.nnz(), "U", level_no);
+  check_csr(H.Er, adjoint ? (int64_t)H.Er.col.size() : H.E.nnz(), "E", level_no);
+  check_csr(H.Fr, adjoint ? (int64_t)H.Fr.col.size() : H.F.nnz(), "F", level_no);
+  check_band_plan(H.Lp, H.Lr, "L", level_no);
+  check_band_plan(H.Up, H.Ur, "U", level_no);
+  if ((int64_t)H.d.size() != m || (int64_t)H.s.size() != n || (int64_t)H.t.size() != n) fail("vector lengths");
+  if (!is_permutation(H.p, n) || !is_permutation(H.q_inv, n)) fail("p / q_inv are not permutations");
+  if (!H.p_inv.empty() && !is_permutation(H.p_inv, n)) fail("p_inv is not a permutation");
+  if (!H.q.empty() && !is_permutation(H.q, n)) fail("q is not a permutation");
+}
+
+// ---------------------------------------------------------------------------------------------
+// On-disk form of the imported hierarchy: exactly the hifamd_add_level / hifamd_set_dense arguments, so that a
+// hierarchy factorized once on a host with the reference can be applied on GPU nodes that do not have it.
+// Little-endian, 8-byte aligned records, see include/hifir_amd.h.
+// ---------------------------------------------------------------------------------------------
+template <class V>
+void put_vec(std::FILE *f, const std::vector<V> &v) {
+  const int64_t cnt = (int64_t)v.size();
+  if (std::fwrite(&cnt, sizeof(cnt), 1, f) != 1) throw Error(kHifirError, "short write");
+  if (cnt && std::fwrite(v.data(), sizeof(V), (size_t)cnt, f) != (size_t)cnt) throw Error(kHifirError, "short write");
+  const size_t padb = (8 - (cnt * sizeof(V)) % 8) % 8;
+  const char zeros[8] = {0};
+  if (padb && std::fwrite(zeros, 1, padb, f) != padb) throw Error(kHifirError, "short write");
+}
+// `limit`: the largest count the file may claim (what the header of the record allows) -- a corrupt count is
+// refused BEFORE anything of that size is allocated
+template <class V>
+void get_vec(std::FILE *f, std::vector<V> &v, int64_t limit) {
+  int64_t cnt = 0;
+  if (std::fread(&cnt, sizeof(cnt), 1, f) != 1) throw Error(kBadPrec, "truncated hierarchy file");
+  if (cnt < 0 || cnt > limit) throw Error(kBadPrec, "corrupt hierarchy file (array length)");
+  v.resize((size_t)cnt);
+  if (cnt && std::fread(v.data(), sizeof(V), (size_t)cnt, f) != (size_t)cnt) throw Error(kBadPrec, "truncated hierarchy file");
+  const size_t padb = (8 - (cnt * sizeof(V)) % 8) % 8;
+  char skip[8];
+  if (padb && std::fread(skip, 1, padb, f) != padb) throw Error(kBadPrec, "truncated hierarchy file");
+}
+template <class T>
+void put_ccs(std::FILE *f, const Ccs<T> &A) {
+  const int64_t hdr[2] = {A.nrows, A.ncols};
+  if (std::fwrite(hdr, sizeof(hdr), 1, f) != 1) throw Error(kHifirError, "short write");
+  put_vec(f, A.colptr);
+  put_vec(f, A.rowind);
+  put_vec(f, A.vals);
+}
+// nrows / ncols: what the level header implies; every length is checked against it and against colptr.back()
+// before a single pointer is handed on
+template <class T>
+void get_ccs(std::FILE *f, Ccs<T> &A, int64_t nrows, int64_t ncols) {
+  int64_t hdr[2];
+  if (std::fread(hdr, sizeof(hdr), 1, f) != 1) throw Error(kBadPrec, "truncated hierarchy file");
+  if (hdr[0] != nrows || hdr[1] != ncols) throw Error(kBadPrec, "inconsistent hierarchy file (matrix shape)");
+  A.nrows = nrows;
+  A.ncols = ncols;
+  get_vec(f, A.colptr, ncols + 1);
+  if ((int64_t)A.colptr.size() != ncols + 1 || A.colptr[0] != 0) throw Error(kBadPrec, "inconsistent hierarchy file (column pointer)");
+  for (int64_t j = 0; j < ncols; ++j)
+    if (A.colptr[(size_t)j + 1] < A.colptr[(size_t)j]) throw Error(kBadPrec, "inconsistent hierarchy file (column pointer)");
+  const int64_t nz = A.colptr.back();
+  if (nz > (int64_t)std::numeric_limits<int32_t>::max()) throw Error(kBadPrec, "inconsistent hierarchy file (nonzero count)");
+  get_vec(f, A.rowind, nz);
+  get_vec(f, A.vals, nz);
+  if ((int64_t)A.rowind.size() != nz || (int64_t)A.vals.size() != nz) throw Error(kBadPrec, "inconsistent hierarchy file (nonzero count)");
+}
+
+template <class T>
+void save_hierarchy(std::FILE *f, const HostHierarchy<T> &host) {
+  const int64_t nl = (int64_t)host.levels.size(), hd = host.has_dense ? (host.dense.kind == 2 ? 3 : host.dense.kind == 1 ? 2 : 1) : 0;
+  if (std::fwrite(&nl, 8, 1, f) != 1 || std::fwrite(&hd, 8, 1, f) != 1) throw Error(kHifirError, "short write");
+  for (const auto &H : host.levels) {
+    const int64_t hdr[3] = {H.m, H.n, H.F_ncols};
+    if (std::fwrite(hdr, sizeof(hdr), 1, f) != 1) throw Error(kHifirError, "short write");
+    put_ccs(f, H.L);
+    put_ccs(f, H.U);
+    put_ccs(f, H.E);
+    put_ccs(f, H.F);
+    put_vec(f, H.d);
+    put_vec(f, H.s);
+    put_vec(f, H.t);
+    put_vec(f, H.p);
+    put_vec(f, H.p_inv);
+    put_vec(f, H.q);
+    put_vec(f, H.q_inv);
+  }
+  if (hd) {
+    const int64_t nd = host.dense.n;
+    const double par = host.dense.kind == 1 ? (double)host.dense.spd : host.dense.rrqr_cond;  // (hd == 2: spd)
+    if (std::fwrite(&nd, 8, 1, f) != 1 || std::fwrite(&par, 8, 1, f) != 1) throw Error(kHifirError, "short write");
+    put_vec(f, host.dense.mat);
+  }
+}
+
+// Replays a file into `sink` (add_level / set_dense / set_dense_symm / set_dense_lup with the ABI's argument
+// lists).  Every array length is validated against the level header and the column pointers before use.
+template <class T, class Sink>
+void load_hierarchy(std::FILE *f, Sink &sink) {
+  int64_t nl = 0, hd = 0;
+  if (std::fread(&nl, 8, 1, f) != 1 || std::fread(&hd, 8, 1, f) != 1) throw Error(kBadPrec, "truncated hierarchy file");
+  if (nl < 1 || nl > 4096 || hd < 0 || hd > 3) throw Error(kBadPrec, "corrupt hierarchy file (header)");
+  int64_t last_nm = 0;
+  for (int64_t l = 0; l < nl; ++l) {
+    int64_t hdr[3];
+    if (std::fread(hdr, sizeof(hdr), 1, f) != 1) throw Error(kBadPrec, "truncated hierarchy file");
+    const int64_t m = hdr[0], n = hdr[1], fn = hdr[2], nm = n - m;
+    if (m < 0 || n < m || n <= 0 || n > (int64_t)std::numeric_limits<int32_t>::max() || (fn != 0 && fn != nm))
+      throw Error(kBadPrec, "corrupt hierarchy file (level header)");
+    Ccs<T> L, U, E, F;
+    std::vector<T> d;
+    std::vector<double> s, t;
+    std::vector<int32_t> p, p_inv, q, q_inv;
+    get_ccs(f, L, m, m);
+    get_ccs(f, U, m, m);
+    get_ccs(f, E, nm, nm ? m : 0);
+    get_ccs(f, F, m, fn);
+    get_vec(f, d, m);
+    get_vec(f, s, n);
+    get_vec(f, t, n);
+    get_vec(f, p, n);
+    get_vec(f, p_inv, n);
+    get_vec(f, q, n);
+    get_vec(f, q_inv, n);
+    if ((int64_t)d.size() != m || (int64_t)s.size() != n || (int64_t)t.size() != n || (int64_t)p.size() != n ||
+        (int64_t)q_inv.size() != n || (!p_inv.empty() && (int64_t)p_inv.size() != n) || (!q.empty() && (int64_t)q.size() != n))
+      throw Error(kBadPrec, "inconsistent hierarchy file (vector lengths)");
+    sink.add_level(m, n, L.colptr.data(), L.rowind.data(), L.vals.data(), U.colptr.data(), U.rowind.data(), U.vals.data(),
+                   E.colptr.data(), E.rowind.data(), E.vals.data(), fn, fn ? F.colptr.data() : nullptr, F.rowind.data(),
+                   F.vals.data(), d.data(), s.data(), t.data(), p.data(), p_inv.empty() ? nullptr : p_inv.data(),
+                   q.empty() ? nullptr : q.data(), q_inv.data());
+    last_nm = nm;
+  }
+  if (hd) {
+    int64_t nd = 0;
+    double cond = 0.0;
+    if (std::fread(&nd, 8, 1, f) != 1 || std::fread(&cond, 8, 1, f) != 1) throw Error(kBadPrec, "truncated hierarchy file");
+    if (nd != last_nm || nd <= 0) throw Error(kBadPrec, "inconsistent hierarchy file (dense block size)");
+    std::vector<T> mat;
+    get_vec(f, mat, nd * nd);
+    if ((int64_t)mat.size() != nd * nd) throw Error(kBadPrec, "inconsistent hierarchy file (dense block)");
+    if (hd == 3)
+      sink.set_dense_lup(nd, mat.data());
+    else if (hd == 2)
+      sink.set_dense_symm(nd, mat.data(), (int)cond);
+    else
+      sink.set_dense(nd, mat.data(), cond);
+  }
+}
+
+}  // namespace hifamd

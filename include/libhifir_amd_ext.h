@@ -1,0 +1,48 @@
+/* libhifir_amd_ext.h -- the ADDITIVE exports of the drop-in libhifir (shim/libhifir_amd_shim.cpp).
+ *
+ * The shim exports every symbol of the reference's C ABI with identical signatures (it compiles against the
+ * reference's own libhifir/include/libhifir.h, so the compiler checks that) and serves lhf?Apply / lhf?Solve from
+ * HBM through include/hifir_amd.h.  The entry points below have no reference counterpart ("additive
+ * exports the build needs"); include this header AFTER libhifir.h.
+ */
+#ifndef LIBHIFIR_AMD_EXT_H
+#define LIBHIFIR_AMD_EXT_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HIP ordinals on which handles created AFTERWARDS keep a resident copy of their hierarchy (default: the current
+ * device only).  lhf?ApplyBatch shards the right-hand-side columns over them -- contiguous column blocks, one host
+ * thread per device, no data-path collective; lhf?Apply / lhf?Solve use the first one.  The same
+ * ordinal may be listed more than once (independent replicas on one GPU: rehearses the sharding on a 1-GPU box).
+ * n <= 0 or ids == NULL restores the default.  LHF_MISMATCHED_SIZES for an ordinal the process cannot see. */
+LhfStatus lhfSetDevices(const int *ids, int n);
+/* number of HIP devices visible to the process (0: every Create / Setup fails with LHF_HIFIR_ERROR -- no CPU fallback) */
+int lhfGetDeviceCount(void);
+
+/* lhf?Apply (libhifir.h:685, :997) for nrhs right-hand sides at once.  B and X are row-interleaved [n][nrhs]
+ * blocks with row strides ldb, ldx (in elements): the layout of hif::Array<std::array<T, Nrhs>>
+ * (src/hif/ds/CompressedStorage.hpp:2127).  Same operator / nirs / betas / rank rules as lhf?Apply
+ * (libhifir.cpp:447-472); ir_status, if given with betas, receives {iterations, flag} per column (2 * nrhs ints). */
+LhfStatus lhfdApplyBatch(const LhfdHifHdl hif, const LhfOperationType op, const double *B, const size_t nrhs,
+                         const size_t ldb, const int nirs, const double *betas, const int rank, double *X,
+                         const size_t ldx, int *ir_status);
+LhfStatus lhfzApplyBatch(const LhfzHifHdl hif, const LhfOperationType op, const double _Complex *B, const size_t nrhs,
+                         const size_t ldb, const int nirs, const double *betas, const int rank, double _Complex *X,
+                         const size_t ldx, int *ir_status);
+
+/* Export / import of the factored hierarchy in the on-disk format of hifamd_save / hifamd_load (include/hifir_amd.h):
+ * factorize once where the host factorization is affordable, apply on GPU nodes without refactorizing.  A loaded
+ * handle serves Apply / Solve / the size queries; lhf?Refactorize gives it a host factorization again. */
+LhfStatus lhfdSaveHierarchy(const LhfdHifHdl hif, const char *path);
+LhfStatus lhfzSaveHierarchy(const LhfzHifHdl hif, const char *path);
+LhfdHifHdl lhfdLoadHierarchy(const char *path);
+LhfzHifHdl lhfzLoadHierarchy(const char *path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIBHIFIR_AMD_EXT_H */

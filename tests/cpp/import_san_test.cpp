@@ -1,0 +1,229 @@
+// Sanitizer harness for the HOST half of hifamd_load / hifamd_add_level / hifamd_set_dense / hifamd_finalize
+// (hifir_amd/csrc/import.hpp + host.hpp -- the very code engine.hip compiles, minus the uploads).
+//
+// Why: round 1 saw an intermittent corruption of two entries of E's row pointer on the host (complex `young1c`,
+// handle created by hifamd_load while a first handle was alive), attributed to a second OpenMP runtime but never
+// shown.  The GPU pool has no sanitizers, so the host path is exercised here, on the CPU, the way that test did:
+//   * several handles alive at once, loaded from the same file, derived arrays compared bit for bit;
+//   * the dense factorization (complex QRCP 228^2 for young1c), the explicit operators and every block inverse
+//     with the thread pool active;
+//   * two loads running concurrently on two threads (distinct handles from distinct threads);
+//   * the adjoint hierarchy;
+//   * truncated and bit-flipped files: must be refused with HIFAMD_BAD_PREC / MISMATCHED_SIZES, never read out of bounds.
+// Build: g++ -std=c++17 -O1 -g -fsanitize=address,undefined  |  -fsanitize=thread ; -DHIFAMD_TEST_OPENMP -fopenmp
+// replaces the std::thread loop by the OpenMP loops the library had before commit b9dba02.
+// Usage: import_san_test file.hifamd [more files...]; exit code 0 = clean.
+#include "import.hpp"
+
+#include <thread>
+
+using namespace hifamd;
+
+template <class T>
+struct Sink {  // what Engine<T> does on import, without a device
+  HostHierarchy<T> host;
+  BandOptions opt;
+  bool analyze = true;
+  void add_level(int64_t m, int64_t n, const int64_t *Lcp, const int32_t *Lri, const T *Lv, const int64_t *Ucp,
+                 const int32_t *Uri, const T *Uv, const int64_t *Ecp, const int32_t *Eri, const T *Ev, int64_t F_ncols,
+                 const int64_t *Fcp, const int32_t *Fri, const T *Fv, const T *d, const double *s, const double *t,
+                 const int32_t *p, const int32_t *p_inv, const int32_t *q, const int32_t *q_inv) {
+    const int64_t parent_nm = host.levels.empty() ? -1 : host.levels.back().n - host.levels.back().m;
+    HostLevel<T> H = import_level<T>(parent_nm, m, n, Lcp, Lri, Lv, Ucp, Uri, Uv, Ecp, Eri, Ev, F_ncols, Fcp, Fri, Fv, d, s, t,
+                                     p, p_inv, q, q_inv);
+    if (analyze) analyze_level(H, opt);
+    host.levels.push_back(std::move(H));
+  }
+  void set_dense(int64_t nd, const T *mat, double cond) {
+    dense_factorize(host.dense, mat, nd, cond);
+    host.has_dense = true;
+  }
+  void set_dense_symm(int64_t nd, const T *mat, int spd) {
+    dense_factorize_symm(host.dense, mat, nd, spd);
+    host.has_dense = true;
+  }
+  void set_dense_lup(int64_t nd, const T *mat) {
+    dense_factorize_lup(host.dense, mat, nd);
+    host.has_dense = true;
+  }
+};
+
+static std::vector<unsigned char> slurp(const char *path) {
+  std::FILE *f = std::fopen(path, "rb");
+  if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+  std::vector<unsigned char> b;
+  unsigned char buf[1 << 16];
+  size_t k;
+  while ((k = std::fread(buf, 1, sizeof(buf), f)) > 0) b.insert(b.end(), buf, buf + k);
+  std::fclose(f);
+  return b;
+}
+
+template <class T>
+static void load_bytes(const std::vector<unsigned char> &bytes, Sink<T> &S) {
+  std::FILE *f = fmemopen((void *)bytes.data(), bytes.size(), "rb");
+  if (!f) throw std::runtime_error("fmemopen failed");
+  try {
+    if (std::fseek(f, 16, SEEK_SET) != 0) throw Error(kBadPrec, "truncated hierarchy file");
+    load_hierarchy<T>(f, S);
+  } catch (...) {
+    std::fclose(f);
+    throw;
+  }
+  std::fclose(f);
+}
+
+template <class V>
+static bool same(const std::vector<V> &a, const std::vector<V> &b) {
+  return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(V)) == 0);
+}
+template <class T>
+static bool same_csr(const Csr<T> &a, const Csr<T> &b) {
+  return same(a.ptr, b.ptr) && same(a.col, b.col) && same(a.val, b.val) && same(a.rowid, b.rowid);
+}
+static bool same_plan(const BandPlan &a, const BandPlan &b) {
+  return same(a.order, b.order) && same(a.grp_slot_ptr, b.grp_slot_ptr) && same(a.wg_grp_ptr, b.wg_grp_ptr) &&
+         same(a.band_wg_ptr, b.band_wg_ptr) && same(a.srcslot, b.srcslot) && same(a.split, b.split) &&
+         same(a.band_dense, b.band_dense) && same(a.band_fused, b.band_fused) && same(a.blk_slot0, b.blk_slot0);
+}
+template <class T>
+static int compare(const Sink<T> &A, const Sink<T> &B, const char *what) {
+  int bad = 0;
+  if (A.host.levels.size() != B.host.levels.size()) return 1;
+  for (size_t l = 0; l < A.host.levels.size(); ++l) {
+    const HostLevel<T> &x = A.host.levels[l], &y = B.host.levels[l];
+    if (!same_csr(x.Lr, y.Lr) || !same_csr(x.Ur, y.Ur) || !same_csr(x.Er, y.Er) || !same_csr(x.Fr, y.Fr)) ++bad;
+    if (!same_plan(x.Lp, y.Lp) || !same_plan(x.Up, y.Up)) ++bad;
+    if (!same(x.d, y.d) || !same(x.s, y.s) || !same(x.t, y.t) || !same(x.p, y.p) || !same(x.q_inv, y.q_inv)) ++bad;
+  }
+  if (A.host.has_dense != B.host.has_dense) ++bad;
+  if (A.host.has_dense)
+    if (A.host.dense.rank != B.host.dense.rank || !same(A.host.dense.jpvt0, B.host.dense.jpvt0) || !same(A.host.dense.qr, B.host.dense.qr) ||
+        !same(A.host.dense.QH, B.host.dense.QH) || !same(A.host.dense.Rinv, B.host.dense.Rinv))
+      ++bad;
+  if (bad) std::fprintf(stderr, "MISMATCH between two handles built from the same file (%s): %d arrays\n", what, bad);
+  return bad;
+}
+
+// the host part of hifamd_finalize: invariants, then every block inverse (thread pool active)
+template <class T>
+static int finalize_host(Sink<T> &S, bool adjoint = false) {
+  int bad = 0;
+  for (size_t l = 0; l < S.host.levels.size(); ++l) check_level_invariants(S.host.levels[l], l, adjoint);
+  std::vector<double> ops;
+  for (auto &H : S.host.levels)
+    for (int tri = 0; tri < 2; ++tri) {
+      BandPlan &P = tri ? H.Up : H.Lp;
+      const Csr<T> &A = tri ? H.Ur : H.Lr;
+      for (size_t q = 0; q < P.blk_slot0.size(); ++q) {
+        ops.assign((size_t)dense_block_elems(P.blk_slot1[q] - P.blk_slot0[q], sizeof(T) != sizeof(double)), 0.0);
+        if (!(build_dense_block(P, A, q, ops.data()) >= 1.0)) ++bad;
+      }
+    }
+  for (size_t l = 0; l < S.host.levels.size(); ++l) check_level_invariants(S.host.levels[l], l, adjoint);
+  return bad;
+}
+
+template <class T>
+static int run_file(const char *path, const std::vector<unsigned char> &bytes, int64_t dense_block) {
+  int bad = 0;
+  Sink<T> A, B, C;
+  A.opt.dense_block = B.opt.dense_block = C.opt.dense_block = dense_block;
+  A.opt.dense_min_rows = B.opt.dense_min_rows = C.opt.dense_min_rows = 8;  // small fixtures still get block-dense bands
+  A.opt.thin_rows = B.opt.thin_rows = C.opt.thin_rows = 12;
+  load_bytes(bytes, A);          // first handle, stays alive
+  bad += finalize_host(A);
+  load_bytes(bytes, B);          // second handle while the first one is alive (the round-1 scenario)
+  bad += finalize_host(B);
+  bad += compare(A, B, "sequential");
+  // two more loads concurrently on two threads
+  Sink<T> D;
+  D.opt = C.opt;
+  std::exception_ptr e1, e2;
+  std::thread t1([&] { try { load_bytes(bytes, C); finalize_host(C); } catch (...) { e1 = std::current_exception(); } });
+  std::thread t2([&] { try { load_bytes(bytes, D); finalize_host(D); } catch (...) { e2 = std::current_exception(); } });
+  t1.join();
+  t2.join();
+  if (e1) std::rethrow_exception(e1);
+  if (e2) std::rethrow_exception(e2);
+  bad += compare(A, C, "concurrent 1") + compare(A, D, "concurrent 2");
+  // adjoint hierarchy of the first handle
+  if (!A.host.levels[0].q.empty() && !A.host.levels[0].p_inv.empty()) {
+    Sink<T> J;
+    J.opt = A.opt;
+    for (const auto &P : A.host.levels) {
+      HostLevel<T> H = adjoint_level(P);
+      analyze_level(H, J.opt);
+      J.host.levels.push_back(std::move(H));
+    }
+    bad += finalize_host(J, true);
+    if (A.host.has_dense && A.host.dense.kind == 0) {
+      HostDense<T> Dn;
+      Dn.n = A.host.dense.n, Dn.rank = A.host.dense.rank, Dn.qr = A.host.dense.qr, Dn.tau = A.host.dense.tau;
+      Dn.jpvt0 = A.host.dense.jpvt0;
+      dense_adjoint_ops(Dn);
+    }
+  }
+  bad += compare(A, B, "after the adjoint build");
+  // save -> identical bytes
+  {
+    std::vector<unsigned char> out(bytes.size() + 64);
+    std::FILE *f = fmemopen(out.data(), out.size(), "wb");
+    save_hierarchy(f, A.host);
+    const long len = std::ftell(f);
+    std::fclose(f);
+    if (len != (long)bytes.size() - 16 || std::memcmp(out.data(), bytes.data() + 16, (size_t)len) != 0) {
+      std::fprintf(stderr, "%s: save_hierarchy does not reproduce the file\n", path);
+      ++bad;
+    }
+  }
+  // hostile files: truncation at ~200 points, and every 8-byte word of the first 4 KB + a sample of the rest
+  // overwritten with a few nasty values -- must throw Error (or load cleanly when the word is plain data)
+  int refused = 0, accepted = 0;
+  auto attempt = [&](const std::vector<unsigned char> &b) {
+    Sink<T> S;
+    S.analyze = false;
+    try {
+      load_bytes(b, S);
+      ++accepted;
+    } catch (const Error &e) {
+      if (e.code < 1 || e.code > 4) ++bad;
+      ++refused;
+    }
+  };
+  const size_t step = std::max<size_t>(8, bytes.size() / 200);
+  for (size_t cut = 16; cut < bytes.size(); cut += step) attempt(std::vector<unsigned char>(bytes.begin(), bytes.begin() + cut));
+  const int64_t nasty[] = {-1, 0, 1, (int64_t)1 << 33, (int64_t)1 << 62, 7};
+  std::vector<unsigned char> mut = bytes;
+  for (size_t off = 16; off + 8 <= bytes.size(); off += (off < 4096 ? 8 : std::max<size_t>(8, (bytes.size() / 300) & ~(size_t)7))) {
+    int64_t keep;
+    std::memcpy(&keep, &mut[off], 8);
+    for (int64_t v : nasty) {
+      std::memcpy(&mut[off], &v, 8);
+      attempt(mut);
+    }
+    std::memcpy(&mut[off], &keep, 8);
+  }
+  std::fprintf(stderr, "%s: levels=%zu dense=%d blocks(L0)=%zu  hostile files: %d refused, %d loaded  -> %s\n", path,
+               A.host.levels.size(), (int)A.host.has_dense, A.host.levels[0].Lp.blk_slot0.size(), refused, accepted,
+               bad ? "FAILED" : "ok");
+  return bad;
+}
+
+int main(int argc, char **argv) {
+  int bad = 0;
+  try {
+    for (int a = 1; a < argc; ++a) {
+      const std::vector<unsigned char> bytes = slurp(argv[a]);
+      if (bytes.size() < 16 || std::memcmp(bytes.data(), "HIFAMD1", 8) != 0) throw std::runtime_error("not a hierarchy file");
+      int64_t vt;
+      std::memcpy(&vt, &bytes[8], 8);
+      for (int64_t db : {(int64_t)64, (int64_t)0})
+        bad += vt == 1 ? run_file<zdouble>(argv[a], bytes, db) : run_file<double>(argv[a], bytes, db);
+    }
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "EXCEPTION: %s\n", e.what());
+    return 2;
+  }
+  return bad ? 1 : 0;
+}
