@@ -6,19 +6,28 @@ Laplacian with 64 right-hand sides.  One "step" = one batched apply X = M^{-1} B
 multilevel hierarchy (prec_solve, reference src/hif/alg/prec_solve.hpp:332-412) over one [n][64]
 block that is already resident in HBM; `value` counts RHS-applies per second over all ranks.
 
-  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 without WORLD_SIZE in the environment: this process starts the N ranks itself (python -m
+torch.distributed.run --nproc-per-node N ... bench.py, as a CHILD, before anything here touches torch or the GPU),
+relays rank 0's JSON line and exits with the child's code.  Launched by torch.distributed.run (the driver's way)
+it is one of the ranks; --gpus must then equal WORLD_SIZE.
 
 Multi-GPU: the path shards over right-hand sides only.  Every rank holds the whole
 hierarchy and applies it to its OWN 64-column block: weak scaling, no collective in the data path;
-one RCCL all_gather of the solution blocks after the timed region (reported as gather_ms).
+one RCCL all_gather of the solution blocks after the timed region (reported as gather_ms).  The STRONG
+split of one 64-column batch (64/N columns per GPU) is timed as well and reported as `strong_scaling`:
+it is flat by construction while the triangular stages are latency-bound.
 
 Hierarchy: factorization is not part of the measured path and stays on the host (north_star).
 When the compiled reference is present (oracle/_ref, the GPU box gets it as a prebuilt binary) the
 cpu_baseline leg factorizes the matrix with the REAL reference and times the reference's own
 single-RHS solve; the hierarchy it produced is then handed to the HIP path field by field through
 the import ABI -- exactly the deployment contract of INTEGRATION.md (reference factorizes, GPU
-applies), so GPU and CPU numbers refer to the same factors.  For N > 1 rank 0 factorizes and the
-other ranks read the factors from a node-local file (hifir_amd/dist.py).
+applies), so GPU and CPU numbers refer to the same factors.  For N > 1 rank 0 factorizes, writes the
+imported hierarchy in the library's on-disk format (hifamd_save) and the other ranks replay that file
+(hifamd_load; hifir_amd/dist.py share_hierarchy).  Without the compiled reference the same file format is
+the only way to get a workload: bench.py then looks for $TMPDIR/hifir_amd_hier_p2d_<nx>_<params>.hifamd.
 """
 import argparse
 import json
@@ -49,7 +58,37 @@ PARAM_SETS = {"default": None, "tuned": dict(tau=1e-2, kappa=5.0, alpha=3.0)}
 
 
 def hier_cache_path(nx, pname):
-    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"hifir_amd_hier_p2d_{nx}_{pname}.npz")
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"hifir_amd_hier_p2d_{nx}_{pname}.hifamd")
+
+
+def spawn_ranks(n):
+    """--gpus N without a launcher: start the N ranks as a child process group.  The parent imports neither torch
+    nor hifir_amd and makes no GPU call; it relays the child's output and exit code."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL across processes)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def lib_fingerprint():
+    """sha256 of the product library: profiles/ summaries are stamped with it (tests/prof_summarize.py) and only a
+    summary made with THIS build may contribute counter traffic / per-stage times to the line."""
+    import hashlib
+
+    p = os.path.join(ROOT, "hifir_amd", "libhifir_amd.so")
+    return hashlib.sha256(open(p, "rb").read()).hexdigest() if os.path.exists(p) else None
 
 
 def cpu_baseline_leg(A, pname, budget_s):
@@ -140,9 +179,14 @@ def main():
                                                       "rehearse the N > 1 flow on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with matching values "
+                         f"(python bench.py --gpus N starts its own ranks)")
     if world > 1 and "HIFIR_AMD_THREADS" not in os.environ:
         # every rank analyses the (replicated) hierarchy on the host (std::thread pool of the library): share the cores
         os.environ["HIFIR_AMD_THREADS"] = str(max(1, (os.cpu_count() or 8) // world))
@@ -171,27 +215,23 @@ def main():
     n = A.shape[0]
 
     def get_hierarchy(pname, want_cpu):
-        """rank 0 factorizes on the host (reference) and shares the factors through a file."""
+        """-> (M, levels or None, cpu): rank 0 factorizes on the host (compiled reference) and imports the factors;
+        the other ranks replay rank 0's hierarchy file (hifamd_save / hifamd_load)."""
         path = hier_cache_path(args.nx, pname)
-        cpu = None
-        levels = None
+        cpu, levels, M = None, None, None
         if rank == 0:
             cpu, levels = cpu_baseline_leg(A, pname, args.cpu_seconds if want_cpu else 0.0)
-            if levels is None:
-                if not os.path.exists(path):
-                    raise SystemExit("no compiled reference (oracle/_ref) and no cached hierarchy file: "
-                                     "cannot build the workload's factors on this machine")
-                levels = hd.load_levels(path)
-        levels = hd.share_levels(levels, path)
-        return levels, cpu
+            if levels is not None:
+                M = hifir_amd.HIF.from_levels(levels, max_nrhs=args.nrhs, device=local_rank)
+            elif os.path.exists(path):
+                M = hifir_amd.HIF.load(path, max_nrhs=args.nrhs, device=local_rank)
+            else:
+                raise SystemExit("no compiled reference (oracle/_ref) and no hierarchy file " + path +
+                                 ": cannot build the workload's factors on this machine")
+        M = hd.share_hierarchy(M, path, max_nrhs=args.nrhs, device=local_rank)
+        return M, levels, cpu
 
-    def run(pname, want_cpu, steps, warmup):
-        levels, cpu = get_hierarchy(pname, want_cpu)
-        M = hifir_amd.HIF.from_levels(levels, max_nrhs=args.nrhs, device=local_rank)
-        g = torch.Generator(device="cuda")
-        g.manual_seed(20260101 + rank)
-        B = (torch.rand((n, args.nrhs), dtype=torch.float64, device="cuda", generator=g) * 2 - 1)
-        X = torch.empty_like(B)
+    def timed(M, B, X, steps, warmup):
         for _ in range(warmup):
             M.solve_mrhs(B, X)
         M.sync()
@@ -204,7 +244,15 @@ def main():
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t0
-        el = hd.max_over_ranks(el, device="cuda" if args.backend == "nccl" else "cpu")
+        return hd.max_over_ranks(el, device="cuda" if args.backend == "nccl" else "cpu")
+
+    def run(pname, want_cpu, steps, warmup):
+        M, levels, cpu = get_hierarchy(pname, want_cpu)
+        g = torch.Generator(device="cuda")
+        g.manual_seed(20260101 + rank)
+        B = (torch.rand((n, args.nrhs), dtype=torch.float64, device="cuda", generator=g) * 2 - 1)
+        X = torch.empty_like(B)
+        el = timed(M, B, X, steps, warmup)
         # kernel-side duration of one apply: HIP events on the stream the kernels run on
         dev_ms = M.time_apply(B, X, warmup=1, reps=max(5, steps // 2))
         balg = M.algorithmic_bytes(args.nrhs)
@@ -224,14 +272,46 @@ def main():
             torch.cuda.synchronize()
             gather_ms = 1e3 * (time.perf_counter() - t1)
             del Xall
+        # STRONG split of ONE 64-column batch: rank r applies columns column_block(64, r, N) of the same block
+        strong = None
+        if world > 1:
+            c0, c1 = hd.column_block(args.nrhs, rank, world)
+            gs = torch.Generator(device="cuda")
+            gs.manual_seed(20260101)  # the same block on every rank
+            Bs = (torch.rand((n, args.nrhs), dtype=torch.float64, device="cuda", generator=gs) * 2 - 1)[:, c0:c1].contiguous()
+            Xs = torch.empty_like(Bs)
+            els = timed(M, Bs, Xs, steps, 1)
+            strong = {"nrhs_total": args.nrhs, "columns_per_gpu": c1 - c0, "ms_per_batch": 1e3 * els / steps,
+                      "rhs_applies_per_s": args.nrhs * steps / els,
+                      "note": "flat by construction: one apply costs the same for 1..64 columns while the triangular "
+                              "stages are latency-bound (nrhs1 at N=1)"}
+            del Bs, Xs
         # parity spot check of what was timed: column 0 against the oracle restatement (rank 0)
         parity = None
-        if rank == 0 and want_cpu:
+        xo = None
+        if rank == 0 and want_cpu and levels is not None:
             from oracle import orc
 
             xo = orc.Oracle(levels).solve(B[:, 0].cpu().numpy())
             xg = X[:, 0].cpu().numpy()
             parity = float(np.abs(xg - xo).max() / np.abs(xo).max())
+        # the EXACT engine mode (HIFIR_AMD_DENSE_BLOCK=0: reference summation order everywhere, thin runs on one
+        # workgroup) on the same hierarchy: its time next to the default (fast) mode's, and bit-exactness of column 0
+        exact = None
+        if rank == 0 and want_cpu and levels is not None:
+            os.environ["HIFIR_AMD_DENSE_BLOCK"] = "0"
+            try:
+                Me = hifir_amd.HIF.from_levels(levels, max_nrhs=args.nrhs, device=local_rank)
+            finally:
+                os.environ.pop("HIFIR_AMD_DENSE_BLOCK", None)
+            Xe = torch.empty_like(B)
+            ems = Me.time_apply(B, Xe, warmup=1, reps=max(3, steps // 4))
+            xe = Xe[:, 0].cpu().numpy()
+            exact = {"ms_per_apply": ems, "col0_bit_exact_vs_oracle": bool(np.array_equal(xe, xo)),
+                     "col0_relerr_vs_oracle": float(np.abs(xe - xo).max() / np.abs(xo).max()),
+                     "roofline_frac": balg / (ems * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            Me.close()
+            del Xe
         # a 128-column batch through the same handle: its two 64-column tiles run on two lanes (second work
         # arena + stream, shared matrices) and hide each other's latency-bound phases; reported next to the
         # metric, never as the metric
@@ -253,7 +333,7 @@ def main():
                          "first_tile_equals_64_column_result": bool(torch.equal(X2[:, :args.nrhs], X))}
             del B2, X2
         res = dict(ms_per_step=1e3 * el / steps, value=world * args.nrhs * steps / el, dev_ms=dev_ms, balg=balg, stage_bytes=stage_bytes, nrhs1_ms=nrhs1_ms, pipelined=pipelined,
-                   stats=st, cpu=cpu, gather_ms=gather_ms, parity=parity, levels=levels)
+                   stats=st, cpu=cpu, gather_ms=gather_ms, parity=parity, levels=levels, strong=strong, exact=exact)
         M.close()
         del B, X
         torch.cuda.empty_cache()
@@ -265,7 +345,7 @@ def main():
         st = r["stats"]
         achieved = r["balg"] / (r["dev_ms"] * 1e-3) / 1e9
         cpu = r["cpu"]
-        if want_cpu:
+        if want_cpu and r["levels"] is not None:
             port = port_baseline(r["levels"], n, min(args.cpu_seconds, 4.0))
             if cpu is None:
                 cpu = port
@@ -273,21 +353,26 @@ def main():
                 cpu["port_value"] = port["value"]
         # HBM traffic of one apply from the committed PMC profile of this same command (separate
         # rocprofv3 --pmc passes, corrected as MI355X_MICROARCH.md prescribes; tests/prof_summarize.py)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_note, stages = None, None, None, None
         if args.params == "default" and args.nx == 1000 and args.nrhs == 64:
             import glob
 
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
             if cands:
-                traffic = json.load(open(cands[-1])).get("hbm_bytes_per_apply_corrected")
-                traffic_src = os.path.relpath(cands[-1], ROOT)
-        # per-stage rooflines: algorithmic bytes of a stage group / its kernels' time in the committed
-        # rocprofv3 kernel trace of this same command (tests/prof_summarize.py)
-        stages = None
-        if traffic_src:
-            sp_ = os.path.join(ROOT, traffic_src.replace("_pmc_summary.json", "_stage_roofline.json"))
-            if os.path.exists(sp_):
-                stages = json.load(open(sp_))
+                summ = json.load(open(cands[-1]))
+                if summ.get("lib_sha256") and summ.get("lib_sha256") == lib_fingerprint():
+                    traffic = summ.get("hbm_bytes_per_apply_corrected")
+                    traffic_src = os.path.relpath(cands[-1], ROOT)
+                    # per-stage rooflines: algorithmic bytes of a stage group / its kernels' time in the committed
+                    # rocprofv3 kernel trace of this same command and build (tests/prof_summarize.py)
+                    sp_ = cands[-1].replace("_pmc_summary.json", "_stage_roofline.json")
+                    if os.path.exists(sp_):
+                        st_ = json.load(open(sp_))
+                        if st_.get("lib_sha256") == lib_fingerprint():
+                            stages = st_
+                else:
+                    traffic_note = (f"{os.path.relpath(cands[-1], ROOT)} was collected with another build of "
+                                    f"libhifir_amd.so (sha256 {str(summ.get('lib_sha256'))[:12]} vs {str(lib_fingerprint())[:12]}): dropped")
         line = {
             "metric": "preconditioner applies/sec + achieved HBM GB/s, 1M-row 5-pt Laplacian, nrhs=64",
             "value": r["value"], "unit": "RHS-applies/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -304,6 +389,7 @@ def main():
                        "parallelism": f"rhs-sharded x{world} (hierarchy replicated)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_note": traffic_note,
                          "kernel": "one whole batched apply (hipGraph of k_trsv_band_p/k_trsv_wide/k_thin_update/k_tri_gemm_d/k_spmm_epi/k_gather_scale/k_scatter_scale)",
                          "algorithmic_bytes": r["balg"], "apply_ms_hip_events": r["dev_ms"],
                          "algorithmic_bytes_by_stage": r["stage_bytes"], "stages_from_profile": stages},
@@ -312,6 +398,10 @@ def main():
         }
         if r["gather_ms"] is not None:
             line["gather_ms"] = r["gather_ms"]
+        if r["strong"] is not None:
+            line["strong_scaling"] = r["strong"]
+        if r["exact"] is not None:
+            line["exact_mode"] = r["exact"]
         if r["pipelined"] is not None:
             line["wide_batch"] = r["pipelined"]
         if r["nrhs1_ms"] is not None:
@@ -324,7 +414,7 @@ def main():
             line["secondary"] = {"params": other, "value": r2["value"], "ms_per_step": r2["ms_per_step"],
                                  "roofline_achieved_GBs": a2, "roofline_frac": a2 / HBM_PEAK_GBS,
                                  "algorithmic_bytes": r2["balg"], "cpu_baseline": r2["cpu"],
-                                 "parity_relerr_col0_vs_oracle": r2["parity"]}
+                                 "parity_relerr_col0_vs_oracle": r2["parity"], "exact_mode": r2["exact"]}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -27,6 +27,7 @@ SIGNATURES = {
     "hifamd_set_dense_lup": (_int, [_vp, _i64, _vp]),
     "hifamd_finalize": (_int, [_vp, _i64]),
     "hifamd_value_type": (_int, [_vp]),
+    "hifamd_device": (_int, [_vp]),
     "hifamd_nrows": (_i64, [_vp]),
     "hifamd_levels": (_i64, [_vp]),
     "hifamd_nnz": (_i64, [_vp]),

@@ -2157,6 +2157,10 @@ HifAmdStatus hifamd_finalize(HifAmdHdl h, int64_t max_nrhs) {
 
 
 int hifamd_value_type(HifAmdHdl h) { return (h && h->eng) ? h->vt : -1; }
+int hifamd_device(HifAmdHdl h) {
+  if (!h || !h->eng) return -1;
+  return h->vt == HIFAMD_D ? ENG_D->device : ENG_Z->device;
+}
 int64_t hifamd_nrows(HifAmdHdl h) { QUERY(q_nrows(ENG_D), q_nrows(ENG_Z)) }
 int64_t hifamd_levels(HifAmdHdl h) { QUERY(q_levels(ENG_D), q_levels(ENG_Z)) }
 int64_t hifamd_nnz(HifAmdHdl h) { QUERY(ENG_D->nnz_total(), ENG_Z->nnz_total()) }

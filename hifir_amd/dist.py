@@ -3,7 +3,8 @@ ROCm, "gloo" on CPU for the tests).  The apply path shards over right-hand-side 
 rank holds the whole hierarchy and applies it to its own column block; there is NO collective in
 the data path.  What is shared between ranks:
 
-  share_levels   rank 0's host-side factors -> every rank (through a file on the node + barrier)
+  share_hierarchy rank 0's imported hierarchy -> every rank, through the library's on-disk format (hifamd_save /
+                 hifamd_load) on the node + two barriers; share_levels: the same for the dict form (npz), tests
   max_over_ranks the bench's timing convention (MAX over ranks)
   gather_blocks  ONE all_gather of the per-rank solution blocks at the end of a batch
 """
@@ -11,11 +12,8 @@ import os
 
 import numpy as np
 
-LEVEL_KEYS = ["m", "n", "dense_n", "dense_rank", "d", "s", "t", "p", "p_inv", "q", "q_inv", "dense"] + [
-    f"{a}_{b}" for a in "LUEF" for b in ("colptr", "rowind", "vals")]
-
-
 def save_levels(path, levels):
+    """Every field of every level (the dict layout of tests/util.py / oracle.orc) into one npz."""
     d = {"nlevels": len(levels)}
     for l, lv in enumerate(levels):
         for k, v in lv.items():
@@ -26,14 +24,17 @@ def save_levels(path, levels):
 
 
 def load_levels(path):
+    """Inverse of save_levels.  No key filter: whatever a level carries (dense_symm, spd, dense_lup, ...) comes
+    back, so every rank builds the SAME last-level solver."""
     z = np.load(path)
     levels = []
     for l in range(int(z["nlevels"])):
         lv = {}
-        for k in LEVEL_KEYS:
-            if f"L{l}_{k}" in z.files:
-                v = z[f"L{l}_{k}"]
-                lv[k] = int(v) if v.ndim == 0 else v
+        pre = f"L{l}_"
+        for key in z.files:
+            if key.startswith(pre):
+                v = z[key]
+                lv[key[len(pre):]] = int(v) if (v.ndim == 0 and v.dtype.kind in "iub") else (float(v) if v.ndim == 0 else v)
         levels.append(lv)
     return levels
 
@@ -51,7 +52,7 @@ def barrier():
 
 
 def share_levels(levels, path):
-    """levels: the hierarchy on rank 0 (None elsewhere).  Returns it on every rank."""
+    """levels: the hierarchy on rank 0 (None elsewhere).  Returns it on every rank (npz hand-off; tests)."""
     d = _dist()
     if d is None or d.get_world_size() == 1:
         return levels
@@ -62,6 +63,27 @@ def share_levels(levels, path):
         levels = load_levels(path)
     d.barrier()
     return levels
+
+
+def share_hierarchy(M, path, max_nrhs=64, device=-1):
+    """The product hand-off: rank 0 holds the imported hierarchy `M` (hifir_amd.HIF; None elsewhere), writes it in
+    the library's own on-disk format (hifamd_save -- exactly the add_level / set_dense arguments, any last-level
+    kind) and every other rank replays the file (hifamd_load + finalize on ITS device).  No collective carries
+    matrix data: the file lives on the node, ranks only meet at two barriers."""
+    from .hif import HIF
+
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return M
+    if d.get_rank() == 0:
+        tmp = path + f".tmp{os.getpid()}"
+        M.save(tmp)
+        os.replace(tmp, path)
+    d.barrier()
+    if d.get_rank() != 0:
+        M = HIF.load(path, max_nrhs=max_nrhs, device=device)
+    d.barrier()
+    return M
 
 
 def max_over_ranks(seconds, device="cpu"):

@@ -48,6 +48,12 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+def _np_dtype_of(t):
+    import torch
+
+    return {torch.float64: np.dtype(np.float64), torch.complex128: np.dtype(np.complex128)}.get(t.dtype)
+
+
 class HIF:
     """A multilevel preconditioner resident on one MI355X."""
 
@@ -224,6 +230,34 @@ class HIF:
         _check(lib().hifamd_level_schedule(self._h, level, which, None, _p(order), None))
         return order, wf
 
+    # ---- argument checks of the device-pointer entry points ------------------------------------------
+    def _dev_block(self, T, what, shape=None):
+        """A CUDA tensor handed to a *_dev entry point must be what the kernels assume: on the handle's device, of
+        the handle's value type, [nrows][nrhs] with unit column stride.  Anything else would be an out-of-bounds
+        device access (a GPU memory fault aborts the process), so it is refused here with MISMATCHED_SIZES."""
+        if not _is_torch(T) or not T.is_cuda:
+            raise HifAmdError(2, f"{what}: expected a CUDA tensor")
+        dev = lib().hifamd_device(self._h)
+        if dev >= 0 and T.device.index != dev:
+            raise HifAmdError(2, f"{what}: tensor lives on cuda:{T.device.index}, the hierarchy on cuda:{dev}")
+        if _np_dtype_of(T) != self.dtype:
+            raise HifAmdError(2, f"{what}: dtype {T.dtype} does not match the hierarchy's {self.dtype}")
+        if T.dim() != 2 or T.shape[0] != self.nrows() or T.shape[1] < 1:
+            raise HifAmdError(2, f"{what}: expected an [nrows][nrhs] block, got {tuple(T.shape)}")
+        if T.stride(1) != 1 or T.stride(0) < T.shape[1]:
+            raise HifAmdError(2, f"{what}: blocks must be row-interleaved (unit column stride)")
+        if shape is not None and tuple(T.shape) != tuple(shape):
+            raise HifAmdError(2, f"{what}: shape {tuple(T.shape)} differs from the input's {tuple(shape)}")
+        return T
+
+    def _host_out(self, X, like, what="x"):
+        """A caller-supplied host output is written through its pointer: it must be exactly that buffer."""
+        if X is None:
+            return np.empty_like(like)
+        if not isinstance(X, np.ndarray) or X.dtype != self.dtype or X.shape != like.shape or not X.flags.c_contiguous:
+            raise HifAmdError(2, f"{what}: output must be a C-contiguous {self.dtype} array of shape {like.shape}")
+        return X
+
     # ---- apply -----------------------------------------------------------------------------------
     def solve(self, b, x=None, trans=False, rank=0):
         """x = M^{-1} b, or x = M^{-H} b with trans=True (HIF::solve, builder.hpp:409-423)."""
@@ -232,8 +266,7 @@ class HIF:
         b = np.ascontiguousarray(b, dtype=self.dtype)
         if b.ndim != 1 or b.shape[0] != self.nrows():
             raise HifAmdError(2, "unmatched sizes")
-        if x is None:
-            x = np.empty_like(b)
+        x = self._host_out(x, b)
         if trans:
             _check(lib().hifamd_apply_batch(self._h, OP_SH, _p(b), 1, _p(x), 1, 1, 1, None, int(rank), None))
         else:
@@ -247,20 +280,17 @@ class HIF:
         if _is_torch(B):
             import torch
 
+            self._dev_block(B, "B")
             if X is None:
                 X = torch.empty_like(B)
-            if B.dim() != 2 or B.shape[0] != self.nrows() or X.shape != B.shape:
-                raise HifAmdError(2, "unmatched sizes")
-            if B.stride(1) != 1 or X.stride(1) != 1:
-                raise HifAmdError(2, "blocks must be row-interleaved (unit column stride)")
+            self._dev_block(X, "X", B.shape)
             _check(lib().hifamd_apply_batch_dev(self._h, op, B.data_ptr(), B.stride(0), X.data_ptr(), X.stride(0),
                                                B.shape[1], int(rank), stream))
             return X
         B = np.ascontiguousarray(B, dtype=self.dtype)
         if B.ndim != 2 or B.shape[0] != self.nrows():
             raise HifAmdError(2, "unmatched sizes")
-        if X is None:
-            X = np.empty_like(B)
+        X = self._host_out(X, B, "X")
         if trans:
             _check(lib().hifamd_apply_batch(self._h, op, _p(B), B.shape[1], _p(X), X.shape[1], B.shape[1], 1, None,
                                            int(rank), None))
@@ -281,7 +311,7 @@ class HIF:
         if _is_torch(x):
             import torch
 
-            X = x.reshape(x.shape[0], -1)
+            X = self._dev_block(x.reshape(x.shape[0], -1), "x")
             Y = torch.empty_like(X)
             _check(lib().hifamd_apply_batch_dev(self._h, op, X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0),
                                                X.shape[1], int(rank), None))
@@ -296,10 +326,10 @@ class HIF:
         """Y = A X on the device (torch CUDA tensors, [n][nrhs] or [n])."""
         import torch
 
-        X2 = X.reshape(X.shape[0], -1)
+        X2 = self._dev_block(X.reshape(X.shape[0], -1), "X")
         if Y is None:
             Y = torch.empty_like(X)
-        Y2 = Y.reshape(Y.shape[0], -1)
+        Y2 = self._dev_block(Y.reshape(Y.shape[0], -1), "Y", X2.shape)
         _check(lib().hifamd_spmv_batch_dev(self._h, X2.data_ptr(), X2.stride(0), Y2.data_ptr(), Y2.stride(0),
                                           X2.shape[1], stream))
         return Y
@@ -328,7 +358,7 @@ class HIF:
         if _is_torch(b):
             import torch
 
-            B = b.reshape(b.shape[0], -1)
+            B = self._dev_block(b.reshape(b.shape[0], -1), "b")
             X = torch.empty_like(B)
             st = np.zeros(2 * B.shape[1], dtype=np.int32)
             _check(lib().hifamd_hifir_batch_dev(self._h, B.data_ptr(), B.stride(0), X.data_ptr(), X.stride(0),
@@ -354,7 +384,7 @@ class HIF:
         if _is_torch(b):
             import torch
 
-            B = b.reshape(b.shape[0], -1)
+            B = self._dev_block(b.reshape(b.shape[0], -1), "b")
             X = torch.empty_like(B)
             fl = np.zeros(B.shape[1], dtype=np.int32)
             it = np.zeros(B.shape[1], dtype=np.int32)
@@ -386,6 +416,8 @@ class HIF:
 
     def time_apply(self, B, X, rank=0, warmup=2, reps=10):
         """Average device milliseconds of one batched apply, HIP events on the handle's stream."""
+        self._dev_block(B, "B")
+        self._dev_block(X, "X", B.shape)
         ms = C.c_double()
         _check(lib().hifamd_time_apply(self._h, B.data_ptr(), B.stride(0), X.data_ptr(), X.stride(0), B.shape[1],
                                       int(rank), int(warmup), int(reps), C.byref(ms)))

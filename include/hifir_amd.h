@@ -117,6 +117,7 @@ HifAmdStatus hifamd_load(const char *path, int device, HifAmdHdl *out);
 
 /* ---- queries (cf. lhf?GetLevels/GetNnz/GetSchurSize/GetSchurRank, libhifir.h:722-740) ------ */
 int hifamd_value_type(HifAmdHdl h);     /* HIFAMD_D / HIFAMD_Z of the handle (what hifamd_load found in the file); -1 for NULL */
+int hifamd_device(HifAmdHdl h);         /* HIP ordinal the handle is bound to (after hifamd_finalize; before: as created, -1 = current) */
 int64_t hifamd_nrows(HifAmdHdl h);
 int64_t hifamd_levels(HifAmdHdl h);     /* counts the dense block as a level (builder.hpp:141-147) */
 int64_t hifamd_nnz(HifAmdHdl h);        /* Prec::nnz summed (Prec.hpp:170-176) */

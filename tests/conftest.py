@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: wall-clock expectations on a GPU box (run with -m perf; not part of -m gpu)")
     config.addinivalue_line("markers", "ref: needs oracle/_ref/libhifref.so (the compiled reference)")
 
 

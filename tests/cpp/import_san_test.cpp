@@ -34,16 +34,17 @@ struct Sink {  // what Engine<T> does on import, without a device
     if (analyze) analyze_level(H, opt);
     host.levels.push_back(std::move(H));
   }
+  // (hostile-file runs -- analyze == false -- only care that the block arrives with the right size)
   void set_dense(int64_t nd, const T *mat, double cond) {
-    dense_factorize(host.dense, mat, nd, cond);
+    if (analyze) dense_factorize(host.dense, mat, nd, cond);
     host.has_dense = true;
   }
   void set_dense_symm(int64_t nd, const T *mat, int spd) {
-    dense_factorize_symm(host.dense, mat, nd, spd);
+    if (analyze) dense_factorize_symm(host.dense, mat, nd, spd);
     host.has_dense = true;
   }
   void set_dense_lup(int64_t nd, const T *mat) {
-    dense_factorize_lup(host.dense, mat, nd);
+    if (analyze) dense_factorize_lup(host.dense, mat, nd);
     host.has_dense = true;
   }
 };

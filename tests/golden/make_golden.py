@@ -142,7 +142,16 @@ def save_hier(name, A, params=None, cplx=False, lup=False):
 
 
 def main():
-    make_kats()
+    only = set(sys.argv[1:])  # names given on the command line: regenerate just those fixtures
+    if only:
+        global save_hier
+        _save = save_hier
+
+        def save_hier(name, *a, **k):  # noqa: F811
+            if name in only:
+                _save(name, *a, **k)
+    else:
+        make_kats()
     tuned = ref.make_params(tau=1e-2, kappa=5.0, alpha=3.0)
     save_hier("p2d_5", poisson2d(5))
     save_hier("p2d_30", poisson2d(30))
@@ -161,6 +170,12 @@ def main():
     save_hier("demo_A", A)  # libhifir/tests/test_real.c:88-146 input
     Z = scipy.io.mmread(os.path.join(REF, "examples", "demo_inputs", "young1c.mtx")).tocsr()
     save_hier("young1c", Z, cplx=True)  # libhifir/tests/test_complex.c:90-140 input
+    # BASELINE config 5's generator (tests/util.py stokes_kkt: complex Stokes-like KKT, omega = 0.1, eps = 1e-8) at
+    # 2,028 rows, default parameters: indefinite, deferred pressure rows, dense QRCP last level
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import stokes_kkt
+
+    save_hier("kkt_26", stokes_kkt(26), cplx=True)
 
 
 if __name__ == "__main__":

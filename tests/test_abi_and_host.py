@@ -3,6 +3,7 @@ calls), and the host-side analysis (import checks, level schedules) is right.  N
 import ctypes
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -181,3 +182,110 @@ def test_host_band_plan_program(tmp_path):
                            os.path.join(root, "tests", "cpp", "plan_test.cpp"), "-o", exe])
     out = subprocess.check_output([exe]).decode()
     assert out.strip().endswith("OK"), out
+
+
+def _save_fixture(name, path):
+    """hifamd_add_level + hifamd_set_dense* + hifamd_save need no GPU."""
+    levels, d = load_hier(name)
+    M = hifir_amd.HIF(dtype=np.complex128 if np.iscomplexobj(levels[0]["d"]) else np.float64)
+    for lv in levels:
+        M.add_level(lv)
+    last = levels[-1]
+    if int(last.get("dense_n", 0)) > 0:
+        if int(last.get("dense_lup", 0)):
+            M.set_dense_lup(last["dense"])
+        elif int(last.get("dense_symm", 0)):
+            M.set_dense_symm(last["dense"], int(last.get("spd", 0)))
+        else:
+            M.set_dense(last["dense"])
+    M.save(path)
+    return M
+
+
+def test_load_refuses_truncated_and_inconsistent_files(tmp_path):
+    """hifamd_load validates every array length against the level header and the column pointers BEFORE anything is
+    handed to add_level (a short rowind / p_inv used to be over-read).  The same inputs run under
+    AddressSanitizer in test_import_path_under_sanitizers."""
+    path = str(tmp_path / "h.hifamd")
+    _save_fixture("p2d_30", path)
+    raw = open(path, "rb").read()
+    L = hifir_amd.lib()
+    h = ctypes.c_void_p()
+
+    def try_load(data):
+        p = str(tmp_path / "bad.hifamd")
+        open(p, "wb").write(data)
+        st = L.hifamd_load(p.encode(), -1, ctypes.byref(h))
+        if st == 0:
+            L.hifamd_destroy(h)
+        else:
+            assert L.hifamd_last_error()
+        return st
+
+    assert try_load(raw) == 0
+    for cut in (17, 40, 100, len(raw) // 3, len(raw) // 2, len(raw) - 8, len(raw) - 1):
+        assert try_load(raw[:cut]) == 3, cut  # HIFAMD_BAD_PREC
+    # the int64 words right behind the header: #levels, has_dense, m, n, F_ncols, then L's shape and colptr count
+    words = np.frombuffer(raw[16:16 + 8 * 8], dtype=np.int64)
+    assert words[0] == 1 and words[2] < words[3]
+    for k in range(8):
+        for v in (-1, 1 << 40, int(words[k]) + 1):
+            if k == 1 and v == 2:
+                continue  # (has_dense 1 -> 2 is another VALID file: the same block factorized as a symmetric one)
+            bad = bytearray(raw)
+            bad[16 + 8 * k:24 + 8 * k] = int(v).to_bytes(8, "little", signed=True)
+            assert try_load(bytes(bad)) in (2, 3), (k, v)
+    # a permutation entry out of range / repeated (p_inv and q are gather indices on the device, too)
+    levels, _ = load_hier("p2d_30")
+    for key in ("p", "q_inv", "p_inv", "q"):
+        for mut in (lambda a: a.__setitem__(3, len(a) + 2), lambda a: a.__setitem__(3, a[4])):
+            lv = dict(levels[0])
+            lv[key] = lv[key].copy()
+            mut(lv[key])
+            with pytest.raises(hifir_amd.HifAmdError) as e:
+                hifir_amd.HIF().add_level(lv)
+            assert e.value.code == 2
+
+
+def test_tensor_arguments_are_validated():
+    """The device-pointer entry points get raw pointers: a CPU / wrong-dtype / wrongly shaped tensor must be refused
+    in the wrapper (HifAmdError), never turned into a device access."""
+    torch = pytest.importorskip("torch")
+    levels, d = load_hier("p2d_5")
+    M = hifir_amd.HIF()
+    M.add_level(levels[0])
+    M.set_dense(levels[0]["dense"])
+    n = len(d["b"])
+    for bad in (torch.zeros(n, 2, dtype=torch.float64),):  # CPU tensor
+        for call in (lambda t: M.solve_mrhs(t), lambda t: M.mmultiply(t), lambda t: M.spmv(t), lambda t: M.hifir(t, 2),
+                     lambda t: M.gmres(t), lambda t: M.time_apply(t, t)):
+            with pytest.raises(hifir_amd.HifAmdError) as e:
+                call(bad)
+            assert e.value.code == 2
+    with pytest.raises(hifir_amd.HifAmdError):
+        M.solve(d["b"], x=np.zeros(n, dtype=np.float32))  # wrong dtype of a caller-supplied output
+    with pytest.raises(hifir_amd.HifAmdError):
+        M.solve_mrhs(np.zeros((n, 2)), X=np.zeros((n, 3)))
+    with pytest.raises(hifir_amd.HifAmdError):
+        M.solve_mrhs(np.zeros((n, 2)), X=np.zeros((2, n)).T)  # not C-contiguous
+
+
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_import_path_under_sanitizers(tmp_path, san):
+    """The host half of hifamd_load / add_level / set_dense / finalize (import.hpp + host.hpp, the code engine.hip
+    compiles) under ASan+UBSan and under TSan: several handles alive, two loads on two threads, the complex QRCP
+    228^2 of young1c with the thread pool active, every block inverse, the adjoint hierarchy, ~1,500 hostile files
+    (tests/cpp/import_san_test.cpp).  Round 1's intermittent corruption of E's row pointer happened on this path."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "import_san_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-pthread", f"-fsanitize={san}", "-fno-sanitize-recover=undefined",
+                           "-I", os.path.join(root, "hifir_amd", "csrc"),
+                           os.path.join(root, "tests", "cpp", "import_san_test.cpp"), "-o", exe])
+    files = []
+    for name in (["young1c", "p2d_5"] if san == "thread" else ["young1c", "p2d_32_symm", "p2d_30_lup", "p2d_5"]):
+        files.append(str(tmp_path / f"{name}.hifamd"))
+        _save_fixture(name, files[-1])
+    env = dict(os.environ, HIFIR_AMD_THREADS="4", ASAN_OPTIONS="detect_leaks=1", TSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert r.stderr.count("-> ok") == 2 * len(files)

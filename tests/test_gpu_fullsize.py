@@ -14,7 +14,7 @@ import scipy.sparse as sp
 
 import hifir_amd
 from oracle import orc, ref
-from util import poisson2d, relerr
+from util import poisson2d, relerr, stokes_kkt
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref.available(), reason="compiled reference not present")]
 
@@ -52,6 +52,42 @@ def test_1m_columns_vs_oracle_and_reference(big):
     assert np.array_equal(M.solve(B[:, 7].copy()), X[:, 7])
     X3 = M.solve_mrhs(np.ascontiguousarray(B[:, :3]))
     assert np.array_equal(X3, X[:, :3])
+
+
+@pytest.fixture(scope="module", params=["fast", "exact"])
+def big_default(request):
+    """THE headline workload (BASELINE configs[1,2], what bench.py times): 1M-row Poisson factorized with
+    DEFAULT_PARAMS -- 6 levels, 582^2 dense QRCP level, ~2,900 wavefronts per triangle set."""
+    import os
+
+    os.environ["HIFIR_AMD_DENSE_BLOCK"] = "0" if request.param == "exact" else "2048"
+    A = poisson2d(1000)
+    R = ref.RefHIF(A.indptr, A.indices, A.data)
+    levels = R.levels()
+    M = hifir_amd.HIF.from_levels(levels, max_nrhs=64)
+    os.environ.pop("HIFIR_AMD_DENSE_BLOCK", None)
+    M.exact = request.param == "exact"
+    return A, R, levels, M, orc.Oracle(levels)
+
+
+def test_1m_default_hierarchy_columns(big_default):
+    A, R, levels, M, O = big_default
+    assert len(levels) >= 5 and int(levels[-1]["dense_n"]) > 0  # multilevel + dense last level
+    n = A.shape[0]
+    rng = np.random.default_rng(12)
+    B = rng.uniform(-1, 1, size=(n, 64))
+    X = M.solve_mrhs(B)
+    for k in (0, 31, 63):
+        assert relerr(X[:, k], O.solve(B[:, k].copy())) <= 1e-12  # (the dense level rules out bit-exactness)
+    assert relerr(X[:, 17], R.solve(B[:, 17].copy())) <= 1e-12     # the compiled reference itself
+    # column separability: nrhs = 1 (BASELINE configs[1]) and nrhs = 3 give the bits of the 64-column batch
+    assert np.array_equal(M.solve(B[:, 7].copy()), X[:, 7])
+    assert np.array_equal(M.solve_mrhs(np.ascontiguousarray(B[:, :3])), X[:, :3])
+    # conjugate-transpose apply and the product round trip on the same hierarchy
+    XT = M.solve_mrhs(np.ascontiguousarray(B[:, :4]), trans=True)
+    assert relerr(XT[:, 1], R.solve(B[:, 1].copy(), trans=True)) <= 1e-12
+    Y = M.mmultiply(np.ascontiguousarray(X[:, :4]))
+    assert (np.linalg.norm(Y - B[:, :4], axis=0) / np.linalg.norm(B[:, :4], axis=0)).max() <= 1e-10
 
 
 def test_1m_transposed_apply(big):
@@ -218,6 +254,33 @@ def test_1m_complex_stand_in_for_config5():
     assert relerr(X[:, 15], R.solve(B[:, 15].copy())) <= 1e-12
     XH = M.solve_mrhs(B, trans=True)
     assert relerr(XH[:, 7], R.solve(B[:, 7].copy(), trans=True)) <= 1e-12
+    Y = M.mmultiply(X)
+    assert (np.linalg.norm(Y - B, axis=0) / np.linalg.norm(B, axis=0)).max() <= 1e-10
+
+
+def test_2m_complex_saddle_point_config5():
+    """BASELINE config 5: complex fp64 saddle point, ~2M rows (1,997,568), nrhs = 16 -- SURVEY 8(d) C5's generator
+    (tests/util.py stokes_kkt: [[K + i w M, B^T], [B, -eps I]], w = 0.1, eps = 1e-8), factorized on the box by the
+    compiled reference with the PDE-tuned parameters (default parameters: ~10 min of host factorization at this
+    size; the 2,028-row fixture kkt_26 covers them), applied on the device: columns vs the oracle and the reference,
+    forward and conjugate-transpose, plus the product round trip."""
+    A = stokes_kkt(816)
+    n = A.shape[0]
+    assert n == 1997568
+    R = ref.RefHIF(A.indptr, A.indices, A.data, ref.make_params(tau=1e-2, kappa=5.0, alpha=3.0))
+    levels = R.levels()
+    assert len(levels) >= 2 and int(levels[-1]["dense_n"]) > 0
+    M = hifir_amd.HIF.from_levels(levels, max_nrhs=16)
+    O = orc.Oracle(levels)
+    rng = np.random.default_rng(13)
+    B = rng.uniform(-1, 1, size=(n, 16)) + 1j * rng.uniform(-1, 1, size=(n, 16))
+    X = M.solve_mrhs(B)
+    assert relerr(X[:, 0], O.solve(B[:, 0].copy())) <= 1e-12
+    assert relerr(X[:, 15], R.solve(B[:, 15].copy())) <= 1e-12
+    XH = M.solve_mrhs(B, trans=True)
+    assert relerr(XH[:, 7], O.solve(B[:, 7].copy(), trans=True)) <= 1e-12
+    assert relerr(XH[:, 3], R.solve(B[:, 3].copy(), trans=True)) <= 1e-12
+    assert relerr(XH[:, 3], X[:, 3]) > 1e-6  # complex symmetric, not Hermitian: conjugation matters
     Y = M.mmultiply(X)
     assert (np.linalg.norm(Y - B, axis=0) / np.linalg.norm(B, axis=0)).max() <= 1e-10
 

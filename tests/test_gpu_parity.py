@@ -200,8 +200,6 @@ def test_rotating_buffers_share_one_graph(cache):
     # a Krylov solver hands over a different (B, X) pair every call: the captured graph is keyed by shape
     # and reads the pointers from a device slot, so nothing is re-captured and every pair gets its own result
     torch = pytest.importorskip("torch")
-    import time
-
     levels, d, M, O = _get(cache, "p2d_64_deep")
     n = len(d["b"])
     rng = np.random.default_rng(41)
@@ -210,17 +208,12 @@ def test_rotating_buffers_share_one_graph(cache):
     M.solve_mrhs(Bs[0], Xs[0])
     M.sync()
 
-    def wall(pairs):
-        t0 = time.perf_counter()
-        for b, x in pairs:
-            M.solve_mrhs(b, x)  # enqueued back to back, no synchronisation in between
-        M.sync()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / len(pairs)
-
-    same = min(wall([(Bs[0], Xs[0])] * len(Bs)) for _ in range(3))  # min of 3: shrug off unrelated hiccups
-    rot = min(wall(list(zip(Bs, Xs))) for _ in range(3))
-    assert rot <= 1.5 * same + 1e-3, (rot, same)  # a re-capture per call would cost tens of milliseconds
+    for b, x in zip(Bs, Xs):
+        M.solve_mrhs(b, x)  # enqueued back to back, no synchronisation in between
+    M.sync()
+    torch.cuda.synchronize()
+    assert M.stats()["launches"] > 0
+    # (the wall-clock side of this -- rotating pairs cost what a fixed pair costs -- is tests/test_gpu_perf.py, -m perf)
     for k in (0, 5, 11):
         Xo = O.solve_batch(Bs[k].cpu().numpy(), threads=4)
         assert relerr(Xs[k].cpu().numpy(), Xo) <= TOL
