@@ -239,9 +239,10 @@ void check_level_invariants(const HostLevel<T> &H, size_t level_no, bool adjoint
     throw Error(kHifirError, std::string("internal error: level ") + std::to_string(level_no) + ": " + why +
                                  " (host copy of the hierarchy is corrupt)");
   };
-  if (H.Lr.nrows != m || H.Ur.nrows != m || H.Er.nrows != nm || H.Fr.nrows != m) fail("matrix shapes");
+  if (H.Lr.nrows != m || H.Ur.nrows != m || H.Er.nrows != nm) fail("matrix shapes");
   if (H.Lr.ncols != m || H.Ur.ncols != m || (nm && H.Er.ncols != m)) fail("matrix shapes");
-  if (H.F_ncols && H.Fr.ncols != nm) fail("matrix shapes");
+  // (a level without a Schur complement has no E / F at all: their stored shapes are then whatever the import left)
+  if (H.F_ncols && (H.Fr.nrows != m || H.Fr.ncols != nm)) fail("matrix shapes");
   // (the adjoint level keeps no CCS copies: its row forms ARE the CCS arrays of the primary level)
   check_csr(H.Lr, adjoint ? (int64_t)H.Lr.col.size() : H.L.nnz(), "L", level_no);
   check_csr(H.Ur, adjoint ? (int64_t)H.Ur.col.size() : H.U.nnz(), "U", level_no);

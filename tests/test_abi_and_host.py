@@ -282,7 +282,7 @@ def test_import_path_under_sanitizers(tmp_path, san):
                            "-I", os.path.join(root, "hifir_amd", "csrc"),
                            os.path.join(root, "tests", "cpp", "import_san_test.cpp"), "-o", exe])
     files = []
-    for name in (["young1c", "p2d_5"] if san == "thread" else ["young1c", "p2d_32_symm", "p2d_30_lup", "p2d_5"]):
+    for name in (["young1c", "p2d_5"] if san == "thread" else ["young1c", "p2d_32_symm", "p2d_30_lup", "p2d_5", "p2d_100_tuned"]):
         files.append(str(tmp_path / f"{name}.hifamd"))
         _save_fixture(name, files[-1])
     env = dict(os.environ, HIFIR_AMD_THREADS="4", ASAN_OPTIONS="detect_leaks=1", TSAN_OPTIONS="halt_on_error=1")
