@@ -236,40 +236,19 @@ def test_constant_null_space_filter_matches_reference():
     assert np.array_equal(M.solve(b), plain)
 
 
-def test_1m_complex_stand_in_for_config5():
-    # BASELINE config 5 stand-in at full size: complex fp64, 1M rows, nrhs = 16 (the SuiteSparse saddle point
-    # cannot be fetched offline): complex shifted 2-D Laplacian, columns vs the oracle and the real reference,
-    # forward and conjugate-transpose
-    A = (poisson2d(1000) - (0.3 + 0.2j) * sp.identity(1000 * 1000)).tocsr()
-    A.sort_indices()
-    R = ref.RefHIF(A.indptr, A.indices, A.data)
-    levels = R.levels()
-    M = hifir_amd.HIF.from_levels(levels, max_nrhs=16)
-    O = orc.Oracle(levels)
-    rng = np.random.default_rng(10)
-    n = A.shape[0]
-    B = rng.uniform(-1, 1, size=(n, 16)) + 1j * rng.uniform(-1, 1, size=(n, 16))
-    X = M.solve_mrhs(B)
-    assert relerr(X[:, 0], O.solve(B[:, 0].copy())) <= 1e-12
-    assert relerr(X[:, 15], R.solve(B[:, 15].copy())) <= 1e-12
-    XH = M.solve_mrhs(B, trans=True)
-    assert relerr(XH[:, 7], R.solve(B[:, 7].copy(), trans=True)) <= 1e-12
-    Y = M.mmultiply(X)
-    assert (np.linalg.norm(Y - B, axis=0) / np.linalg.norm(B, axis=0)).max() <= 1e-10
-
-
 def test_2m_complex_saddle_point_config5():
     """BASELINE config 5: complex fp64 saddle point, ~2M rows (1,997,568), nrhs = 16 -- SURVEY 8(d) C5's generator
     (tests/util.py stokes_kkt: [[K + i w M, B^T], [B, -eps I]], w = 0.1, eps = 1e-8), factorized on the box by the
-    compiled reference with the PDE-tuned parameters (default parameters: ~10 min of host factorization at this
-    size; the 2,028-row fixture kkt_26 covers them), applied on the device: columns vs the oracle and the reference,
-    forward and conjugate-transpose, plus the product round trip."""
+    compiled reference with tau = 1e-2, alpha = 3 and the default kappa = 3 (4 levels + a 1,364^2 dense QRCP last
+    level, nnz(M) = 74 M; DEFAULT_PARAMS take ~10 min of host factorization at this size -- the 2,028-row fixture
+    kkt_26 covers them), applied on the device: columns vs the oracle and the reference, forward and
+    conjugate-transpose, plus the product round trip."""
     A = stokes_kkt(816)
     n = A.shape[0]
     assert n == 1997568
-    R = ref.RefHIF(A.indptr, A.indices, A.data, ref.make_params(tau=1e-2, kappa=5.0, alpha=3.0))
+    R = ref.RefHIF(A.indptr, A.indices, A.data, ref.make_params(tau=1e-2, kappa=3.0, alpha=3.0))
     levels = R.levels()
-    assert len(levels) >= 2 and int(levels[-1]["dense_n"]) > 0
+    assert len(levels) >= 2 and int(levels[-1]["dense_n"]) > 0  # dense QRCP last level (on the f64 matrix cores)
     M = hifir_amd.HIF.from_levels(levels, max_nrhs=16)
     O = orc.Oracle(levels)
     rng = np.random.default_rng(13)
