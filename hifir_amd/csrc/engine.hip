@@ -13,6 +13,7 @@
 #include <map>
 #include <memory>
 #include <tuple>
+#include <type_traits>
 
 #include "../../include/hifir_amd.h"
 #include "host.hpp"
@@ -141,8 +142,9 @@ struct DevCsr {
   // band plan of a triangle (host.hpp BandPlan); empty for E, F, A
   DevBuf srcslot, split, wg_grp_ptr, grp_slot_ptr;
   DevBuf wg_slot;  // first slot of every workgroup (+ end): grp_slot_ptr[wg_grp_ptr[g]], one load level less at kernel start
+  DevBuf csplit, grp_inv_off;  // component-dense bands (host.hpp plan_bands_cd)
   std::vector<int32_t> band_wg_ptr, band_slot_ptr;
-  std::vector<uint8_t> band_prefix, band_dense, band_fused;
+  std::vector<uint8_t> band_prefix, band_dense, band_fused, band_cd, band_old;
   std::vector<int32_t> band_blk_ptr, blk_slot0, blk_slot1;
   std::vector<int64_t> blk_inv_off;
   DevBuf tinv;  // explicit inverses of the diagonal blocks of block-dense thin bands
@@ -160,6 +162,10 @@ struct DevCsr {
     wg_grp_ptr.alias(o.wg_grp_ptr);
     grp_slot_ptr.alias(o.grp_slot_ptr);
     wg_slot.alias(o.wg_slot);
+    csplit.alias(o.csplit);
+    grp_inv_off.alias(o.grp_inv_off);
+    band_cd = o.band_cd;
+    band_old = o.band_old;
     tinv.alias(o.tinv);
     band_wg_ptr = o.band_wg_ptr;
     band_slot_ptr = o.band_slot_ptr;
@@ -190,6 +196,10 @@ struct DevCsr {
         for (size_t g = 0; g < ws.size(); ++g) ws[g] = P->grp_slot_ptr[(size_t)P->wg_grp_ptr[g]];
         wg_slot.upload(ws);
       }
+      csplit.upload(P->csplit);
+      grp_inv_off.upload(P->grp_inv_off);
+      band_cd = P->band_cd;
+      band_old = P->band_old;
       band_wg_ptr = P->band_wg_ptr;
       band_prefix = P->band_prefix;
       band_fused = P->band_fused;
@@ -321,6 +331,9 @@ class Engine : public EngineBase {
     band_opt.fuse = env_int("HIFIR_AMD_BAND_FUSE", sizeof(T) == sizeof(double) ? 1 : 0) != 0;
     band_opt.fuse_reorder = band_opt.dense_block > 0;                  // exact mode keeps the reference's order
     band_opt.fuse_max_wgs = env_int("HIFIR_AMD_BAND_FUSE_WGS", 512);
+    // component-dense bands (host.hpp plan_bands_cd): real data, fast mode; HIFIR_AMD_CD_ROWS=0 keeps the depth-cut bands
+    band_opt.cd_rows = (sizeof(T) == sizeof(double) && band_opt.dense_block > 0) ? env_int("HIFIR_AMD_CD_ROWS", 192) : 0;
+    if (band_opt.cd_rows > 256) band_opt.cd_rows = 256;  // 128 KB of the CU's 160 KB LDS
   }
 
   void bind_device() {
@@ -331,6 +344,11 @@ class Engine : public EngineBase {
     if (device >= cnt) throw Error(HIFAMD_HIFIR_ERROR, "device ordinal out of range");
     HIP_OK(hipSetDevice(device));
     if (!stream) HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (sizeof(T) == sizeof(double) && band_opt.cd_rows > 0) {  // k_band_cd keeps a component in up to 128 KB of LDS
+      const int lds = (int)(band_opt.cd_rows * 64 * sizeof(double));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
   }
 
   ~Engine() override {
@@ -554,38 +572,62 @@ class Engine : public EngineBase {
     host.has_dense = true;
   }
 
-  // Block inverses of a triangle's block-dense thin bands: built one block at a time into two pinned staging
-  // buffers (reused, so the host never holds more than two blocks) and streamed to HBM while the next block
-  // is being inverted.  A band whose inverse grows beyond dense_max_growth reverts to the sequential scheme.
+  // Block inverses of a triangle -- the 2,048-row blocks of its dense chains and the components of its
+  // component-dense bands: built into two pinned staging buffers (reused, so the host never holds more than two
+  // buffers full) and streamed to HBM while the next batch is being inverted.  Consecutive small blocks share a
+  // batch (built in parallel, one thread per block, ONE copy); a big block is a batch of its own (parallel inside).
+  // A band whose inverses grow beyond dense_max_growth reverts to the sequential (flag) scheme.
   void ship_block_inverses(BandPlan &P, const Csr<T> &A, int64_t total_elems, DevCsr &M) {
     M.upload(A, &P);
     if (!total_elems) return;
     M.tinv.alloc((size_t)total_elems * sizeof(double));
     const bool cplx = sizeof(T) != sizeof(double);
-    const size_t cap = (size_t)dense_block_elems(band_opt.dense_block, cplx) * sizeof(double);
-    if (!pin[0]) {
-      HIP_OK(hipHostMalloc((void **)&pin[0], cap, hipHostMallocDefault));
-      HIP_OK(hipHostMalloc((void **)&pin[1], cap, hipHostMallocDefault));
-      HIP_OK(hipEventCreateWithFlags(&pin_done[0], hipEventDisableTiming));
-      HIP_OK(hipEventCreateWithFlags(&pin_done[1], hipEventDisableTiming));
+    auto elems_of = [&](size_t q) { return dense_block_elems(P.blk_slot1[q] - P.blk_slot0[q], cplx); };
+    int64_t biggest = dense_block_elems(std::max<int64_t>(band_opt.dense_block, 32), cplx);
+    for (size_t q = 0; q < P.blk_slot0.size(); ++q) biggest = std::max(biggest, elems_of(q));
+    const size_t cap = (size_t)biggest * sizeof(double);
+    if (!pin[0] || pin_cap < cap) {
+      for (int k = 0; k < 2; ++k) {
+        if (pin[k]) (void)hipHostFree(pin[k]);
+        HIP_OK(hipHostMalloc((void **)&pin[k], cap, hipHostMallocDefault));
+        if (!pin_done[k]) HIP_OK(hipEventCreateWithFlags(&pin_done[k], hipEventDisableTiming));
+      }
+      pin_cap = cap;
     }
     std::vector<uint8_t> bad(P.blk_slot0.size(), 0);
-    for (size_t q = 0; q < P.blk_slot0.size(); ++q) {
+    const size_t nblk = P.blk_slot0.size();
+    for (size_t q0 = 0; q0 < nblk;) {
+      size_t q1 = q0 + 1;
+      int64_t batch = elems_of(q0);
+      while (q1 < nblk && batch + elems_of(q1) <= biggest && P.blk_inv_off[q1] == P.blk_inv_off[q0] + batch) batch += elems_of(q1++);
       const int which = (int)(pin_next++ & 1);
       HIP_OK(hipEventSynchronize(pin_done[which]));  // the copy that last used this buffer has finished
-      const int64_t nb = P.blk_slot1[q] - P.blk_slot0[q];
-      const double growth = build_dense_block(P, A, q, pin[which]);
-      if (!(growth <= band_opt.dense_max_growth)) bad[q] = 1;
-      HIP_OK(hipMemcpyAsync(M.tinv.as<double>() + P.blk_inv_off[q], pin[which],
-                            (size_t)dense_block_elems(nb, cplx) * sizeof(double), hipMemcpyHostToDevice, stream));
+      double *buf = pin[which];
+      if (q1 - q0 == 1) {
+        if (!(build_dense_block(P, A, q0, buf) <= band_opt.dense_max_growth)) bad[q0] = 1;
+      } else {
+        parallel_for((int64_t)(q1 - q0), 1, [&](int64_t i0, int64_t i1) {
+          for (int64_t i = i0; i < i1; ++i) {
+            const size_t q = q0 + (size_t)i;
+            if (!(build_dense_block(P, A, q, buf + (P.blk_inv_off[q] - P.blk_inv_off[q0]), true) <= band_opt.dense_max_growth)) bad[q] = 1;
+          }
+        });
+      }
+      HIP_OK(hipMemcpyAsync(M.tinv.as<double>() + P.blk_inv_off[q0], buf, (size_t)batch * sizeof(double), hipMemcpyHostToDevice,
+                            stream));
       HIP_OK(hipEventRecord(pin_done[which], stream));
+      q0 = q1;
     }
     bool any_bad = false;
     for (int64_t b = 0; b < P.nbands(); ++b)
       for (int32_t q = P.band_blk_ptr[(size_t)b]; q < P.band_blk_ptr[(size_t)b + 1]; ++q)
-        if (bad[(size_t)q]) P.band_dense[(size_t)b] = 0, any_bad = true;
-    if (any_bad) M.band_dense = P.band_dense;  // (launch_trsv walks the band table of the device copy)
+        if (bad[(size_t)q]) P.band_dense[(size_t)b] = 0, P.band_cd[(size_t)b] = 0, any_bad = true;
+    if (any_bad) {  // (launch_trsv walks the band table of the device copy)
+      M.band_dense = P.band_dense;
+      M.band_cd = P.band_cd;
+    }
   }
+  size_t pin_cap = 0;
   double *pin[2] = {nullptr, nullptr};
   hipEvent_t pin_done[2] = {nullptr, nullptr};
   uint64_t pin_next = 0;
@@ -694,6 +736,7 @@ class Engine : public EngineBase {
       pin[k] = nullptr;
       pin_done[k] = nullptr;
     }
+    pin_cap = 0;
     finalized = true;
   }
 
@@ -788,7 +831,7 @@ class Engine : public EngineBase {
       const int32_t qb0 = M.band_dense[b] ? M.band_blk_ptr[b] : -1;
       const bool direct = pre && M.band_dense[b] && logR == 6 && qb0 < M.band_blk_ptr[b + 1] &&
                           M.blk_slot0[(size_t)qb0] == M.band_slot_ptr[b];
-      if (pre && !(fused && have_carried)) {
+      if (pre && !(fused && have_carried)) {  // (a fused band whose predecessor could not carry it: its own launch)
         const int64_t s0 = M.band_slot_ptr[b], s1 = M.band_slot_ptr[b + 1];
         hipLaunchKernelGGL((k_trsv_wide<D, LOWER, true>), dim3(grid_for(s1 - s0, logR)), dim3(256), 0, st, s0, s1,
                            M.ptr.as<int32_t>(), M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(),
@@ -801,7 +844,8 @@ class Engine : public EngineBase {
           launch_dense_block<LOWER>(st, L, M, q, logR, count, direct && q == qb0);
         continue;
       }
-      if (logR == 6 && band_pipe) {  // the overlapped pipeline (trsv_band_r64); HIFIR_AMD_BAND_PIPE=0: the first version
+      const bool cdb = !M.band_cd.empty() && M.band_cd[b] && logR == 6;
+      if ((logR == 6 && band_pipe) || cdb) {  // the overlapped pipeline (trsv_band_r64); HIFIR_AMD_BAND_PIPE=0: the first version
         // extra workgroups for the carried prefix of the NEXT band (they run on the units this band leaves idle)
         int32_t ps0 = 0, ps1 = 0;
         unsigned extra = 0;
@@ -810,6 +854,11 @@ class Engine : public EngineBase {
           ps1 = M.band_slot_ptr[b + 2];
           extra = (unsigned)std::min<int64_t>(256, std::max<int64_t>(1, ((int64_t)ps1 - ps0 + 15) / 16));
           carried = true;
+        }
+        if (cdb) {
+          launch_band_cd<LOWER>(st, L, M, g0, g1, pre, ps0, ps1, extra);
+          ++count;
+          continue;
         }
         hipLaunchKernelGGL((k_trsv_band_p<D, LOWER>), dim3((unsigned)(g1 - g0) + extra), dim3(1024), 0, st, g0,
                            M.wg_slot.as<int32_t>(), M.ptr.as<int32_t>(),
@@ -839,6 +888,22 @@ class Engine : public EngineBase {
   template <bool LOWER>
   void launch_dense_block(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t q, int logR, int64_t &count,
                           bool rhs_ready = false);
+  // one component-dense band (kernels.hip.hpp k_band_cd): real data, R = 64
+  template <bool LOWER>
+  void launch_band_cd(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t g0, int32_t g1, int pre, int32_t ps0,
+                      int32_t ps1, unsigned extra) {
+    if constexpr (std::is_same<T, double>::value) {
+      const size_t lds = (size_t)band_opt.cd_rows * 64 * sizeof(double);  // (the attribute for > 64 KB is set in bind_device)
+      hipLaunchKernelGGL((k_band_cd<LOWER>), dim3((unsigned)(g1 - g0) + extra), dim3(1024), lds, st, g0,
+                         M.wg_grp_ptr.as<int32_t>(), M.grp_slot_ptr.as<int32_t>(), M.grp_inv_off.as<int64_t>(),
+                         M.ptr.as<int32_t>(), M.split.as<int32_t>(), M.csplit.as<int32_t>(), M.col.as<int32_t>(),
+                         M.val.as<double>(), M.rowid.as<int32_t>(), L.d.as<double>(), L.w.as<double>(), L.v.as<double>(),
+                         M.tinv.as<double>(), pre, pre ? 0 : 1, (int32_t)(g1 - g0), ps0, ps1);
+    } else {
+      (void)st, (void)L, (void)M, (void)g0, (void)g1, (void)pre, (void)ps0, (void)ps1, (void)extra;
+      throw Error(HIFAMD_HIFIR_ERROR, "internal error: component-dense band on a complex handle");
+    }
+  }
 
   void launch_ldu(hipStream_t st, DevLevel &L, int logR, int64_t &count) {
     if (!L.m) return;

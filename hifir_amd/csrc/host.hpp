@@ -16,6 +16,7 @@
 #include <thread>
 #include <mutex>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <stdexcept>
 #include <string>
@@ -262,6 +263,12 @@ struct BandPlan {
   std::vector<int64_t> blk_inv_off;   // block -> offset of its (rows x rows, column-major) inverse
   std::vector<int32_t> srcslot;       // per nonzero (slot order): slot of the source row
   std::vector<int32_t> split;         // per slot: where the band kernel starts in the row
+  // Component-dense bands (plan_bands_cd): every group of such a band is one dependency component (<= cd_rows rows,
+  // LDS-resident), solved as  x_c = Tinv_c (rhs_c - old-source sums)  with the explicit inverse of its own triangle:
+  std::vector<uint8_t> band_cd;       // band b is a component-dense band
+  std::vector<uint8_t> band_old;      // band b has nonzeros that refer to earlier bands (else no prefix work exists)
+  std::vector<int32_t> csplit;        // per slot: first nonzero whose source lies in the row's own component
+  std::vector<int64_t> grp_inv_off;   // per group: offset of the component's inverse (cd bands; -1 elsewhere)
   int64_t nbands() const { return (int64_t)band_wg_ptr.size() - 1; }
   int64_t nwg() const { return (int64_t)wg_grp_ptr.size() - 1; }
 };
@@ -278,6 +285,8 @@ struct BandOptions {
   bool fuse_reorder = true;    // ... with the rows' nonzeros reordered so that the prefix covers ALL old sources (fast mode)
   int64_t fuse_max_wgs = 512;  // band b-1 must leave compute units idle (96 / 192 / 256 / 512 / 1024: 9.23 / 8.87 / 8.86 / 8.81 / 9.28 ms)
   int64_t dense_min_rows = 96;   // thin bands shorter than this stay on the sequential workgroup
+  int64_t cd_rows = 192;         // component-dense bands: rows per component (LDS-resident; 0 = scheme off)
+  double cd_min_row_nnz = 4.0;   // ... only for triangles with at least this many nonzeros per row on average
   double dense_max_growth = 1e4; // ... and so do bands whose block inverses grow beyond this
 };
 
@@ -475,6 +484,234 @@ BandPlan plan_bands(const Csr<T> &A, const Schedule &S, bool lower, const BandOp
   return P;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Component-dense plan.  The depth-cut bands above stop growing as soon as ONE component gets heavy, so the upper
+// part of a triangle -- where the elimination forest has merged into a few hundred subtrees -- costs dozens of
+// short launches, and its top (few rows per wavefront, hundreds of wavefronts) a chain of 2,048-row blocks.
+// Here the triangle is cut along its SUBTREES instead: rows are visited in dependency order and joined to the
+// components of the rows they need (union-find) as long as a component stays within cd_rows rows; a row whose
+// component would grow beyond that is deferred to the next pass, and with it everything that needs it.  One pass =
+// one band = one launch; its components are independent of each other, each is served by ONE workgroup that keeps
+// the component's right-hand sides in LDS and applies the explicit inverse of the component's own (small) triangle
+// on the matrix cores -- no dependent step, no polling inside a launch, any depth.  Measured on the reference's
+// 1M-row hierarchies: 6-7 passes per triangle instead of 20-40 depth bands, and what is left over for the chain
+// of 2,048-row blocks shrinks from ~9,000 rows to a few hundred.
+// An upper triangle fans OUT from the root of the forest: it is planned on its reversed dependency graph (row j
+// "needs" every row i that reads it -- the CCS columns), which is an in-forest again, and the passes then run in
+// reverse order: a row's sources lie in the same component or in a pass that ran earlier.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+BandPlan plan_bands_cd(const Csr<T> &A, const Schedule &S, bool lower, const BandOptions &opt) {
+  BandPlan P;
+  const int64_t m = A.nrows;
+  std::vector<int32_t> depth((size_t)m);
+  for (int64_t w = 0; w < S.nwf(); ++w)
+    for (int64_t s = S.wf_ptr[(size_t)w]; s < S.wf_ptr[(size_t)w + 1]; ++s) depth[(size_t)S.order[(size_t)s]] = (int32_t)w;
+  // "needs" lists of the planning graph: the rows themselves (lower), or the transposed pattern (upper)
+  std::vector<int32_t> tptr, tcol;
+  const int32_t *nptr = A.ptr.data(), *ncol = A.col.data();
+  if (!lower) {
+    tptr.assign((size_t)m + 1, 0);
+    for (size_t k = 0; k < A.col.size(); ++k) ++tptr[(size_t)A.col[k] + 1];
+    for (int64_t i = 0; i < m; ++i) tptr[(size_t)i + 1] += tptr[(size_t)i];
+    tcol.resize(A.col.size());
+    std::vector<int32_t> fill(tptr.begin(), tptr.end() - 1);
+    for (int64_t i = 0; i < m; ++i)
+      for (int32_t k = A.ptr[(size_t)i]; k < A.ptr[(size_t)i + 1]; ++k) tcol[(size_t)fill[(size_t)A.col[(size_t)k]]++] = (int32_t)i;
+    nptr = tptr.data(), ncol = tcol.data();
+  }
+  // visiting order: any topological order of the planning graph.  lower: the level schedule; upper (reversed
+  // graph, needs point to SMALLER rows): ascending row number
+  std::vector<int32_t> remaining((size_t)m), next;
+  if (lower)
+    remaining = S.order;
+  else
+    for (int64_t i = 0; i < m; ++i) remaining[(size_t)i] = (int32_t)i;
+  std::vector<int32_t> pass((size_t)m, -1), parent((size_t)m), crows((size_t)m);
+  std::vector<uint8_t> deferred((size_t)m, 0);
+  auto find = [&](int32_t x) {
+    while (parent[(size_t)x] != x) {
+      parent[(size_t)x] = parent[(size_t)parent[(size_t)x]];
+      x = parent[(size_t)x];
+    }
+    return x;
+  };
+  const int64_t rest_rows = opt.dense_block > 0 ? opt.dense_block : 0;  // what one block of the dense chain takes
+  std::vector<std::vector<int32_t>> pass_rows;                           // rows of every pass, visiting order
+  std::vector<int32_t> roots;
+  int32_t np = 0;
+  while (!remaining.empty() && (int64_t)remaining.size() > rest_rows) {
+    next.clear();
+    std::vector<int32_t> mine;
+    for (int32_t i : remaining) {
+      parent[(size_t)i] = i;
+      crows[(size_t)i] = 1;
+      bool dfr = false;
+      roots.clear();
+      int64_t r = 1;
+      for (int32_t k = nptr[i]; k < nptr[i + 1] && !dfr; ++k) {
+        const int32_t j = ncol[k];
+        if (pass[(size_t)j] >= 0 && pass[(size_t)j] < np) continue;  // finished in an earlier pass
+        if (deferred[(size_t)j]) {
+          dfr = true;
+          break;
+        }
+        const int32_t rt = find(j);
+        if (std::find(roots.begin(), roots.end(), rt) == roots.end()) {
+          roots.push_back(rt);
+          r += crows[(size_t)rt];
+        }
+      }
+      if (dfr || r > opt.cd_rows) {
+        deferred[(size_t)i] = 1;
+        next.push_back(i);
+        continue;
+      }
+      for (int32_t rt : roots) parent[(size_t)rt] = i;
+      crows[(size_t)i] = (int32_t)r;
+      pass[(size_t)i] = np;
+      mine.push_back(i);
+    }
+    for (int32_t i : next) deferred[(size_t)i] = 0;
+    if (mine.empty()) throw Error(4, "internal error: component-dense planner made no progress");
+    // a pass that filled fewer than four components means the rest is (nearly) one chain: a launch per <= cd_rows rows
+    // would lose against the dense block chain's launch pair per dense_block rows
+    const bool degenerate = (int64_t)mine.size() < 4 * opt.cd_rows;
+    pass_rows.push_back(std::move(mine));
+    ++np;
+    remaining.swap(next);
+    if (degenerate && opt.dense_block > 0) break;
+  }
+  if (!remaining.empty() && opt.dense_block <= 0) {  // no dense chain available (cannot happen: cd needs dense_block > 0)
+    throw Error(4, "internal error: component-dense plan without the dense block chain");
+  }
+  // ---- emit bands in EXECUTION order: lower: pass 0, 1, ..., rest;  upper: rest, pass np-1, ..., 0
+  P.grp_slot_ptr.push_back(0);
+  P.wg_grp_ptr.push_back(0);
+  P.band_wg_ptr.push_back(0);
+  std::vector<int32_t> comp_id((size_t)m, -1);
+  auto emit_rest = [&]() {
+    if (remaining.empty()) return;
+    // slot ranges in dependency (depth) order, cut into blocks of dense_block rows by plan_dense_blocks; one band
+    // per max_wg_rows rows (a band whose inverses grow too much falls back to ONE flag workgroup)
+    std::vector<int32_t> rows(remaining);
+    std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) {
+      return depth[(size_t)a] != depth[(size_t)b] ? depth[(size_t)a] < depth[(size_t)b] : (lower ? a < b : a > b);
+    });
+    for (size_t at = 0; at < rows.size(); at += (size_t)opt.max_wg_rows) {
+      const size_t end = std::min(rows.size(), at + (size_t)opt.max_wg_rows);
+      int32_t cur = -1;
+      for (size_t q = at; q < end; ++q) {
+        const int32_t i = rows[q];
+        if (depth[(size_t)i] != cur) {
+          if (cur != -1) P.grp_slot_ptr.push_back((int32_t)P.order.size());
+          cur = depth[(size_t)i];
+        }
+        P.order.push_back(i);
+      }
+      P.grp_slot_ptr.push_back((int32_t)P.order.size());
+      P.wg_grp_ptr.push_back((int32_t)P.grp_slot_ptr.size() - 1);
+      P.band_wg_ptr.push_back((int32_t)P.wg_grp_ptr.size() - 1);
+      P.band_prefix.push_back(1);
+      P.band_dense.push_back(1);
+      P.band_cd.push_back(0);
+    }
+  };
+  auto emit_pass = [&](int32_t p) {
+    const std::vector<int32_t> &rows = pass_rows[(size_t)p];
+    // components of the pass: union-find roots were the LAST row joined; recompute ids by a second sweep
+    for (int32_t i : rows) parent[(size_t)i] = i;
+    for (int32_t i : rows)
+      for (int32_t k = nptr[i]; k < nptr[i + 1]; ++k) {
+        const int32_t j = ncol[k];
+        if (pass[(size_t)j] != p) continue;
+        const int32_t a = find(i), b = find(j);
+        if (a != b) parent[(size_t)a] = b;
+      }
+    std::vector<std::vector<int32_t>> crow;
+    for (int32_t i : rows) {
+      const int32_t rt = find(i);
+      if (comp_id[(size_t)rt] < 0) {
+        comp_id[(size_t)rt] = (int32_t)crow.size();
+        crow.emplace_back();
+      }
+      crow[(size_t)comp_id[(size_t)rt]].push_back(i);
+    }
+    for (int32_t i : rows) comp_id[(size_t)find(i)] = -1;  // (reset for the next pass)
+    // tiny components (a few rows: leaves, rows without in-pass sources) are packed together: a union of independent
+    // components is a valid block (block-diagonal inverse), and one 32-row block costs less than 32 one-row blocks
+    {
+      std::vector<std::vector<int32_t>> packed;
+      std::vector<int32_t> bag;
+      for (auto &r : crow) {
+        if ((int64_t)r.size() > 8) {
+          packed.push_back(std::move(r));
+          continue;
+        }
+        if (bag.size() + r.size() > 32) {
+          packed.push_back(std::move(bag));
+          bag.clear();
+        }
+        bag.insert(bag.end(), r.begin(), r.end());
+      }
+      if (!bag.empty()) packed.push_back(std::move(bag));
+      crow.swap(packed);
+    }
+    const int64_t nc = (int64_t)crow.size();
+    std::vector<int64_t> cw((size_t)nc, 0);
+    for (int64_t c = 0; c < nc; ++c)
+      for (int32_t i : crow[(size_t)c]) cw[(size_t)c] += (A.ptr[(size_t)i + 1] - A.ptr[(size_t)i]) + 2 + (int64_t)crow[(size_t)c].size() / 2;
+    // heaviest components first: the hardware hands workgroups out in order, so the long ones start first
+    std::vector<int64_t> idx((size_t)nc);
+    for (int64_t c = 0; c < nc; ++c) idx[(size_t)c] = c;
+    std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return cw[(size_t)a] > cw[(size_t)b]; });
+    // workgroups: one component each up to max_wgs; beyond that the lightest are chained onto shared workgroups
+    const int64_t nw = std::min<int64_t>(nc, std::max<int64_t>(1, opt.max_wgs));
+    std::vector<std::vector<int64_t>> wgc((size_t)nw);
+    {
+      std::vector<std::pair<int64_t, int64_t>> heap;
+      for (int64_t g = 0; g < nw; ++g) heap.push_back({0, g});
+      auto cmp = [](const std::pair<int64_t, int64_t> &x, const std::pair<int64_t, int64_t> &y) { return x > y; };
+      std::make_heap(heap.begin(), heap.end(), cmp);
+      for (int64_t q = 0; q < nc; ++q) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        auto top = heap.back();
+        heap.pop_back();
+        wgc[(size_t)top.second].push_back(idx[(size_t)q]);
+        top.first += cw[(size_t)idx[(size_t)q]];
+        heap.push_back(top);
+        std::push_heap(heap.begin(), heap.end(), cmp);
+      }
+    }
+    for (int64_t g = 0; g < nw; ++g) {
+      for (int64_t c : wgc[(size_t)g]) {
+        std::vector<int32_t> &r = crow[(size_t)c];
+        // inside a component: the triangle's own dependency order (its inverse is then lower triangular)
+        std::stable_sort(r.begin(), r.end(), [&](int32_t a, int32_t b) {
+          return depth[(size_t)a] != depth[(size_t)b] ? depth[(size_t)a] < depth[(size_t)b] : (lower ? a < b : a > b);
+        });
+        for (int32_t i : r) P.order.push_back(i);
+        P.grp_slot_ptr.push_back((int32_t)P.order.size());
+      }
+      P.wg_grp_ptr.push_back((int32_t)P.grp_slot_ptr.size() - 1);
+    }
+    P.band_wg_ptr.push_back((int32_t)P.wg_grp_ptr.size() - 1);
+    P.band_prefix.push_back(0);
+    P.band_dense.push_back(0);
+    P.band_cd.push_back(1);
+  };
+  P.order.reserve((size_t)m);
+  if (lower) {
+    for (int32_t p = 0; p < np; ++p) emit_pass(p);
+    emit_rest();
+  } else {
+    emit_rest();
+    for (int32_t p = np - 1; p >= 0; --p) emit_pass(p);
+  }
+  if ((int64_t)P.order.size() != m) throw Error(4, "internal error: component-dense plan lost rows");
+  return P;
+}
+
 // After the CSR has been permuted into the band plan's slot order: source slots and split points.
 // Block-dense thin bands.  A thin band is a short, deep, single-component triangular system: hundreds
 // of dependent steps of a few rows each, i.e. pure latency (~2 us per step through LDS flags).  Cut
@@ -503,8 +740,19 @@ int64_t plan_dense_blocks(BandPlan &P, const BandOptions &opt) {
   P.blk_slot1.clear();
   P.blk_inv_off.clear();
   int64_t total = 0;
+  P.grp_inv_off.assign(P.grp_slot_ptr.size() - 1, -1);
   for (int64_t b = 0; b < P.nbands(); ++b) {
-    if (P.band_dense[(size_t)b]) {
+    if (!P.band_cd.empty() && P.band_cd[(size_t)b]) {  // component-dense band: one inverse per component (group)
+      for (int32_t g = P.band_wg_ptr[(size_t)b]; g < P.band_wg_ptr[(size_t)b + 1]; ++g)
+        for (int32_t c = P.wg_grp_ptr[(size_t)g]; c < P.wg_grp_ptr[(size_t)g + 1]; ++c) {
+          const int32_t r0 = P.grp_slot_ptr[(size_t)c], r1 = P.grp_slot_ptr[(size_t)c + 1];
+          P.blk_slot0.push_back(r0);
+          P.blk_slot1.push_back(r1);
+          P.blk_inv_off.push_back(total);
+          P.grp_inv_off[(size_t)c] = total;
+          total += nplanes * plane_elems(r1 - r0, round_up32(r1 - r0));
+        }
+    } else if (P.band_dense[(size_t)b]) {
       const int32_t g = P.band_wg_ptr[(size_t)b];
       const int32_t s0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]], s1 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]];
       for (int32_t r0 = s0; r0 < s1; r0 += (int32_t)opt.dense_block) {
@@ -526,7 +774,7 @@ inline int64_t dense_block_elems(int64_t nb, bool cplx) { return (cplx ? 2 : 1) 
 // triangle written straight into operand layout.  Returns the largest |entry| (the caller compares it with
 // dense_max_growth and lets an unstable band fall back to the sequential workgroup).
 template <class T>
-double build_dense_block(const BandPlan &P, const Csr<T> &A, size_t q, double *ops) {
+double build_dense_block(const BandPlan &P, const Csr<T> &A, size_t q, double *ops, bool serial = false) {
   const int32_t r0 = P.blk_slot0[q], nb = P.blk_slot1[q] - r0;
   const int64_t ldk = round_up32(nb), plane = plane_elems(nb, ldk);
   std::memset(ops, 0, sizeof(double) * (size_t)dense_block_elems(nb, sizeof(T) != sizeof(double)));
@@ -551,7 +799,7 @@ double build_dense_block(const BandPlan &P, const Csr<T> &A, size_t q, double *o
   // no per-column test is needed beyond q >= c0.
   constexpr int32_t CB = 16;
   std::mutex gmx;
-  parallel_for((nb + CB - 1) / CB, 1, [&](int64_t cb0, int64_t cb1) {
+  auto body = [&](int64_t cb0, int64_t cb1) {
     std::vector<T> Yc((size_t)nb * CB);
     double g = 1.0;
     for (int64_t cb = cb0; cb < cb1; ++cb) {
@@ -580,7 +828,11 @@ double build_dense_block(const BandPlan &P, const Csr<T> &A, size_t q, double *o
     }
     std::lock_guard<std::mutex> lk(gmx);
     growth = std::max(growth, g);
-  });
+  };
+  if (serial)  // (the caller runs many small blocks in parallel)
+    body(0, (nb + CB - 1) / CB);
+  else
+    parallel_for((nb + CB - 1) / CB, 1, body);
   return growth;
 }
 
@@ -602,65 +854,97 @@ void finish_band_plan(BandPlan &P, Csr<T> &A /* rows in slot order */, const Ban
   // reference's order and carries only the leading run of old sources.
   const int64_t nb_ = P.nbands();
   P.band_fused.assign((size_t)nb_, 0);
+  P.band_old.assign((size_t)nb_, 0);
+  if (P.band_cd.size() != (size_t)nb_) P.band_cd.assign((size_t)nb_, 0);
+  P.csplit.assign((size_t)m, 0);
   auto band_first_slot = [&](int64_t b) { return P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b]]]; };
   if (opt.fuse)
     for (int64_t b = 1; b < nb_; ++b) {
       const int64_t wgs_prev = P.band_wg_ptr[(size_t)b] - P.band_wg_ptr[(size_t)b - 1];
-      if (!P.band_dense[(size_t)b] && !P.band_prefix[(size_t)b] && !P.band_dense[(size_t)b - 1] && wgs_prev <= opt.fuse_max_wgs)
+      if (P.band_cd[(size_t)b]) {  // a component-dense band is carried by ANY preceding band kernel (its workgroups are
+        if (!P.band_dense[(size_t)b - 1]) P.band_fused[(size_t)b] = 1;  // handed out behind the band's own)
+      } else if (!P.band_dense[(size_t)b] && !P.band_prefix[(size_t)b] && !P.band_dense[(size_t)b - 1] &&
+                 !P.band_cd[(size_t)b - 1] && wgs_prev <= opt.fuse_max_wgs)
         P.band_fused[(size_t)b] = 1;
     }
   std::vector<int32_t> idx, tcol, tsrc;
   std::vector<T> tval;
+  // stable partition of the row's nonzeros [k0, k1) by class (0, 1, 2, ...): relative order inside a class is kept
+  auto reorder_row = [&](int32_t k0, int32_t k1, const std::function<int(int32_t)> &cls, int ncls) {
+    bool sorted = true;
+    int last = 0;
+    for (int32_t k = k0; k < k1 && sorted; ++k) {
+      const int c = cls(P.srcslot[(size_t)k]);
+      if (c < last) sorted = false;
+      last = c;
+    }
+    if (sorted) return;
+    idx.clear();
+    for (int c = 0; c < ncls; ++c)
+      for (int32_t k = k0; k < k1; ++k)
+        if (cls(P.srcslot[(size_t)k]) == c) idx.push_back(k);
+    tcol.resize(idx.size());
+    tsrc.resize(idx.size());
+    tval.resize(idx.size());
+    for (size_t q = 0; q < idx.size(); ++q) {
+      tcol[q] = A.col[(size_t)idx[q]];
+      tsrc[q] = P.srcslot[(size_t)idx[q]];
+      tval[q] = A.val[(size_t)idx[q]];
+    }
+    for (size_t q = 0; q < idx.size(); ++q) {
+      A.col[(size_t)k0 + q] = tcol[q];
+      P.srcslot[(size_t)k0 + q] = tsrc[q];
+      A.val[(size_t)k0 + q] = tval[q];
+    }
+  };
   for (int64_t b = 0; b < nb_; ++b) {
     const int32_t band0 = band_first_slot(b);
     const int32_t prev0 = b > 0 ? band_first_slot(b - 1) : 0;
+    const bool cd = P.band_cd[(size_t)b] != 0;
     for (int32_t g = P.band_wg_ptr[(size_t)b]; g < P.band_wg_ptr[(size_t)b + 1]; ++g) {
-      const int32_t s0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]], s1 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]];
-      for (int32_t s = s0; s < s1; ++s) {
-        // Block-dense bands (fast mode only; their summation order differs from the reference's anyway):
-        // a row lists ALL nonzeros whose sources were finished before the band first (relative order kept),
-        // so that the chip-wide prefix pass folds every one of them in and [split, end) holds in-band
-        // sources only.  The rows of the band's first block then need nothing but that prefix before their
-        // block product (Engine::launch_trsv delivers it straight into the product's right-hand side).
-        // Bands with a carried prefix (fast mode): the same with "older than band b-1" as the criterion.
-        const bool reorder = P.band_dense[(size_t)b] || (P.band_fused[(size_t)b] && opt.fuse_reorder);
-        const int32_t thr = P.band_dense[(size_t)b] ? s0 : prev0;
-        if (reorder) {
+      // the unit whose rows may depend on each other: the whole workgroup (flag / dense bands), or ONE component
+      // = group of a component-dense band
+      const int32_t c0 = P.wg_grp_ptr[(size_t)g], c1 = P.wg_grp_ptr[(size_t)g + 1];
+      for (int32_t c = c0; c < c1; c = cd ? c + 1 : c1) {
+        const int32_t s0 = P.grp_slot_ptr[(size_t)c], s1 = P.grp_slot_ptr[(size_t)(cd ? c + 1 : c1)];
+        for (int32_t s = s0; s < s1; ++s) {
           const int32_t k0 = A.ptr[(size_t)s], k1 = A.ptr[(size_t)s + 1];
-          idx.clear();
-          for (int32_t k = k0; k < k1; ++k)
-            if (P.srcslot[(size_t)k] < thr) idx.push_back(k);
-          const size_t npre = idx.size();
-          bool moved = false;
-          for (size_t q = 0; q < npre; ++q) moved = moved || idx[q] != k0 + (int32_t)q;
-          if (moved) {
-            for (int32_t k = k0; k < k1; ++k)
-              if (P.srcslot[(size_t)k] >= thr) idx.push_back(k);
-            tcol.resize(idx.size());
-            tsrc.resize(idx.size());
-            tval.resize(idx.size());
-            for (size_t q = 0; q < idx.size(); ++q) {
-              tcol[q] = A.col[(size_t)idx[q]];
-              tsrc[q] = P.srcslot[(size_t)idx[q]];
-              tval[q] = A.val[(size_t)idx[q]];
-            }
-            for (size_t q = 0; q < idx.size(); ++q) {
-              A.col[(size_t)k0 + q] = tcol[q];
-              P.srcslot[(size_t)k0 + q] = tsrc[q];
-              A.val[(size_t)k0 + q] = tval[q];
-            }
+          // Block-dense bands (fast mode only; their summation order differs from the reference's anyway):
+          // a row lists ALL nonzeros whose sources were finished before the band first (relative order kept),
+          // so that the chip-wide prefix pass folds every one of them in and [split, end) holds in-band
+          // sources only.  The rows of the band's first block then need nothing but that prefix before their
+          // block product (Engine::launch_trsv delivers it straight into the product's right-hand side).
+          // Bands with a carried prefix (fast mode): the same with "older than band b-1" as the criterion.
+          // Component-dense bands: [older than band b-1 | band b-1 | own component]; the first part is carried by the
+          // previous launch (when fused), the second is gathered by the component's workgroup, the third IS the inverse.
+          if (cd) {
+            const bool fz = P.band_fused[(size_t)b] != 0;
+            reorder_row(k0, k1, [&](int32_t q) { return q >= s0 ? 2 : ((fz && q < prev0) ? 0 : 1); }, 3);
+          } else if (P.band_dense[(size_t)b]) {
+            reorder_row(k0, k1, [&](int32_t q) { return q < s0 ? 0 : 1; }, 2);
+          } else if (P.band_fused[(size_t)b] && opt.fuse_reorder) {
+            reorder_row(k0, k1, [&](int32_t q) { return q < prev0 ? 0 : 1; }, 2);
           }
-        }
-        int32_t kk = A.ptr[(size_t)s];
-        if (P.band_prefix[(size_t)b])
-          while (kk < A.ptr[(size_t)s + 1] && P.srcslot[(size_t)kk] < s0) ++kk;
-        else if (P.band_fused[(size_t)b])
-          while (kk < A.ptr[(size_t)s + 1] && P.srcslot[(size_t)kk] < prev0) ++kk;
-        P.split[(size_t)s] = kk;
-        for (int32_t k = A.ptr[(size_t)s]; k < A.ptr[(size_t)s + 1]; ++k) {
-          const int32_t q = P.srcslot[(size_t)k];  // either before the band, or earlier in this workgroup
-          if (!(q < band0 || (q >= s0 && q < s)))
-            throw Error(4, "internal error: band plan violates the dependency order");
+          int32_t kk = k0;
+          if (P.band_prefix[(size_t)b])
+            while (kk < k1 && P.srcslot[(size_t)kk] < s0) ++kk;
+          else if (P.band_fused[(size_t)b])
+            while (kk < k1 && P.srcslot[(size_t)kk] < prev0) ++kk;
+          P.split[(size_t)s] = kk;
+          int32_t kc = k1;
+          if (cd) {
+            kc = kk;
+            while (kc < k1 && P.srcslot[(size_t)kc] < s0) ++kc;
+          }
+          P.csplit[(size_t)s] = kc;
+          for (int32_t k = k0; k < k1; ++k) {
+            const int32_t q = P.srcslot[(size_t)k];  // either before the band, or earlier in this unit
+            if (q < band0) P.band_old[(size_t)b] = 1;
+            if (!(q < band0 || (q >= s0 && q < s)))
+              throw Error(4, "internal error: band plan violates the dependency order");
+            if (cd && ((k < kc) != (q < s0)))
+              throw Error(4, "internal error: component-dense row is not partitioned into old and own sources");
+          }
         }
       }
     }

@@ -92,8 +92,14 @@ void analyze_level(HostLevel<T> &H, const BandOptions &band_opt, bool dump = fal
   H.Ls = level_schedule(H.Lr, true);
   H.Us = level_schedule(H.Ur, false);
   double t1 = now();
-  H.Lp = plan_bands(H.Lr, H.Ls, true, band_opt);
-  H.Up = plan_bands(H.Ur, H.Us, false, band_opt);
+  // component-dense plan (host.hpp plan_bands_cd) for triangles with real rows to gather; the depth-cut bands for the
+  // nearly diagonal ones (level 0 of a PDE hierarchy: ~2 nonzeros per row, shallow, bandwidth-bound) and in exact mode
+  auto use_cd = [&](const Csr<T> &A) {
+    return band_opt.cd_rows > 0 && band_opt.dense_block > 0 && A.nrows > 0 &&
+           (double)A.col.size() >= band_opt.cd_min_row_nnz * (double)A.nrows;
+  };
+  H.Lp = use_cd(H.Lr) ? plan_bands_cd(H.Lr, H.Ls, true, band_opt) : plan_bands(H.Lr, H.Ls, true, band_opt);
+  H.Up = use_cd(H.Ur) ? plan_bands_cd(H.Ur, H.Us, false, band_opt) : plan_bands(H.Ur, H.Us, false, band_opt);
   double t2 = now();
   H.Lr = permute_rows(H.Lr, H.Lp.order);
   H.Ur = permute_rows(H.Ur, H.Up.order);
@@ -118,10 +124,16 @@ void analyze_level(HostLevel<T> &H, const BandOptions &band_opt, bool dump = fal
         maxrows = std::max<int64_t>(maxrows, e - a);
         maxdepth = std::max<int64_t>(maxdepth, P.wg_grp_ptr[(size_t)g + 1] - P.wg_grp_ptr[(size_t)g]);
       }
-      std::fprintf(stderr, "PLAN level=%zu tri=%c band=%ld rows=%d nnz=%d wgs=%d prefix=%d dense=%d fused=%d maxwg_nnz=%ld maxwg_rows=%ld maxdepth=%ld\n",
+      int64_t own = 0, prevb = 0;  // nonzeros inside the rows' own component / gathered by the band kernel itself
+      for (int32_t q = s0; q < s1; ++q) {
+        own += A.ptr[(size_t)q + 1] - P.csplit[(size_t)q];
+        prevb += P.csplit[(size_t)q] - P.split[(size_t)q];
+      }
+      std::fprintf(stderr, "PLAN level=%zu tri=%c band=%ld rows=%d nnz=%d wgs=%d prefix=%d dense=%d fused=%d cd=%d comps=%d own=%ld inband=%ld maxwg_nnz=%ld maxwg_rows=%ld maxdepth=%ld\n",
                    level_no, tri ? 'U' : 'L', (long)b, s1 - s0, A.ptr[(size_t)s1] - A.ptr[(size_t)s0], g1 - g0,
-                   (int)P.band_prefix[(size_t)b], (int)P.band_dense[(size_t)b], (int)P.band_fused[(size_t)b], (long)maxnnz,
-                   (long)maxrows, (long)maxdepth);
+                   (int)P.band_prefix[(size_t)b], (int)P.band_dense[(size_t)b], (int)P.band_fused[(size_t)b],
+                   (int)P.band_cd[(size_t)b], P.wg_grp_ptr[(size_t)g1] - P.wg_grp_ptr[(size_t)g0], (long)own, (long)prevb,
+                   (long)maxnnz, (long)maxrows, (long)maxdepth);
     }
   }
 }
@@ -206,7 +218,7 @@ void check_csr(const Csr<T> &A, int64_t nnz_expected, const char *what, size_t l
 }
 
 template <class T>
-void check_band_plan(const BandPlan &P, const Csr<T> &A, const char *what, size_t level_no) {
+void check_band_plan(const BandPlan &P, const Csr<T> &A, const char *what, size_t level_no, int64_t cd_rows_limit = 1 << 20) {
   auto fail = [&](const char *why, int64_t at) {
     throw Error(kHifirError, std::string("internal error: band plan of ") + what + " of level " + std::to_string(level_no) +
                                  ": " + why + " at " + std::to_string(at));
@@ -225,9 +237,25 @@ void check_band_plan(const BandPlan &P, const Csr<T> &A, const char *what, size_
   monotone(P.grp_slot_ptr, (int32_t)m, "group pointer");
   monotone(P.wg_grp_ptr, (int32_t)P.grp_slot_ptr.size() - 1, "workgroup pointer");
   monotone(P.band_wg_ptr, (int32_t)P.wg_grp_ptr.size() - 1, "band pointer");
-  for (int32_t g = 0; g + 1 < (int32_t)P.wg_grp_ptr.size(); ++g)
-    if (P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]] - P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]] > 16384)
-      fail("workgroup owns more rows than it has LDS flags", g);
+  const int64_t nbands = (int64_t)P.band_wg_ptr.size() - 1;
+  if ((int64_t)P.band_cd.size() != nbands || (int64_t)P.band_dense.size() != nbands || (int64_t)P.band_prefix.size() != nbands ||
+      (int64_t)P.band_fused.size() != nbands || (int64_t)P.csplit.size() != m ||
+      (int64_t)P.grp_inv_off.size() != (int64_t)P.grp_slot_ptr.size() - 1)
+    fail("per-band array length", nbands);
+  for (int64_t s = 0; s < m; ++s)
+    if (P.csplit[(size_t)s] < P.split[(size_t)s] || P.csplit[(size_t)s] > A.ptr[(size_t)s + 1]) fail("component split outside its row", s);
+  for (int64_t b = 0; b < nbands; ++b)
+    for (int32_t g = P.band_wg_ptr[(size_t)b]; g < P.band_wg_ptr[(size_t)b + 1]; ++g) {
+      if (P.band_cd[(size_t)b]) {  // components must fit the LDS block of the kernel and own an inverse
+        for (int32_t c = P.wg_grp_ptr[(size_t)g]; c < P.wg_grp_ptr[(size_t)g + 1]; ++c) {
+          const int32_t nb = P.grp_slot_ptr[(size_t)c + 1] - P.grp_slot_ptr[(size_t)c];
+          if (nb < 1 || nb > cd_rows_limit) fail("component size", c);
+          if (P.grp_inv_off[(size_t)c] < 0) fail("component without an inverse", c);
+        }
+      } else if (P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]] - P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]] > 16384 &&
+                 !P.band_dense[(size_t)b])
+        fail("workgroup owns more rows than it has LDS flags", g);
+    }
   for (size_t q = 0; q < P.blk_slot0.size(); ++q)
     if (P.blk_slot0[q] < 0 || P.blk_slot1[q] <= P.blk_slot0[q] || P.blk_slot1[q] > m) fail("block range", (int64_t)q);
 }

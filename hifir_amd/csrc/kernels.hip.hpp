@@ -1431,6 +1431,104 @@ __global__ void __launch_bounds__(NW * 64) k_tri_gemm_d(int nb, const double *__
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Component-dense band (host.hpp plan_bands_cd), R = 64, real data.  Workgroup wg0 + blockIdx.x owns the components
+// (groups) [wg_grp_ptr[g], wg_grp_ptr[g+1]); a component is a set of <= cd_rows rows that depend only on each other and
+// on rows finished by EARLIER launches.  Per component:
+//   phase 1  t[r] = rhs[r] - sum over the row's nonzeros in [kbeg, csplit) -- sources outside the component, all
+//            finished: the 16 waves stream the rows with the item/batch pipeline of trsv_stream_r64, no flags, no
+//            polling -- into LDS (one 512-byte row per component row);
+//   phase 2  x = Tinv_c * t on the f64 matrix cores: Tinv_c is the explicit inverse of the component's own unit
+//            triangle (strip-major, built on the host), the B operand comes from LDS.  Units of (16-row strip, 16-column
+//            tile) are dealt to the waves heaviest first; two accumulators per unit, operand sets of 8 k-steps double
+//            buffered (the layout and lane maps of k_tri_gemm_d).
+// No dependent step survives inside a launch, whatever the depth of the component.  kbeg = split[] when the previous
+// launch carried this band's prefix over the older sources (then the rows already hold partial sums), else ptr[].
+// Workgroups beyond n_band run the carried prefix of the NEXT band, exactly as in k_trsv_band_p.
+// The summation order differs from the reference's (tolerance-level, like every block-dense band); exact mode never
+// plans such bands.
+// ---------------------------------------------------------------------------------------------
+template <bool LOWER>
+__global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__restrict__ wg_grp_ptr,
+                                                  const int32_t *__restrict__ grp_slot_ptr,
+                                                  const int64_t *__restrict__ grp_inv_off,
+                                                  const int32_t *__restrict__ ptr, const int32_t *__restrict__ split,
+                                                  const int32_t *__restrict__ csplit, const int32_t *__restrict__ col,
+                                                  const double *__restrict__ val, const int32_t *__restrict__ rowid,
+                                                  const double *__restrict__ d, double *w, double *v,
+                                                  const double *__restrict__ tinv, int start_at_split, int first_u,
+                                                  int32_t n_band, int32_t ps0, int32_t ps1) {
+  extern __shared__ double cd_tbuf[];  // [cd_rows][64]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if ((int32_t)blockIdx.x >= n_band) {  // carried prefix of the next band over the sources older than this band
+    const int32_t pw = __builtin_amdgcn_readfirstlane(((int32_t)blockIdx.x - n_band) * nw + wave);
+    trsv_stream_r64<double, 0, LOWER, true>(ps0 + pw, ps1, ((int32_t)gridDim.x - n_band) * nw, ptr, split, col, val, nullptr,
+                                            rowid, d, LOWER ? w : v, w, lane, nullptr, 0, nullptr, true);
+    return;
+  }
+  const int32_t *kbeg = start_at_split ? split : ptr;
+  double *x = LOWER ? w : v;
+  const int g = wg0 + (int)blockIdx.x;
+  const int32_t c_first = wg_grp_ptr[g], c_last = wg_grp_ptr[g + 1];
+  const int kq = lane >> 4;
+  for (int32_t c = c_first; c < c_last; ++c) {
+    const int32_t s0 = grp_slot_ptr[c], s1 = grp_slot_ptr[c + 1], nb = s1 - s0;
+    // ---- phase 1: right-hand sides of the component into LDS
+    trsv_stream_r64<double, 0, LOWER, true>(s0 + wave, s1, nw, kbeg, csplit, col, val, nullptr, rowid, d, x, w, lane, nullptr,
+                                            0, nullptr, first_u != 0, cd_tbuf, s0, s1);
+    __syncthreads();
+    // ---- phase 2: x = Tinv * t
+    const int lda = (nb + 31) & ~31;
+    const double *Ac = tinv + grp_inv_off[c];
+    const int S = (nb + 15) >> 4, nunits = S * 4;
+    for (int q = wave; q < nunits; q += nw) {
+      const int strip = S - 1 - (q >> 2), ct = q & 3;
+      const int kend = min(nb, 16 * (strip + 1));
+      const int nsets = (kend + 31) >> 5;
+      const double *Ap = Ac + ((int64_t)strip * lda) * 16 + (lane & 15);
+      const double *Bp = cd_tbuf + ct * 16 + (lane & 15);
+      v4f64 acc0 = v4f64{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+      constexpr int KU = 8;
+      double a0[KU], a1[KU];
+#define HIFAMD_CD_LOAD(aa, t_)                                          \
+  {                                                                     \
+    const double *ap_ = Ap + (int64_t)(32 * (t_) + kq) * 16;            \
+    _Pragma("unroll") for (int u = 0; u < KU; ++u) aa[u] = ap_[u * 64]; \
+  }
+#define HIFAMD_CD_MFMA(aa, t_)                                                        \
+  {                                                                                   \
+    const int kb_ = 32 * (t_) + kq;                                                   \
+    _Pragma("unroll") for (int u = 0; u < KU; u += 2) {                               \
+      const double b0_ = (kb_ + 4 * u < nb) ? Bp[(kb_ + 4 * u) << 6] : 0.0;           \
+      const double b1_ = (kb_ + 4 * u + 4 < nb) ? Bp[(kb_ + 4 * u + 4) << 6] : 0.0;   \
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], b0_, acc0, 0, 0, 0);         \
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u + 1], b1_, acc1, 0, 0, 0);     \
+    }                                                                                 \
+  }
+      int t = 0;
+      HIFAMD_CD_LOAD(a0, 0)
+      while (t < nsets) {
+        if (t + 1 < nsets) HIFAMD_CD_LOAD(a1, t + 1)
+        HIFAMD_CD_MFMA(a0, t)
+        if (t + 1 >= nsets) break;
+        if (t + 2 < nsets) HIFAMD_CD_LOAD(a0, t + 2)
+        HIFAMD_CD_MFMA(a1, t + 1)
+        t += 2;
+      }
+#undef HIFAMD_CD_LOAD
+#undef HIFAMD_CD_MFMA
+      const v4f64 acc = acc0 + acc1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * strip + kq + 4 * r;
+        if (row < nb) x[((int64_t)rowid[s0 + row] << 6) + ct * 16 + (lane & 15)] = acc[r];
+      }
+    }
+    __syncthreads();  // (the next component overwrites the LDS block)
+  }
+}
+
 // Complex products on the real matrix cores: with X viewed as a real [rows][2R] block (re, im interleaved),
 // T1 = A_re * X and T2 = A_im * X are two real MFMA products (k_dense_gemm_d / k_tri_gemm_d at logR + 1);
 // this kernel recombines  out = (T1_re - T2_im) + i (T1_im + T2_re),  applies the output row permutation

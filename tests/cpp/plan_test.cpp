@@ -91,8 +91,104 @@ static int run(int64_t m, int fan, int64_t dense_block) {
   return bad;
 }
 
+// The component-dense plan (host.hpp plan_bands_cd), lower and upper, checked NUMERICALLY on the host: the plan is
+// executed band by band exactly as the device does it -- right-hand sides minus the sources outside the component
+// ([ptr, csplit)), then the product with the component's explicit inverse read from the operand layout the kernels
+// use; dense rest bands block by block -- and compared with the plain sequential substitution.
+template <class T>
+static int run_cd(int64_t m, int fan, int64_t cd_rows, int64_t dense_block) {
+  BandOptions opt;
+  opt.cd_rows = cd_rows;
+  opt.dense_block = dense_block;
+  opt.max_wg_rows = 16384;
+  int bad = 0;
+  for (int upper = 0; upper < 2; ++upper) {
+    Ccs<T> L = make_lower<T>(m, fan, 91 + m);
+    Csr<T> R;
+    if (!upper) {
+      R = ccs_to_csr(L, false);
+    } else {  // the transposed pattern as a strict UPPER triangle in descending-column row form
+      Ccs<T> U;
+      U.nrows = U.ncols = m;
+      U.colptr.assign((size_t)m + 1, 0);
+      Csr<T> Lr = ccs_to_csr(L, false);  // rows of L = columns of U
+      for (int64_t j = 0; j < m; ++j) U.colptr[(size_t)j + 1] = U.colptr[(size_t)j] + (Lr.ptr[(size_t)j + 1] - Lr.ptr[(size_t)j]);
+      U.rowind.assign(Lr.col.begin(), Lr.col.end());
+      U.vals.assign(Lr.val.begin(), Lr.val.end());
+      R = ccs_to_csr(U, true);
+    }
+    Schedule S = level_schedule(R, !upper);
+    BandPlan P = plan_bands_cd(R, S, !upper, opt);
+    Csr<T> Rs = permute_rows(R, P.order);
+    finish_band_plan(P, Rs, opt);  // (re-checks every dependency against the executed order, throws otherwise)
+    const int64_t elems = plan_dense_blocks<T>(P, opt);
+    std::vector<double> ops((size_t)elems, 0.0);
+    for (size_t q = 0; q < P.blk_slot0.size(); ++q) build_dense_block(P, Rs, q, ops.data() + P.blk_inv_off[q], true);
+    // reference: plain substitution in the natural order
+    std::mt19937_64 g(5 + m);
+    std::uniform_real_distribution<double> u(-1.0, 1.0);
+    std::vector<T> b((size_t)m), xr, x;
+    for (auto &v : b) v = T(u(g));
+    xr = b;
+    for (int64_t ii = 0; ii < m; ++ii) {
+      const int64_t i = upper ? m - 1 - ii : ii;
+      T acc = xr[(size_t)i];
+      for (int32_t k = R.ptr[(size_t)i]; k < R.ptr[(size_t)i + 1]; ++k) acc -= R.val[(size_t)k] * xr[(size_t)R.col[(size_t)k]];
+      xr[(size_t)i] = acc;
+    }
+    x = b;
+    auto tinv_at = [&](size_t q, int32_t r, int32_t k) {
+      const int32_t nb = P.blk_slot1[q] - P.blk_slot0[q];
+      const int64_t lda = round_up32(nb), plane = plane_elems(nb, lda);
+      const int64_t e = ((int64_t)(r >> 4) * lda + k) * 16 + (r & 15);
+      const double *o = ops.data() + P.blk_inv_off[q];
+      return sizeof(T) == sizeof(double) ? T(o[e]) : T(zdouble(o[e], o[plane + e]).real());
+    };
+    int64_t ncd = 0, ncomp = 0, maxcomp = 0;
+    for (int64_t bnd = 0; bnd < P.nbands(); ++bnd) {
+      if (!P.band_cd[(size_t)bnd] && !P.band_dense[(size_t)bnd]) {
+        ++bad;  // the component-dense planner emits nothing else
+        continue;
+      }
+      ncd += P.band_cd[(size_t)bnd];
+      for (int32_t q = P.band_blk_ptr[(size_t)bnd]; q < P.band_blk_ptr[(size_t)bnd + 1]; ++q) {
+        const int32_t r0 = P.blk_slot0[(size_t)q], nb = P.blk_slot1[(size_t)q] - r0;
+        if (P.band_cd[(size_t)bnd]) ++ncomp, maxcomp = std::max<int64_t>(maxcomp, nb);
+        std::vector<T> t((size_t)nb);
+        for (int32_t r = 0; r < nb; ++r) {
+          const int32_t s = r0 + r;
+          T acc = x[(size_t)Rs.rowid[(size_t)s]];
+          for (int32_t k = Rs.ptr[(size_t)s]; k < Rs.ptr[(size_t)s + 1]; ++k)
+            if (P.srcslot[(size_t)k] < r0) {
+              if (P.band_cd[(size_t)bnd] && k >= P.csplit[(size_t)s]) ++bad;
+              acc -= Rs.val[(size_t)k] * x[(size_t)Rs.col[(size_t)k]];
+            } else if (P.band_cd[(size_t)bnd] && k < P.csplit[(size_t)s])
+              ++bad;
+          t[(size_t)r] = acc;
+        }
+        for (int32_t r = 0; r < nb; ++r) {
+          T acc = T(0);
+          for (int32_t k = 0; k <= r; ++k) acc += tinv_at((size_t)q, r, k) * t[(size_t)k];
+          x[(size_t)Rs.rowid[(size_t)(r0 + r)]] = acc;
+        }
+      }
+    }
+    double err = 0.0, nrm = 0.0;
+    for (int64_t i = 0; i < m; ++i) err = std::max(err, abs_(x[(size_t)i] - xr[(size_t)i])), nrm = std::max(nrm, abs_(xr[(size_t)i]));
+    if (!(err <= 1e-12 * nrm) || maxcomp > cd_rows) ++bad;
+    std::printf("cd plan m=%ld fan=%d %s cd_rows=%ld: %ld wavefronts -> %ld bands (%ld component-dense, %ld components, largest %ld rows), "
+                "relerr %.2e, bad=%d\n", (long)m, fan, upper ? "upper" : "lower", (long)cd_rows, (long)S.nwf(), (long)P.nbands(),
+                (long)ncd, (long)ncomp, (long)maxcomp, err / nrm, bad);
+  }
+  return bad;
+}
+
 int main() {
   int bad = 0;
+  bad += run_cd<double>(3000, 2, 192, 2048);
+  bad += run_cd<double>(9000, 3, 64, 512);
+  bad += run_cd<double>(20000, 6, 192, 2048);
+  bad += run_cd<double>(700, 1, 32, 64);
   bad += run<double>(3000, 2, 2048);
   bad += run<double>(9000, 3, 2048);
   bad += run<double>(9000, 3, 512);
