@@ -142,7 +142,7 @@ struct DevCsr {
   // band plan of a triangle (host.hpp BandPlan); empty for E, F, A
   DevBuf srcslot, split, wg_grp_ptr, grp_slot_ptr;
   DevBuf wg_slot;  // first slot of every workgroup (+ end): grp_slot_ptr[wg_grp_ptr[g]], one load level less at kernel start
-  DevBuf csplit, grp_inv_off;  // component-dense bands (host.hpp plan_bands_cd)
+  DevBuf csplit, grp_inv_off, cd_desc, mid_col, mid_val, mid_lrow;  // component-dense bands (host.hpp plan_bands_cd)
   std::vector<int32_t> band_wg_ptr, band_slot_ptr;
   std::vector<uint8_t> band_prefix, band_dense, band_fused, band_cd, band_old;
   std::vector<int32_t> band_blk_ptr, blk_slot0, blk_slot1;
@@ -164,6 +164,10 @@ struct DevCsr {
     wg_slot.alias(o.wg_slot);
     csplit.alias(o.csplit);
     grp_inv_off.alias(o.grp_inv_off);
+    cd_desc.alias(o.cd_desc);
+    mid_col.alias(o.mid_col);
+    mid_val.alias(o.mid_val);
+    mid_lrow.alias(o.mid_lrow);
     band_cd = o.band_cd;
     band_old = o.band_old;
     tinv.alias(o.tinv);
@@ -198,6 +202,15 @@ struct DevCsr {
       }
       csplit.upload(P->csplit);
       grp_inv_off.upload(P->grp_inv_off);
+      cd_desc.upload(P->cd_desc);
+      {  // the packed gather streams of the component-dense bands: column and value of every entry, 80 padding entries
+        std::vector<int32_t> mc(P->mid_k.size());
+        std::vector<T> mv(P->mid_k.size());
+        for (size_t e = 0; e < mc.size(); ++e) mc[e] = A.col[(size_t)P->mid_k[e]], mv[e] = A.val[(size_t)P->mid_k[e]];
+        mid_col.upload(mc, 80);
+        mid_val.upload(mv, 80);
+        mid_lrow.upload(P->mid_lrow, 80);
+      }
       band_cd = P->band_cd;
       band_old = P->band_old;
       band_wg_ptr = P->band_wg_ptr;
@@ -332,8 +345,8 @@ class Engine : public EngineBase {
     band_opt.fuse_reorder = band_opt.dense_block > 0;                  // exact mode keeps the reference's order
     band_opt.fuse_max_wgs = env_int("HIFIR_AMD_BAND_FUSE_WGS", 512);
     // component-dense bands (host.hpp plan_bands_cd): real data, fast mode; HIFIR_AMD_CD_ROWS=0 keeps the depth-cut bands
-    band_opt.cd_rows = (sizeof(T) == sizeof(double) && band_opt.dense_block > 0) ? env_int("HIFIR_AMD_CD_ROWS", 192) : 0;
-    if (band_opt.cd_rows > 256) band_opt.cd_rows = 256;  // 128 KB of the CU's 160 KB LDS
+    band_opt.cd_rows = (sizeof(T) == sizeof(double) && band_opt.dense_block > 0) ? env_int("HIFIR_AMD_CD_ROWS", 128) : 0;
+    if (band_opt.cd_rows > 240) band_opt.cd_rows = 240;  // (local row ids are bytes; 120 KB of the CU's 160 KB LDS)
   }
 
   void bind_device() {
@@ -894,11 +907,12 @@ class Engine : public EngineBase {
                       int32_t ps1, unsigned extra) {
     if constexpr (std::is_same<T, double>::value) {
       const size_t lds = (size_t)band_opt.cd_rows * 64 * sizeof(double);  // (the attribute for > 64 KB is set in bind_device)
+      (void)pre;  // (the packed streams already start at split[] for a carried band, at ptr[] otherwise)
       hipLaunchKernelGGL((k_band_cd<LOWER>), dim3((unsigned)(g1 - g0) + extra), dim3(1024), lds, st, g0,
-                         M.wg_grp_ptr.as<int32_t>(), M.grp_slot_ptr.as<int32_t>(), M.grp_inv_off.as<int64_t>(),
-                         M.ptr.as<int32_t>(), M.split.as<int32_t>(), M.csplit.as<int32_t>(), M.col.as<int32_t>(),
-                         M.val.as<double>(), M.rowid.as<int32_t>(), L.d.as<double>(), L.w.as<double>(), L.v.as<double>(),
-                         M.tinv.as<double>(), pre, pre ? 0 : 1, (int32_t)(g1 - g0), ps0, ps1);
+                         M.wg_grp_ptr.as<int32_t>(), M.cd_desc.as<int32_t>(), M.ptr.as<int32_t>(), M.split.as<int32_t>(),
+                         M.col.as<int32_t>(), M.val.as<double>(), M.rowid.as<int32_t>(), L.d.as<double>(), L.w.as<double>(),
+                         L.v.as<double>(), M.tinv.as<double>(), M.mid_col.as<int32_t>(), M.mid_val.as<double>(),
+                         M.mid_lrow.as<uint8_t>(), pre ? 0 : 1, (int32_t)(g1 - g0), ps0, ps1);
     } else {
       (void)st, (void)L, (void)M, (void)g0, (void)g1, (void)pre, (void)ps0, (void)ps1, (void)extra;
       throw Error(HIFAMD_HIFIR_ERROR, "internal error: component-dense band on a complex handle");

@@ -269,9 +269,19 @@ struct BandPlan {
   std::vector<uint8_t> band_old;      // band b has nonzeros that refer to earlier bands (else no prefix work exists)
   std::vector<int32_t> csplit;        // per slot: first nonzero whose source lies in the row's own component
   std::vector<int64_t> grp_inv_off;   // per group: offset of the component's inverse (cd bands; -1 elsewhere)
+  // what a component's workgroup gathers itself -- the nonzeros [split, csplit) of its rows (sources in the previous
+  // band; everything older when no launch carried it) -- as ONE packed stream per component, so that a wave keeps its
+  // gathers in flight across row boundaries: entry e = (nonzero index mid_k[e] of the slot-ordered CSR, local row)
+  std::vector<int32_t> mid_k;
+  std::vector<uint8_t> mid_lrow;
+  // per group kCdDescWords int32 words (cd bands; zeros elsewhere): s0, nb, mid0, nmid, inv_off (2 words), then the
+  // 16 waves' row chunks wrow[17] (uint8) and their entry offsets wmid[17] (uint16, relative to mid0)
+  std::vector<int32_t> cd_desc;
   int64_t nbands() const { return (int64_t)band_wg_ptr.size() - 1; }
   int64_t nwg() const { return (int64_t)wg_grp_ptr.size() - 1; }
 };
+
+constexpr int kCdDescWords = 20;  // 80 bytes per component descriptor (BandPlan::cd_desc)
 
 struct BandOptions {
   int64_t thin_rows = 96;    // a wavefront this narrow belongs to a thin run
@@ -730,6 +740,62 @@ inline void put_operand(double *base, int64_t plane, int64_t idx, const zdouble 
   base[plane + idx] = v.imag();
 }
 
+// Packed gather streams and descriptors of the component-dense bands (BandPlan::mid_k / mid_lrow / cd_desc).  The
+// rows of a component are dealt to the workgroup's 16 waves as CONTIGUOUS chunks balanced by (entries + rows); a wave
+// initialises its rows' right-hand sides in LDS and subtracts its entries, no other wave touches those rows in phase 1.
+inline void build_cd_streams(BandPlan &P) {
+  const size_t ngrp = P.grp_slot_ptr.size() - 1;
+  P.cd_desc.assign(ngrp * (size_t)kCdDescWords, 0);
+  P.mid_k.clear();
+  P.mid_lrow.clear();
+  if (P.band_cd.empty()) return;
+  constexpr int NW = 16;
+  for (int64_t b = 0; b < P.nbands(); ++b) {
+    if (!P.band_cd[(size_t)b]) continue;
+    for (int32_t g = P.band_wg_ptr[(size_t)b]; g < P.band_wg_ptr[(size_t)b + 1]; ++g)
+      for (int32_t c = P.wg_grp_ptr[(size_t)g]; c < P.wg_grp_ptr[(size_t)g + 1]; ++c) {
+        const int32_t s0 = P.grp_slot_ptr[(size_t)c], nb = P.grp_slot_ptr[(size_t)c + 1] - s0;
+        if (nb > 255) throw Error(4, "internal error: component larger than 255 rows");
+        const int64_t mid0 = (int64_t)P.mid_k.size();
+        std::vector<int32_t> rowstart((size_t)nb + 1, 0);
+        for (int32_t r = 0; r < nb; ++r) {
+          for (int32_t k = P.split[(size_t)(s0 + r)]; k < P.csplit[(size_t)(s0 + r)]; ++k) {
+            P.mid_k.push_back(k);
+            P.mid_lrow.push_back((uint8_t)r);
+          }
+          rowstart[(size_t)r + 1] = (int32_t)((int64_t)P.mid_k.size() - mid0);
+        }
+        const int32_t nmid = rowstart[(size_t)nb];
+        if (nmid > 65535 || mid0 + nmid > (int64_t)std::numeric_limits<int32_t>::max())
+          throw Error(4, "internal error: component gather stream too long");
+        int32_t *dsc = &P.cd_desc[(size_t)c * kCdDescWords];
+        dsc[0] = s0, dsc[1] = nb, dsc[2] = (int32_t)mid0, dsc[3] = nmid;
+        std::memcpy(&dsc[4], &P.grp_inv_off[(size_t)c], 8);
+        uint8_t *wrow = reinterpret_cast<uint8_t *>(&dsc[6]);
+        uint16_t *wmid = reinterpret_cast<uint16_t *>(&dsc[11]);
+        // chunk boundaries: wave w takes rows while the cost so far (an entry = 1, a row = 2) stays within its share;
+        // at most 64 rows per wave (its row ids sit one per lane)
+        const double total = (double)nmid + 2.0 * nb;
+        int32_t r = 0;
+        for (int w = 0; w < NW; ++w) {
+          wrow[w] = (uint8_t)r;
+          wmid[w] = (uint16_t)rowstart[(size_t)r];
+          const double goal = (w == NW - 1) ? total + 1.0 : total * (w + 1) / NW;
+          const int32_t first = r;
+          while (r < nb && r - first < 64 && (double)rowstart[(size_t)r + 1] + 2.0 * (r + 1) <= goal + 1e-9) ++r;
+        }
+        if (r < nb) {  // (a chunk ran into the 64-row limit: spread the rows evenly instead -- nb <= 255: <= 16 rows per wave)
+          for (int w = 0; w < NW; ++w) {
+            const int32_t rr = (int32_t)((int64_t)nb * w / NW);
+            wrow[w] = (uint8_t)rr, wmid[w] = (uint16_t)rowstart[(size_t)rr];
+          }
+        }
+        wrow[NW] = (uint8_t)nb;
+        wmid[NW] = (uint16_t)nmid;
+      }
+  }
+}
+
 // Pass 1 (import time, cheap): cut every candidate band into blocks and lay their MFMA operands out back to
 // back; returns the total number of doubles.  blk_inv_off counts doubles; complex blocks hold two planes.
 template <class T>
@@ -765,6 +831,7 @@ int64_t plan_dense_blocks(BandPlan &P, const BandOptions &opt) {
     }
     P.band_blk_ptr.push_back((int32_t)P.blk_slot0.size());
   }
+  build_cd_streams(P);
   return total;
 }
 inline int64_t dense_block_elems(int64_t nb, bool cplx) { return (cplx ? 2 : 1) * plane_elems(nb, round_up32(nb)); }

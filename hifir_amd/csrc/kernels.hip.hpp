@@ -1434,60 +1434,132 @@ __global__ void __launch_bounds__(NW * 64) k_tri_gemm_d(int nb, const double *__
 // ---------------------------------------------------------------------------------------------
 // Component-dense band (host.hpp plan_bands_cd), R = 64, real data.  Workgroup wg0 + blockIdx.x owns the components
 // (groups) [wg_grp_ptr[g], wg_grp_ptr[g+1]); a component is a set of <= cd_rows rows that depend only on each other and
-// on rows finished by EARLIER launches.  Per component:
-//   phase 1  t[r] = rhs[r] - sum over the row's nonzeros in [kbeg, csplit) -- sources outside the component, all
-//            finished: the 16 waves stream the rows with the item/batch pipeline of trsv_stream_r64, no flags, no
-//            polling -- into LDS (one 512-byte row per component row);
+// on rows finished by EARLIER launches.  Per component (descriptor: host.hpp build_cd_streams):
+//   phase 1  t[r] = rhs[r] - (the row's nonzeros whose sources lie outside the component and were not carried by the
+//            previous launch).  Those nonzeros of ALL rows form one packed stream (column, value, local row); every wave
+//            owns a contiguous chunk of rows and of the stream: it puts its rows' right-hand sides into LDS (all loads in
+//            flight at once), then walks its entries as items of 64 with eight gathers per batch -- across row
+//            boundaries, the running row's sum in a register, LDS touched once per row change.  No flags, no polling;
 //   phase 2  x = Tinv_c * t on the f64 matrix cores: Tinv_c is the explicit inverse of the component's own unit
-//            triangle (strip-major, built on the host), the B operand comes from LDS.  Units of (16-row strip, 16-column
-//            tile) are dealt to the waves heaviest first; two accumulators per unit, operand sets of 8 k-steps double
-//            buffered (the layout and lane maps of k_tri_gemm_d).
-// No dependent step survives inside a launch, whatever the depth of the component.  kbeg = split[] when the previous
-// launch carried this band's prefix over the older sources (then the rows already hold partial sums), else ptr[].
-// Workgroups beyond n_band run the carried prefix of the NEXT band, exactly as in k_trsv_band_p.
-// The summation order differs from the reference's (tolerance-level, like every block-dense band); exact mode never
-// plans such bands.
+//            triangle (strip-major, built on the host), the B operand comes from LDS.  A unit is one 16-row strip x two
+//            16-column tiles (an A fragment feeds two MFMAs); units go to the waves heaviest first in snake order over
+//            the four SIMDs; operand sets of 8 k-steps are double buffered.
+// No dependent step survives inside a launch, whatever the depth of the component.  Workgroups beyond n_band run the
+// carried prefix of the NEXT band, exactly as in k_trsv_band_p.  The summation order differs from the reference's
+// (tolerance-level, like every block-dense band); exact mode never plans such bands.
 // ---------------------------------------------------------------------------------------------
 template <bool LOWER>
 __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__restrict__ wg_grp_ptr,
-                                                  const int32_t *__restrict__ grp_slot_ptr,
-                                                  const int64_t *__restrict__ grp_inv_off,
-                                                  const int32_t *__restrict__ ptr, const int32_t *__restrict__ split,
-                                                  const int32_t *__restrict__ csplit, const int32_t *__restrict__ col,
+                                                  const int32_t *__restrict__ cd_desc, const int32_t *__restrict__ ptr,
+                                                  const int32_t *__restrict__ split, const int32_t *__restrict__ col,
                                                   const double *__restrict__ val, const int32_t *__restrict__ rowid,
                                                   const double *__restrict__ d, double *w, double *v,
-                                                  const double *__restrict__ tinv, int start_at_split, int first_u,
-                                                  int32_t n_band, int32_t ps0, int32_t ps1) {
+                                                  const double *__restrict__ tinv, const int32_t *__restrict__ mid_col,
+                                                  const double *__restrict__ mid_val, const uint8_t *__restrict__ mid_lrow,
+                                                  int first_u, int32_t n_band, int32_t ps0, int32_t ps1) {
   extern __shared__ double cd_tbuf[];  // [cd_rows][64]
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
   if ((int32_t)blockIdx.x >= n_band) {  // carried prefix of the next band over the sources older than this band
     const int32_t pw = __builtin_amdgcn_readfirstlane(((int32_t)blockIdx.x - n_band) * nw + wave);
     trsv_stream_r64<double, 0, LOWER, true>(ps0 + pw, ps1, ((int32_t)gridDim.x - n_band) * nw, ptr, split, col, val, nullptr,
                                             rowid, d, LOWER ? w : v, w, lane, nullptr, 0, nullptr, true);
     return;
   }
-  const int32_t *kbeg = start_at_split ? split : ptr;
   double *x = LOWER ? w : v;
+  const bool div_u = !LOWER && first_u;
+  const double *rhs = div_u ? (const double *)w : (const double *)x;
   const int g = wg0 + (int)blockIdx.x;
   const int32_t c_first = wg_grp_ptr[g], c_last = wg_grp_ptr[g + 1];
   const int kq = lane >> 4;
   for (int32_t c = c_first; c < c_last; ++c) {
-    const int32_t s0 = grp_slot_ptr[c], s1 = grp_slot_ptr[c + 1], nb = s1 - s0;
-    // ---- phase 1: right-hand sides of the component into LDS
-    trsv_stream_r64<double, 0, LOWER, true>(s0 + wave, s1, nw, kbeg, csplit, col, val, nullptr, rowid, d, x, w, lane, nullptr,
-                                            0, nullptr, first_u != 0, cd_tbuf, s0, s1);
+    const int32_t *dsc = cd_desc + (int64_t)c * 20;
+    const int32_t s0 = dsc[0], nb = dsc[1], mid0 = dsc[2];
+    const int64_t inv_off = ((int64_t)(uint32_t)dsc[5] << 32) | (uint32_t)dsc[4];
+    const uint8_t *wrow = reinterpret_cast<const uint8_t *>(dsc + 6);
+    const uint16_t *wmid = reinterpret_cast<const uint16_t *>(dsc + 11);
+    const int r0 = wrow[wave], nr = (int)wrow[wave + 1] - r0;
+    const int32_t e0 = mid0 + (int32_t)wmid[wave], e1 = mid0 + (int32_t)wmid[wave + 1];
+    // ---- phase 1a: right-hand sides of this wave's rows into LDS (row ids one per lane, eight loads in flight)
+    int32_t h_i = 0;
+    double h_d = 1.0;
+    if (lane < nr) {
+      h_i = rowid[s0 + r0 + lane];
+      if (div_u) h_d = d[h_i];
+    }
+    // first item of the wave's entry stream: requested before the right-hand sides are waited for
+    int32_t colv = 0, lrv = 0;
+    double valv = 0.0;
+    if (e0 + lane < e1) {
+      colv = mid_col[e0 + lane];
+      valv = mid_val[e0 + lane];
+      lrv = mid_lrow[e0 + lane];
+    }
+    for (int j = 0; j < nr; j += 8) {
+      double t_[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int32_t i = rl32(h_i, min(j + q, 63));
+        t_[q] = (j + q < nr) ? rhs[((int64_t)i << 6) + lane] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (j + q < nr) cd_tbuf[((r0 + j + q) << 6) + lane] = div_u ? t_[q] / rl64(h_d, min(j + q, 63)) : t_[q];
+    }
+    // ---- phase 1b: the wave's entries, items of 64, eight gathers per batch; the running row's sum stays in a register
+    int cur_r = -1;
+    double acc = 0.0;
+    for (int32_t e = e0; e < e1; e += 64) {
+      const int cnt = min(64, e1 - e);
+      int32_t colv2 = 0, lrv2 = 0;
+      double valv2 = 0.0;
+      if (e + 64 + lane < e1) {
+        colv2 = mid_col[e + 64 + lane];
+        valv2 = mid_val[e + 64 + lane];
+        lrv2 = mid_lrow[e + 64 + lane];
+      }
+      for (int t = 0; t < cnt; t += 8) {
+        int32_t j_[8], r_[8];
+        double a_[8], xv_[8];
+#pragma unroll
+        for (int b2 = 0; b2 < 8; ++b2) {
+          const int idx = min(t + b2, 63);
+          j_[b2] = rl32(colv, idx);
+          a_[b2] = rl64(valv, idx);
+          r_[b2] = rl32(lrv, idx);
+        }
+#pragma unroll
+        for (int b2 = 0; b2 < 8; ++b2)
+          if (t + b2 < cnt) xv_[b2] = x[((int64_t)j_[b2] << 6) + lane];
+#pragma unroll
+        for (int b2 = 0; b2 < 8; ++b2)
+          if (t + b2 < cnt) {
+            if (r_[b2] != cur_r) {  // (wave-uniform)
+              if (cur_r >= 0) cd_tbuf[(cur_r << 6) + lane] = acc;
+              cur_r = r_[b2];
+              acc = cd_tbuf[(cur_r << 6) + lane];
+            }
+            acc = acc - a_[b2] * xv_[b2];
+          }
+      }
+      colv = colv2;
+      valv = valv2;
+      lrv = lrv2;
+    }
+    if (cur_r >= 0) cd_tbuf[(cur_r << 6) + lane] = acc;
     __syncthreads();
     // ---- phase 2: x = Tinv * t
     const int lda = (nb + 31) & ~31;
-    const double *Ac = tinv + grp_inv_off[c];
-    const int S = (nb + 15) >> 4, nunits = S * 4;
-    for (int q = wave; q < nunits; q += nw) {
-      const int strip = S - 1 - (q >> 2), ct = q & 3;
+    const double *Ac = tinv + inv_off;
+    const int S = (nb + 15) >> 4, nunits = S * 2;
+    // snake order over the SIMDs (wave % 4): units are handed out heaviest first
+    const int wrow4 = wave >> 2, wcol4 = wave & 3;
+    for (int q = wrow4 * 4 + ((wrow4 & 1) ? 3 - wcol4 : wcol4); q < nunits; q += nw) {
+      const int strip = S - 1 - (q >> 1), ch = q & 1;
       const int kend = min(nb, 16 * (strip + 1));
       const int nsets = (kend + 31) >> 5;
       const double *Ap = Ac + ((int64_t)strip * lda) * 16 + (lane & 15);
-      const double *Bp = cd_tbuf + ct * 16 + (lane & 15);
+      const double *Bp = cd_tbuf + ch * 32 + (lane & 15);
       v4f64 acc0 = v4f64{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
       constexpr int KU = 8;
       double a0[KU], a1[KU];
@@ -1496,15 +1568,16 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
     const double *ap_ = Ap + (int64_t)(32 * (t_) + kq) * 16;            \
     _Pragma("unroll") for (int u = 0; u < KU; ++u) aa[u] = ap_[u * 64]; \
   }
-#define HIFAMD_CD_MFMA(aa, t_)                                                        \
-  {                                                                                   \
-    const int kb_ = 32 * (t_) + kq;                                                   \
-    _Pragma("unroll") for (int u = 0; u < KU; u += 2) {                               \
-      const double b0_ = (kb_ + 4 * u < nb) ? Bp[(kb_ + 4 * u) << 6] : 0.0;           \
-      const double b1_ = (kb_ + 4 * u + 4 < nb) ? Bp[(kb_ + 4 * u + 4) << 6] : 0.0;   \
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], b0_, acc0, 0, 0, 0);         \
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u + 1], b1_, acc1, 0, 0, 0);     \
-    }                                                                                 \
+#define HIFAMD_CD_MFMA(aa, t_)                                                    \
+  {                                                                               \
+    const int kb_ = 32 * (t_) + kq;                                               \
+    _Pragma("unroll") for (int u = 0; u < KU; ++u) {                              \
+      const bool ok_ = kb_ + 4 * u < nb;                                          \
+      const double b0_ = ok_ ? Bp[(kb_ + 4 * u) << 6] : 0.0;                      \
+      const double b1_ = ok_ ? Bp[((kb_ + 4 * u) << 6) + 16] : 0.0;               \
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], b0_, acc0, 0, 0, 0);     \
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], b1_, acc1, 0, 0, 0);     \
+    }                                                                             \
   }
       int t = 0;
       HIFAMD_CD_LOAD(a0, 0)
@@ -1518,11 +1591,14 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
       }
 #undef HIFAMD_CD_LOAD
 #undef HIFAMD_CD_MFMA
-      const v4f64 acc = acc0 + acc1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * strip + kq + 4 * r;
-        if (row < nb) x[((int64_t)rowid[s0 + row] << 6) + ct * 16 + (lane & 15)] = acc[r];
+        if (row < nb) {
+          double *xo = x + ((int64_t)rowid[s0 + row] << 6) + ch * 32 + (lane & 15);
+          xo[0] = acc0[r];
+          xo[16] = acc1[r];
+        }
       }
     }
     __syncthreads();  // (the next component overwrites the LDS block)

@@ -144,6 +144,30 @@ static int run_cd(int64_t m, int fan, int64_t cd_rows, int64_t dense_block) {
       const double *o = ops.data() + P.blk_inv_off[q];
       return sizeof(T) == sizeof(double) ? T(o[e]) : T(zdouble(o[e], o[plane + e]).real());
     };
+    // the packed gather streams and descriptors of the component-dense bands (build_cd_streams): every component's
+    // stream is exactly the [split, csplit) ranges of its rows in order, and the 16 wave chunks tile rows and entries
+    for (int64_t bnd = 0; bnd < P.nbands(); ++bnd) {
+      if (!P.band_cd[(size_t)bnd]) continue;
+      for (int32_t gg = P.band_wg_ptr[(size_t)bnd]; gg < P.band_wg_ptr[(size_t)bnd + 1]; ++gg)
+        for (int32_t c = P.wg_grp_ptr[(size_t)gg]; c < P.wg_grp_ptr[(size_t)gg + 1]; ++c) {
+          const int32_t *dsc = &P.cd_desc[(size_t)c * kCdDescWords];
+          const int32_t s0 = dsc[0], nb = dsc[1], mid0 = dsc[2], nmid = dsc[3];
+          int64_t off;
+          std::memcpy(&off, &dsc[4], 8);
+          const uint8_t *wrow = reinterpret_cast<const uint8_t *>(&dsc[6]);
+          const uint16_t *wmid = reinterpret_cast<const uint16_t *>(&dsc[11]);
+          if (s0 != P.grp_slot_ptr[(size_t)c] || nb != P.grp_slot_ptr[(size_t)c + 1] - s0 || off != P.grp_inv_off[(size_t)c]) ++bad;
+          if (wrow[0] != 0 || wrow[16] != nb || wmid[0] != 0 || wmid[16] != nmid) ++bad;
+          int32_t e = mid0;
+          for (int w = 0; w < 16; ++w) {
+            if (wrow[w + 1] < wrow[w] || wrow[w + 1] - wrow[w] > 64 || wmid[w] != e - mid0) ++bad;
+            for (int32_t r = wrow[w]; r < wrow[w + 1]; ++r)
+              for (int32_t k = P.split[(size_t)(s0 + r)]; k < P.csplit[(size_t)(s0 + r)]; ++k, ++e)
+                if (e >= mid0 + nmid || P.mid_k[(size_t)e] != k || P.mid_lrow[(size_t)e] != r) ++bad;
+          }
+          if (e != mid0 + nmid) ++bad;
+        }
+    }
     int64_t ncd = 0, ncomp = 0, maxcomp = 0;
     for (int64_t bnd = 0; bnd < P.nbands(); ++bnd) {
       if (!P.band_cd[(size_t)bnd] && !P.band_dense[(size_t)bnd]) {
