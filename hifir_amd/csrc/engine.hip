@@ -143,7 +143,7 @@ struct DevCsr {
   DevBuf srcslot, split, wg_grp_ptr, grp_slot_ptr;
   DevBuf wg_slot;  // first slot of every workgroup (+ end): grp_slot_ptr[wg_grp_ptr[g]], one load level less at kernel start
   DevBuf csplit, grp_inv_off, cd_desc, mid_col, mid_val, mid_lrow;  // component-dense bands (host.hpp plan_bands_cd)
-  std::vector<int32_t> band_wg_ptr, band_slot_ptr;
+  std::vector<int32_t> band_wg_ptr, band_slot_ptr, host_wg_grp_ptr;
   std::vector<uint8_t> band_prefix, band_dense, band_fused, band_cd, band_old;
   std::vector<int32_t> band_blk_ptr, blk_slot0, blk_slot1;
   std::vector<int64_t> blk_inv_off;
@@ -170,6 +170,7 @@ struct DevCsr {
     mid_lrow.alias(o.mid_lrow);
     band_cd = o.band_cd;
     band_old = o.band_old;
+    host_wg_grp_ptr = o.host_wg_grp_ptr;
     tinv.alias(o.tinv);
     band_wg_ptr = o.band_wg_ptr;
     band_slot_ptr = o.band_slot_ptr;
@@ -213,6 +214,7 @@ struct DevCsr {
       }
       band_cd = P->band_cd;
       band_old = P->band_old;
+      host_wg_grp_ptr = P->wg_grp_ptr;
       band_wg_ptr = P->band_wg_ptr;
       band_prefix = P->band_prefix;
       band_fused = P->band_fused;
@@ -234,6 +236,10 @@ struct DevLevel {
   DevCsr L, U, E, F;
   DevBuf d, s, t, p, qinv;
   DevBuf w, v;  // arena: n * Rmax each
+  // combined top operator G = U_TT^{-1} D_T^{-1} L_TT^{-1} (host.hpp choose_top / build_top_operator), MFMA operand
+  DevBuf topG;
+  int64_t top_n = 0;
+  int32_t top_bandL = -1, top_bandU = -1;
   DevBuf q, pinv;        // product only (prec_prod.hpp:76,132), uploaded with the product buffers
   DevBuf pg, pc, pr;     // product only: permuted input, child product / D(U+I)g, result rows
 };
@@ -308,6 +314,7 @@ class Engine : public EngineBase {
   bool use_graph = true;
   int min_logR = 6;
   int gemm_waves = 16;   // split-K width of the block-inverse GEMM
+  int cd_dbg = 0;        // development aid (HIFIR_AMD_CD_DBG): phases of k_band_cd switched off for timing experiments
   int band_pipe = 1;     // 1: k_trsv_band_p (next row's head behind the last gathers), 0: k_trsv_band at R = 64 too
   BandOptions band_opt;  // how triangles are cut into bands (host.hpp)
   DevBuf errflag;        // sticky error word: a bounded spin of k_trsv_band expired
@@ -332,6 +339,7 @@ class Engine : public EngineBase {
     min_logR = std::min(6, std::max(0, env_int("HIFIR_AMD_MIN_LOGR", 6)));
     gemm_waves = env_int("HIFIR_AMD_GEMM_WAVES", 16);
     band_pipe = env_int("HIFIR_AMD_BAND_PIPE", 1);
+    cd_dbg = env_int("HIFIR_AMD_CD_DBG", 0);
     use_twin = env_int("HIFIR_AMD_TWIN", 1);
     band_opt.thin_rows = env_int("HIFIR_AMD_THIN_ROWS", 96);
     band_opt.band_depth = env_int("HIFIR_AMD_BAND_DEPTH", 32);
@@ -346,6 +354,8 @@ class Engine : public EngineBase {
     band_opt.fuse_max_wgs = env_int("HIFIR_AMD_BAND_FUSE_WGS", 512);
     // component-dense bands (host.hpp plan_bands_cd): real data, fast mode; HIFIR_AMD_CD_ROWS=0 keeps the depth-cut bands
     band_opt.cd_rows = (sizeof(T) == sizeof(double) && band_opt.dense_block > 0) ? env_int("HIFIR_AMD_CD_ROWS", 128) : 0;
+    band_opt.top_max = env_int("HIFIR_AMD_TOP_ROWS", 4096);      // combined top operator (host.hpp choose_top); 0 = off
+    band_opt.top_few_wgs = env_int("HIFIR_AMD_TOP_WGS", 96);
     if (band_opt.cd_rows > 240) band_opt.cd_rows = 240;  // (local row ids are bytes; 120 KB of the CU's 160 KB LDS)
   }
 
@@ -358,7 +368,7 @@ class Engine : public EngineBase {
     HIP_OK(hipSetDevice(device));
     if (!stream) HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (sizeof(T) == sizeof(double) && band_opt.cd_rows > 0) {  // k_band_cd keeps a component in up to 128 KB of LDS
-      const int lds = (int)(band_opt.cd_rows * 64 * sizeof(double));
+      const int lds = (int)(band_opt.cd_rows * (64 * sizeof(double) + sizeof(int32_t)));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
@@ -491,6 +501,10 @@ class Engine : public EngineBase {
         L.U.alias(Pl->U);
         L.E.alias(Pl->E);
         L.F.alias(Pl->F);
+        L.topG.alias(Pl->topG);
+        L.top_n = Pl->top_n;
+        L.top_bandL = Pl->top_bandL;
+        L.top_bandU = Pl->top_bandU;
         L.d.alias(Pl->d);
         L.s.alias(Pl->s);
         L.t.alias(Pl->t);
@@ -641,6 +655,7 @@ class Engine : public EngineBase {
     }
   }
   size_t pin_cap = 0;
+  int64_t top_rows_max = 0;  // rows of the largest combined top operator (sizes blk_tmp)
   double *pin[2] = {nullptr, nullptr};
   hipEvent_t pin_done[2] = {nullptr, nullptr};
   uint64_t pin_next = 0;
@@ -669,6 +684,20 @@ class Engine : public EngineBase {
       L.E_void = H.E_void;
       ship_block_inverses(H.Lp, H.Lr, H.Ltinv_elems, L.L);
       ship_block_inverses(H.Up, H.Ur, H.Utinv_elems, L.U);
+      if (H.top_n > 0 && H.Lp.band_dense[(size_t)H.top_bandL] && H.Up.band_dense[(size_t)H.top_bandU]) {
+        // (a top band whose block inverses grew too much has lost its dense flag: then the bands run one by one)
+        const int32_t r0L = H.Lp.grp_slot_ptr[(size_t)H.Lp.wg_grp_ptr[(size_t)H.Lp.band_wg_ptr[(size_t)H.top_bandL]]];
+        const int32_t r0U = H.Up.grp_slot_ptr[(size_t)H.Up.wg_grp_ptr[(size_t)H.Up.band_wg_ptr[(size_t)H.top_bandU]]];
+        std::vector<T> G;
+        const double growth = build_top_operator(H.Lr, H.Lp, r0L, H.Ur, H.Up, r0U, H.top_n, H.d, G);
+        if (growth <= band_opt.dense_max_growth) {
+          L.topG.upload(mfma_operand(G.data(), H.top_n, H.top_n));
+          L.top_n = H.top_n;
+          L.top_bandL = H.top_bandL;
+          L.top_bandU = H.top_bandU;
+          top_rows_max = std::max(top_rows_max, H.top_n);
+        }
+      }
       L.E.upload(H.Er, nullptr);
       L.F.upload(H.Fr, nullptr);
       L.d.upload(H.d);
@@ -739,7 +768,7 @@ class Engine : public EngineBase {
       HIP_OK(hipStreamSynchronize(xfer_stream()));
     }
     if (band_opt.dense_block > 0) {  // +32 rows: the MFMA kernel reads whole 32-k operand sets (masked)
-      blk_tmp.alloc((size_t)(band_opt.dense_block + 32) * Rmax * sizeof(T));
+      blk_tmp.alloc((size_t)(std::max<int64_t>(band_opt.dense_block, top_rows_max) + 32) * Rmax * sizeof(T));
       zero_dev(blk_tmp.p, blk_tmp.bytes);
     }
     HIP_OK(hipStreamSynchronize(stream));  // (transfers were synchronous on the transfer stream)
@@ -829,8 +858,14 @@ class Engine : public EngineBase {
     if (M.nrows == 0) return;
     D *w = L.w.as<D>(), *v = L.v.as<D>();
     const size_t nb = M.band_wg_ptr.size() - 1;
+    const bool top = L.top_n > 0 && logR == 6;  // the level's narrow top is ONE dense product (launch_top)
     bool carried = false;  // the previous band's launch ran this band's carried prefix (host.hpp finish_band_plan)
     for (size_t b = 0; b < nb; ++b) {
+      if (top && (int32_t)b == (LOWER ? L.top_bandL : L.top_bandU)) {
+        if (LOWER) launch_top(st, L, logR, count);  // (U's top band: already solved by that product)
+        carried = false;
+        continue;
+      }
       const int32_t g0 = M.band_wg_ptr[b], g1 = M.band_wg_ptr[b + 1];
       const bool fused = !M.band_fused.empty() && M.band_fused[b];
       const bool have_carried = carried;
@@ -901,18 +936,44 @@ class Engine : public EngineBase {
   template <bool LOWER>
   void launch_dense_block(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t q, int logR, int64_t &count,
                           bool rhs_ready = false);
+  // the level's top rows: t_T = w_T - (sources outside T) by the chip-wide prefix pass, straight into the product's
+  // right-hand side; then v_T = G t_T on the matrix cores (G = U_TT^{-1} D_T^{-1} L_TT^{-1}, rows scattered by L's row ids)
+  void launch_top(hipStream_t st, const DevLevel &L, int logR, int64_t &count) {
+    if constexpr (std::is_same<T, double>::value) {
+      const DevCsr &M = L.L;
+      const size_t b = (size_t)L.top_bandL;
+      const int64_t s0 = M.band_slot_ptr[b], s1 = M.band_slot_ptr[b + 1];
+      const int nt = (int)L.top_n;
+      hipLaunchKernelGGL((k_trsv_wide<double, true, true>), dim3(grid_for(s1 - s0, logR)), dim3(256), 0, st, s0, s1,
+                         M.ptr.as<int32_t>(), M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<double>(),
+                         M.rowid.as<int32_t>(), L.d.as<double>(), L.w.as<double>(), L.v.as<double>(), logR, 1,
+                         blk_tmp.as<double>(), (int32_t)s1);
+      hipLaunchKernelGGL(k_dense_gemm_d<4>, dim3((unsigned)((nt + 15) / 16), ((1u << logR) + 15) / 16), dim3(256), 0, st, nt, nt,
+                         nt, 0, L.topG.as<double>(), nt, (const double *)blk_tmp.as<double>(), logR,
+                         M.rowid.as<int32_t>() + s0, L.v.as<double>(), (const double *)nullptr, (double *)nullptr);
+      count += 2;
+    } else {
+      (void)st, (void)L, (void)logR, (void)count;
+      throw Error(HIFAMD_HIFIR_ERROR, "internal error: combined top operator on a complex handle");
+    }
+  }
   // one component-dense band (kernels.hip.hpp k_band_cd): real data, R = 64
   template <bool LOWER>
   void launch_band_cd(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t g0, int32_t g1, int pre, int32_t ps0,
                       int32_t ps1, unsigned extra) {
     if constexpr (std::is_same<T, double>::value) {
-      const size_t lds = (size_t)band_opt.cd_rows * 64 * sizeof(double);  // (the attribute for > 64 KB is set in bind_device)
+      // LDS: the component's right-hand sides + its row ids (the attribute for > 64 KB is set in bind_device)
+      const size_t lds = (size_t)band_opt.cd_rows * (64 * sizeof(double) + sizeof(int32_t));
+      // one component per workgroup (the usual case): the kernel derives the component from blockIdx
+      const int32_t c0 = M.host_wg_grp_ptr[(size_t)g0], c1 = M.host_wg_grp_ptr[(size_t)g1];
+      const int32_t single_c0 = (c1 - c0 == g1 - g0) ? c0 : -1;
       (void)pre;  // (the packed streams already start at split[] for a carried band, at ptr[] otherwise)
       hipLaunchKernelGGL((k_band_cd<LOWER>), dim3((unsigned)(g1 - g0) + extra), dim3(1024), lds, st, g0,
                          M.wg_grp_ptr.as<int32_t>(), M.cd_desc.as<int32_t>(), M.ptr.as<int32_t>(), M.split.as<int32_t>(),
                          M.col.as<int32_t>(), M.val.as<double>(), M.rowid.as<int32_t>(), L.d.as<double>(), L.w.as<double>(),
                          L.v.as<double>(), M.tinv.as<double>(), M.mid_col.as<int32_t>(), M.mid_val.as<double>(),
-                         M.mid_lrow.as<uint8_t>(), pre ? 0 : 1, (int32_t)(g1 - g0), ps0, ps1);
+                         M.mid_lrow.as<uint8_t>(), pre ? 0 : 1, (int32_t)(g1 - g0), ps0, ps1, single_c0,
+                         (int32_t)band_opt.cd_rows, cd_dbg);
     } else {
       (void)st, (void)L, (void)M, (void)g0, (void)g1, (void)pre, (void)ps0, (void)ps1, (void)extra;
       throw Error(HIFAMD_HIFIR_ERROR, "internal error: component-dense band on a complex handle");

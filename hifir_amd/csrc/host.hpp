@@ -297,6 +297,8 @@ struct BandOptions {
   int64_t dense_min_rows = 96;   // thin bands shorter than this stay on the sequential workgroup
   int64_t cd_rows = 192;         // component-dense bands: rows per component (LDS-resident; 0 = scheme off)
   double cd_min_row_nnz = 4.0;   // ... only for triangles with at least this many nonzeros per row on average
+  int64_t top_max = 4096;        // combined top operator (choose_top): at most this many rows (0 = off)
+  int64_t top_few_wgs = 96;      // ... made of the last bands of L's plan that have at most this many workgroups
   double dense_max_growth = 1e4; // ... and so do bands whose block inverses grow beyond this
 };
 
@@ -511,7 +513,8 @@ BandPlan plan_bands(const Csr<T> &A, const Schedule &S, bool lower, const BandOp
 // reverse order: a row's sources lie in the same component or in a pass that ran earlier.
 // ---------------------------------------------------------------------------------------------
 template <class T>
-BandPlan plan_bands_cd(const Csr<T> &A, const Schedule &S, bool lower, const BandOptions &opt) {
+BandPlan plan_bands_cd(const Csr<T> &A, const Schedule &S, bool lower, const BandOptions &opt,
+                       const std::vector<uint8_t> *top = nullptr) {
   BandPlan P;
   const int64_t m = A.nrows;
   std::vector<int32_t> depth((size_t)m);
@@ -537,6 +540,16 @@ BandPlan plan_bands_cd(const Csr<T> &A, const Schedule &S, bool lower, const Ban
     remaining = S.order;
   else
     for (int64_t i = 0; i < m; ++i) remaining[(size_t)i] = (int32_t)i;
+  // a forced TOP set (choose_top): those rows are never planned into passes; they form the rest band, whatever its
+  // size, and the passes run until every other row is placed.  The set is closed (nothing outside it needs... see
+  // choose_top), so no planned row ever waits for a top row in the planning graph.
+  std::vector<int32_t> top_rows;
+  if (top) {
+    std::vector<int32_t> keep;
+    keep.reserve(remaining.size());
+    for (int32_t i : remaining) ((*top)[(size_t)i] ? top_rows : keep).push_back(i);
+    remaining.swap(keep);
+  }
   std::vector<int32_t> pass((size_t)m, -1), parent((size_t)m), crows((size_t)m);
   std::vector<uint8_t> deferred((size_t)m, 0);
   auto find = [&](int32_t x) {
@@ -550,7 +563,7 @@ BandPlan plan_bands_cd(const Csr<T> &A, const Schedule &S, bool lower, const Ban
   std::vector<std::vector<int32_t>> pass_rows;                           // rows of every pass, visiting order
   std::vector<int32_t> roots;
   int32_t np = 0;
-  while (!remaining.empty() && (int64_t)remaining.size() > rest_rows) {
+  while (!remaining.empty() && (top || (int64_t)remaining.size() > rest_rows)) {
     next.clear();
     std::vector<int32_t> mine;
     for (int32_t i : remaining) {
@@ -562,6 +575,7 @@ BandPlan plan_bands_cd(const Csr<T> &A, const Schedule &S, bool lower, const Ban
       for (int32_t k = nptr[i]; k < nptr[i + 1] && !dfr; ++k) {
         const int32_t j = ncol[k];
         if (pass[(size_t)j] >= 0 && pass[(size_t)j] < np) continue;  // finished in an earlier pass
+        if (top && (*top)[(size_t)j]) throw Error(4, "internal error: the top set is not closed");
         if (deferred[(size_t)j]) {
           dfr = true;
           break;
@@ -590,11 +604,12 @@ BandPlan plan_bands_cd(const Csr<T> &A, const Schedule &S, bool lower, const Ban
     pass_rows.push_back(std::move(mine));
     ++np;
     remaining.swap(next);
-    if (degenerate && opt.dense_block > 0) break;
+    if (degenerate && opt.dense_block > 0 && !top) break;
   }
   if (!remaining.empty() && opt.dense_block <= 0) {  // no dense chain available (cannot happen: cd needs dense_block > 0)
     throw Error(4, "internal error: component-dense plan without the dense block chain");
   }
+  if (top) remaining = top_rows;  // (the rest band IS the top set)
   // ---- emit bands in EXECUTION order: lower: pass 0, 1, ..., rest;  upper: rest, pass np-1, ..., 0
   P.grp_slot_ptr.push_back(0);
   P.wg_grp_ptr.push_back(0);
@@ -1018,6 +1033,130 @@ void finish_band_plan(BandPlan &P, Csr<T> &A /* rows in slot order */, const Ban
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The narrow top of a level.  L's solve ENDS in the top of the elimination forest and U's BEGINS there: a handful of
+// poorly parallel passes plus the dense rest band on either side -- about ten launches that keep a few compute units
+// busy.  For a set T of rows that is closed under both triangles (every row that reads a T row in L is in T; every row a
+// T row reads in U is in T) the three steps collapse into ONE dense product
+//     z_T = U_TT^{-1} D_T^{-1} L_TT^{-1} (w_T - L_TC x_C) = G t_T ,
+// after which U continues with the rows outside T.  choose_top takes the last bands of a first plan of L (whole bands,
+// hence closed in L) up to top_max rows and closes the set under U and L; it gives up (empty result) when the closure
+// outgrows top_max -- for the (structurally symmetric) factors of a PDE hierarchy nothing has to be added.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+std::vector<uint8_t> choose_top(const Csr<T> &Lr, const Csr<T> &Ur, const BandPlan &Lp0, int64_t top_max, int64_t few_wgs) {
+  const int64_t m = Lr.nrows, nb = Lp0.nbands();
+  std::vector<uint8_t> top;
+  if (m == 0 || nb < 2 || top_max <= 0) return top;
+  auto band_slot = [&](int64_t b) { return Lp0.grp_slot_ptr[(size_t)Lp0.wg_grp_ptr[(size_t)Lp0.band_wg_ptr[(size_t)b]]]; };
+  // last bands of L's plan while they are narrow and fit
+  int64_t b0 = nb;
+  while (b0 > 1) {
+    const int64_t cand = b0 - 1;
+    const int64_t rows_after = m - band_slot(cand);
+    const int64_t wgs = Lp0.band_wg_ptr[(size_t)cand + 1] - Lp0.band_wg_ptr[(size_t)cand];
+    if (rows_after > top_max || (wgs > few_wgs && !Lp0.band_dense[(size_t)cand])) break;
+    b0 = cand;
+  }
+  if (b0 >= nb) return top;
+  top.assign((size_t)m, 0);
+  std::vector<int32_t> work;
+  int64_t cnt = 0;
+  for (int64_t s = band_slot(b0); s < m; ++s) top[(size_t)Lp0.order[(size_t)s]] = 1, work.push_back(Lp0.order[(size_t)s]), ++cnt;
+  // closure: U-sources of T rows join T; so do the rows that read a T row in L (L's columns = transposed pattern)
+  std::vector<int32_t> tptr((size_t)m + 1, 0), tcol(Lr.col.size());
+  for (size_t k = 0; k < Lr.col.size(); ++k) ++tptr[(size_t)Lr.col[k] + 1];
+  for (int64_t i = 0; i < m; ++i) tptr[(size_t)i + 1] += tptr[(size_t)i];
+  {
+    std::vector<int32_t> fill(tptr.begin(), tptr.end() - 1);
+    for (int64_t i = 0; i < m; ++i)
+      for (int32_t k = Lr.ptr[(size_t)i]; k < Lr.ptr[(size_t)i + 1]; ++k) tcol[(size_t)fill[(size_t)Lr.col[(size_t)k]]++] = (int32_t)i;
+  }
+  while (!work.empty()) {
+    const int32_t i = work.back();
+    work.pop_back();
+    auto add = [&](int32_t j) {
+      if (!top[(size_t)j]) top[(size_t)j] = 1, work.push_back(j), ++cnt;
+    };
+    for (int32_t k = Ur.ptr[(size_t)i]; k < Ur.ptr[(size_t)i + 1]; ++k) add(Ur.col[(size_t)k]);  // what i reads in U
+    for (int32_t k = tptr[(size_t)i]; k < tptr[(size_t)i + 1]; ++k) add(tcol[(size_t)k]);          // who reads i in L
+    if (cnt > top_max) return std::vector<uint8_t>();
+  }
+  return top;
+}
+
+// G = U_TT^{-1} D_T^{-1} L_TT^{-1}, column-major |T| x |T|, rows and columns in the slot order of L's top band
+// [r0L, r0L + nt).  Lr / Ur: the slot-ordered triangles after finish_band_plan (per-nonzero source slots in the plans);
+// U's top band is [r0U, r0U + nt).  Returns the largest |entry| (growth check, like the block inverses).
+template <class T>
+double build_top_operator(const Csr<T> &Lr, const BandPlan &Lp, int32_t r0L, const Csr<T> &Ur, const BandPlan &Up, int32_t r0U,
+                          int64_t nt, const std::vector<T> &d, std::vector<T> &G) {
+  G.assign((size_t)(nt * nt), T(0));
+  // U-local index of every L-local row (same row set, two slot orders)
+  std::vector<int32_t> u_of_row((size_t)Lr.nrows, -1), l2u((size_t)nt), u2l((size_t)nt);
+  for (int64_t r = 0; r < nt; ++r) u_of_row[(size_t)Ur.rowid[(size_t)(r0U + r)]] = (int32_t)r;
+  for (int64_t r = 0; r < nt; ++r) {
+    const int32_t u = u_of_row[(size_t)Lr.rowid[(size_t)(r0L + r)]];
+    if (u < 0) throw Error(4, "internal error: the top bands of L and U hold different rows");
+    l2u[(size_t)r] = u;
+    u2l[(size_t)u] = (int32_t)r;
+  }
+  double growth = 0.0;
+  std::mutex gmx;
+  constexpr int64_t CB = 16;  // columns side by side: every update is a contiguous axpy
+  parallel_for((nt + CB - 1) / CB, 1, [&](int64_t cb0, int64_t cb1) {
+    std::vector<T> Y((size_t)(nt * CB)), Z((size_t)(nt * CB));
+    double g = 0.0;
+    for (int64_t cb = cb0; cb < cb1; ++cb) {
+      const int64_t c0 = cb * CB, cw = std::min<int64_t>(CB, nt - c0);
+      std::fill(Y.begin(), Y.end(), T(0));
+      for (int64_t j = 0; j < cw; ++j) Y[(size_t)((c0 + j) * CB + j)] = T(1);
+      // forward: L_TT y = e (unit diagonal), L slot order; rows before c0 stay zero
+      for (int64_t r = c0; r < nt; ++r) {
+        T *yr = &Y[(size_t)(r * CB)];
+        const int32_t s = r0L + (int32_t)r;
+        for (int32_t k = Lr.ptr[(size_t)s]; k < Lr.ptr[(size_t)s + 1]; ++k) {
+          const int32_t q = Lp.srcslot[(size_t)k] - r0L;
+          if (q < c0) continue;  // (outside T, or a row that is still zero)
+          const T a = Lr.val[(size_t)k];
+          const T *yq = &Y[(size_t)((int64_t)q * CB)];
+          for (int64_t j = 0; j < CB; ++j) yr[j] -= a * yq[j];
+        }
+      }
+      // scale by D^{-1} and move to U's order
+      for (int64_t r = 0; r < nt; ++r) {
+        const T dr = d[(size_t)Lr.rowid[(size_t)(r0L + r)]];
+        T *zr = &Z[(size_t)((int64_t)l2u[(size_t)r] * CB)];
+        const T *yr = &Y[(size_t)(r * CB)];
+        for (int64_t j = 0; j < CB; ++j) zr[j] = yr[j] / dr;
+      }
+      // backward: U_TT z = y (unit diagonal), U slot order (its own dependency order)
+      for (int64_t r = 0; r < nt; ++r) {
+        T *zr = &Z[(size_t)(r * CB)];
+        const int32_t s = r0U + (int32_t)r;
+        for (int32_t k = Ur.ptr[(size_t)s]; k < Ur.ptr[(size_t)s + 1]; ++k) {
+          const int32_t q = Up.srcslot[(size_t)k] - r0U;
+          if (q < 0 || q >= nt) throw Error(4, "internal error: a top row of U reads a row outside the top set");
+          const T a = Ur.val[(size_t)k];
+          const T *zq = &Z[(size_t)((int64_t)q * CB)];
+          for (int64_t j = 0; j < CB; ++j) zr[j] -= a * zq[j];
+        }
+      }
+      for (int64_t u = 0; u < nt; ++u) {
+        const int64_t r = u2l[(size_t)u];
+        for (int64_t j = 0; j < cw; ++j) {
+          const T val = Z[(size_t)(u * CB + j)];
+          G[(size_t)(r + (c0 + j) * nt)] = val;
+          g = std::max(g, abs_(val));
+        }
+      }
+    }
+    std::lock_guard<std::mutex> lk(gmx);
+    growth = std::max(growth, g);
+  });
+  return growth;
+}
+
 // Physically permute the CSR rows into slot order so that the matrix streams through HBM in the
 // order the kernels consume it (coalesced index/value reads for every batch width).
 template <class T>
@@ -1058,6 +1197,11 @@ struct HostLevel {
   Schedule Ls, Us;   // plain level schedules (wavefronts), kept for queries
   BandPlan Lp, Up;   // what the device executes
   int64_t Ltinv_elems = 0, Utinv_elems = 0;  // doubles of block-inverse operands (built and shipped at finalize)
+  // Combined top operator (choose_top / build_top_operator): the rows of `top` -- the narrow top of the elimination
+  // forest, where L ends and U begins -- are solved by ONE dense product  z_T = U_TT^{-1} D_T^{-1} L_TT^{-1} t_T
+  std::vector<uint8_t> top;         // per row; empty = no combined operator
+  int64_t top_n = 0;                // |T|
+  int32_t top_bandL = -1, top_bandU = -1;  // the bands of Lp / Up that hold exactly the rows of T
 };
 
 // Dense last level: A P = Q R (GEQP3 semantics), numerical rank as QRCP::factorize decides it

@@ -98,8 +98,33 @@ void analyze_level(HostLevel<T> &H, const BandOptions &band_opt, bool dump = fal
     return band_opt.cd_rows > 0 && band_opt.dense_block > 0 && A.nrows > 0 &&
            (double)A.col.size() >= band_opt.cd_min_row_nnz * (double)A.nrows;
   };
-  H.Lp = use_cd(H.Lr) ? plan_bands_cd(H.Lr, H.Ls, true, band_opt) : plan_bands(H.Lr, H.Ls, true, band_opt);
-  H.Up = use_cd(H.Ur) ? plan_bands_cd(H.Ur, H.Us, false, band_opt) : plan_bands(H.Ur, H.Us, false, band_opt);
+  H.top.clear();
+  H.top_n = 0;
+  H.top_bandL = H.top_bandU = -1;
+  if (use_cd(H.Lr) && use_cd(H.Ur)) {
+    H.Lp = plan_bands_cd(H.Lr, H.Ls, true, band_opt);
+    // the narrow top of the level as ONE dense operator (host.hpp choose_top): replan both triangles around it
+    if (band_opt.top_max > 0) H.top = choose_top(H.Lr, H.Ur, H.Lp, band_opt.top_max, band_opt.top_few_wgs);
+    if (!H.top.empty()) {
+      H.Lp = plan_bands_cd(H.Lr, H.Ls, true, band_opt, &H.top);
+      H.Up = plan_bands_cd(H.Ur, H.Us, false, band_opt, &H.top);
+      for (uint8_t t : H.top) H.top_n += t;
+      H.top_bandL = (int32_t)H.Lp.nbands() - 1;  // lower: the rest band comes last; upper: first
+      H.top_bandU = 0;
+      if (H.top_n > band_opt.max_wg_rows) {  // (the rest would have been cut into several bands: no combined operator)
+        H.top.clear();
+        H.top_n = 0;
+        H.top_bandL = H.top_bandU = -1;
+        H.Lp = plan_bands_cd(H.Lr, H.Ls, true, band_opt);
+        H.Up = plan_bands_cd(H.Ur, H.Us, false, band_opt);
+      }
+    } else {
+      H.Up = plan_bands_cd(H.Ur, H.Us, false, band_opt);
+    }
+  } else {
+    H.Lp = use_cd(H.Lr) ? plan_bands_cd(H.Lr, H.Ls, true, band_opt) : plan_bands(H.Lr, H.Ls, true, band_opt);
+    H.Up = use_cd(H.Ur) ? plan_bands_cd(H.Ur, H.Us, false, band_opt) : plan_bands(H.Ur, H.Us, false, band_opt);
+  }
   double t2 = now();
   H.Lr = permute_rows(H.Lr, H.Lp.order);
   H.Ur = permute_rows(H.Ur, H.Up.order);

@@ -1456,12 +1456,14 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
                                                   const double *__restrict__ d, double *w, double *v,
                                                   const double *__restrict__ tinv, const int32_t *__restrict__ mid_col,
                                                   const double *__restrict__ mid_val, const uint8_t *__restrict__ mid_lrow,
-                                                  int first_u, int32_t n_band, int32_t ps0, int32_t ps1) {
-  extern __shared__ double cd_tbuf[];  // [cd_rows][64]
+                                                  int first_u, int32_t n_band, int32_t ps0, int32_t ps1, int32_t single_c0,
+                                                  int32_t lds_rows, int dbg) {
+  extern __shared__ double cd_tbuf[];  // [lds_rows][64] right-hand sides, then lds_rows row ids
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
   if ((int32_t)blockIdx.x >= n_band) {  // carried prefix of the next band over the sources older than this band
     const int32_t pw = __builtin_amdgcn_readfirstlane(((int32_t)blockIdx.x - n_band) * nw + wave);
+    if (dbg & 4) return;
     trsv_stream_r64<double, 0, LOWER, true>(ps0 + pw, ps1, ((int32_t)gridDim.x - n_band) * nw, ptr, split, col, val, nullptr,
                                             rowid, d, LOWER ? w : v, w, lane, nullptr, 0, nullptr, true);
     return;
@@ -1469,9 +1471,19 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
   double *x = LOWER ? w : v;
   const bool div_u = !LOWER && first_u;
   const double *rhs = div_u ? (const double *)w : (const double *)x;
-  const int g = wg0 + (int)blockIdx.x;
-  const int32_t c_first = wg_grp_ptr[g], c_last = wg_grp_ptr[g + 1];
+  // single_c0 >= 0: every workgroup of this band owns exactly ONE component, number single_c0 + blockIdx.x (saves the
+  // dependent load of the workgroup's group range)
+  int32_t c_first, c_last;
+  if (single_c0 >= 0) {
+    c_first = single_c0 + (int32_t)blockIdx.x;
+    c_last = c_first + 1;
+  } else {
+    const int g = wg0 + (int)blockIdx.x;
+    c_first = wg_grp_ptr[g];
+    c_last = wg_grp_ptr[g + 1];
+  }
   const int kq = lane >> 4;
+  int32_t *cd_rowid = reinterpret_cast<int32_t *>(cd_tbuf + (size_t)lds_rows * 64);  // the component's row ids, for phase 2
   for (int32_t c = c_first; c < c_last; ++c) {
     const int32_t *dsc = cd_desc + (int64_t)c * 20;
     const int32_t s0 = dsc[0], nb = dsc[1], mid0 = dsc[2];
@@ -1480,11 +1492,25 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
     const uint16_t *wmid = reinterpret_cast<const uint16_t *>(dsc + 11);
     const int r0 = wrow[wave], nr = (int)wrow[wave + 1] - r0;
     const int32_t e0 = mid0 + (int32_t)wmid[wave], e1 = mid0 + (int32_t)wmid[wave + 1];
+    // phase 2's first operand set is requested NOW: it does not depend on phase 1 and its latency hides behind it
+    const int lda = (nb + 31) & ~31;
+    const double *Ac = tinv + inv_off;
+    const int S = (nb + 15) >> 4, nunits = S * 2;
+    const int wrow4 = wave >> 2, wcol4 = wave & 3;
+    const int q_first = wrow4 * 4 + ((wrow4 & 1) ? 3 - wcol4 : wcol4);  // snake order over the SIMDs (wave % 4)
+    constexpr int KU = 8;
+    double a0[KU], a1[KU];
+    if (q_first < nunits) {
+      const double *ap_ = Ac + ((int64_t)(S - 1 - (q_first >> 1)) * lda) * 16 + (lane & 15) + (int64_t)kq * 16;
+#pragma unroll
+      for (int u = 0; u < KU; ++u) a0[u] = ap_[u * 64];
+    }
     // ---- phase 1a: right-hand sides of this wave's rows into LDS (row ids one per lane, eight loads in flight)
     int32_t h_i = 0;
     double h_d = 1.0;
     if (lane < nr) {
       h_i = rowid[s0 + r0 + lane];
+      cd_rowid[r0 + lane] = h_i;
       if (div_u) h_d = d[h_i];
     }
     // first item of the wave's entry stream: requested before the right-hand sides are waited for
@@ -1509,7 +1535,7 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
     // ---- phase 1b: the wave's entries, items of 64, eight gathers per batch; the running row's sum stays in a register
     int cur_r = -1;
     double acc = 0.0;
-    for (int32_t e = e0; e < e1; e += 64) {
+    for (int32_t e = e0; e < ((dbg & 1) ? e0 : e1); e += 64) {
       const int cnt = min(64, e1 - e);
       int32_t colv2 = 0, lrv2 = 0;
       double valv2 = 0.0;
@@ -1548,21 +1574,14 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
     }
     if (cur_r >= 0) cd_tbuf[(cur_r << 6) + lane] = acc;
     __syncthreads();
-    // ---- phase 2: x = Tinv * t
-    const int lda = (nb + 31) & ~31;
-    const double *Ac = tinv + inv_off;
-    const int S = (nb + 15) >> 4, nunits = S * 2;
-    // snake order over the SIMDs (wave % 4): units are handed out heaviest first
-    const int wrow4 = wave >> 2, wcol4 = wave & 3;
-    for (int q = wrow4 * 4 + ((wrow4 & 1) ? 3 - wcol4 : wcol4); q < nunits; q += nw) {
+    // ---- phase 2: x = Tinv * t (units are handed out heaviest first)
+    for (int q = q_first; q < ((dbg & 2) ? 0 : nunits); q += nw) {
       const int strip = S - 1 - (q >> 1), ch = q & 1;
       const int kend = min(nb, 16 * (strip + 1));
       const int nsets = (kend + 31) >> 5;
       const double *Ap = Ac + ((int64_t)strip * lda) * 16 + (lane & 15);
       const double *Bp = cd_tbuf + ch * 32 + (lane & 15);
       v4f64 acc0 = v4f64{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
-      constexpr int KU = 8;
-      double a0[KU], a1[KU];
 #define HIFAMD_CD_LOAD(aa, t_)                                          \
   {                                                                     \
     const double *ap_ = Ap + (int64_t)(32 * (t_) + kq) * 16;            \
@@ -1580,7 +1599,7 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
     }                                                                             \
   }
       int t = 0;
-      HIFAMD_CD_LOAD(a0, 0)
+      if (q != q_first) HIFAMD_CD_LOAD(a0, 0)  // (the first unit's first set was requested before phase 1)
       while (t < nsets) {
         if (t + 1 < nsets) HIFAMD_CD_LOAD(a1, t + 1)
         HIFAMD_CD_MFMA(a0, t)
@@ -1595,7 +1614,7 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * strip + kq + 4 * r;
         if (row < nb) {
-          double *xo = x + ((int64_t)rowid[s0 + row] << 6) + ch * 32 + (lane & 15);
+          double *xo = x + ((int64_t)cd_rowid[row] << 6) + ch * 32 + (lane & 15);
           xo[0] = acc0[r];
           xo[16] = acc1[r];
         }
