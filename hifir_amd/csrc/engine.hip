@@ -314,6 +314,7 @@ class Engine : public EngineBase {
   bool use_graph = true;
   int min_logR = 6;
   int gemm_waves = 16;   // split-K width of the block-inverse GEMM
+  bool fuse_gather = true;  // S1 fused into the L solve (HIFIR_AMD_FUSE_S1=0: separate k_gather_scale launches)
   int cd_dbg = 0;        // development aid (HIFIR_AMD_CD_DBG): phases of k_band_cd switched off for timing experiments
   int band_pipe = 1;     // 1: k_trsv_band_p (next row's head behind the last gathers), 0: k_trsv_band at R = 64 too
   BandOptions band_opt;  // how triangles are cut into bands (host.hpp)
@@ -340,6 +341,7 @@ class Engine : public EngineBase {
     gemm_waves = env_int("HIFIR_AMD_GEMM_WAVES", 16);
     band_pipe = env_int("HIFIR_AMD_BAND_PIPE", 1);
     cd_dbg = env_int("HIFIR_AMD_CD_DBG", 0);
+    fuse_gather = env_int("HIFIR_AMD_FUSE_S1", 1) != 0;
     use_twin = env_int("HIFIR_AMD_TWIN", 1);
     band_opt.thin_rows = env_int("HIFIR_AMD_THIN_ROWS", 96);
     band_opt.band_depth = env_int("HIFIR_AMD_BAND_DEPTH", 32);
@@ -354,6 +356,7 @@ class Engine : public EngineBase {
     band_opt.fuse_max_wgs = env_int("HIFIR_AMD_BAND_FUSE_WGS", 512);
     // component-dense bands (host.hpp plan_bands_cd): real data, fast mode; HIFIR_AMD_CD_ROWS=0 keeps the depth-cut bands
     band_opt.cd_rows = (sizeof(T) == sizeof(double) && band_opt.dense_block > 0) ? env_int("HIFIR_AMD_CD_ROWS", 128) : 0;
+    band_opt.cd_max_nnz = env_int("HIFIR_AMD_CD_NNZ", 0);
     band_opt.top_max = env_int("HIFIR_AMD_TOP_ROWS", 4096);      // combined top operator (host.hpp choose_top); 0 = off
     band_opt.top_few_wgs = env_int("HIFIR_AMD_TOP_WGS", 96);
     if (band_opt.cd_rows > 240) band_opt.cd_rows = 240;  // (local row ids are bytes; 120 KB of the CU's 160 KB LDS)
@@ -440,6 +443,7 @@ class Engine : public EngineBase {
       E->min_logR = min_logR;
       E->band_opt = band_opt;
       E->gemm_waves = gemm_waves;
+      E->fuse_gather = fuse_gather;
       for (const auto &P : host.levels) E->add_level_adjoint(P);
       if (host.has_dense && host.dense.kind == 2) {  // LUP: ?getrs 'T' / ?gemv 'C' (LUP.hpp:150,187)
         E->host.dense.kind = 2;
@@ -486,6 +490,7 @@ class Engine : public EngineBase {
       E->min_logR = min_logR;
       E->band_opt = band_opt;
       E->gemm_waves = gemm_waves;
+      E->fuse_gather = fuse_gather;
       E->max_nrhs = max_nrhs;
       E->Rmax = Rmax;
       E->host.has_dense = host.has_dense;
@@ -691,7 +696,7 @@ class Engine : public EngineBase {
         std::vector<T> G;
         const double growth = build_top_operator(H.Lr, H.Lp, r0L, H.Ur, H.Up, r0U, H.top_n, H.d, G);
         if (growth <= band_opt.dense_max_growth) {
-          L.topG.upload(mfma_operand(G.data(), H.top_n, H.top_n));
+          L.topG.upload(mfma_operand(G.data(), H.top_n, H.top_n, round_up32(H.top_n)));  // (k zero-padded to 32)
           L.top_n = H.top_n;
           L.top_bandL = H.top_bandL;
           L.top_bandU = H.top_bandU;
@@ -852,17 +857,21 @@ class Engine : public EngineBase {
 
   // One triangle = its bands in order (host.hpp BandPlan): an optional PREFIX pass on the whole
   // chip, then ONE launch whose workgroups each own whole dependency components of the band.
+  typedef FirstL<D> FL;
+  static FL no_fl() { return FL{IoPtr<const D>{nullptr, nullptr, 0}, 0, 0, nullptr, nullptr}; }
+  // flp != NULL: S1 is fused into this L solve -- whichever kernel touches a row first reads s[p] * b[p] (kernels FirstL)
   template <bool LOWER>
-  void launch_trsv(hipStream_t st, const DevLevel &L, int logR, int64_t &count) {
+  void launch_trsv(hipStream_t st, const DevLevel &L, int logR, int64_t &count, const FL *flp = nullptr) {
     const DevCsr &M = LOWER ? L.L : L.U;
     if (M.nrows == 0) return;
+    const FL fl = (LOWER && flp) ? *flp : no_fl();
     D *w = L.w.as<D>(), *v = L.v.as<D>();
     const size_t nb = M.band_wg_ptr.size() - 1;
     const bool top = L.top_n > 0 && logR == 6;  // the level's narrow top is ONE dense product (launch_top)
     bool carried = false;  // the previous band's launch ran this band's carried prefix (host.hpp finish_band_plan)
     for (size_t b = 0; b < nb; ++b) {
       if (top && (int32_t)b == (LOWER ? L.top_bandL : L.top_bandU)) {
-        if (LOWER) launch_top(st, L, logR, count);  // (U's top band: already solved by that product)
+        if (LOWER) launch_top(st, L, logR, count, fl);  // (U's top band: already solved by that product)
         carried = false;
         continue;
       }
@@ -884,7 +893,7 @@ class Engine : public EngineBase {
         hipLaunchKernelGGL((k_trsv_wide<D, LOWER, true>), dim3(grid_for(s1 - s0, logR)), dim3(256), 0, st, s0, s1,
                            M.ptr.as<int32_t>(), M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(),
                            M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR, 1, direct ? blk_tmp.as<D>() : (D *)nullptr,
-                           direct ? M.blk_slot1[(size_t)qb0] : 0);
+                           direct ? M.blk_slot1[(size_t)qb0] : 0, fl);
         ++count;
       }
       if (M.band_dense[b]) {  // block by block: sparse update, then ONE dense product per block
@@ -904,7 +913,7 @@ class Engine : public EngineBase {
           carried = true;
         }
         if (cdb) {
-          launch_band_cd<LOWER>(st, L, M, g0, g1, pre, ps0, ps1, extra);
+          launch_band_cd<LOWER>(st, L, M, g0, g1, pre, ps0, ps1, extra, fl);
           ++count;
           continue;
         }
@@ -912,7 +921,7 @@ class Engine : public EngineBase {
                            M.wg_slot.as<int32_t>(), M.ptr.as<int32_t>(),
                            M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(), M.srcslot.as<int32_t>(),
                            M.rowid.as<int32_t>(), L.d.as<D>(), w, v, errflag.as<unsigned>(), pre ? 0 : 1,
-                           (int32_t)(g1 - g0), ps0, ps1
+                           (int32_t)(g1 - g0), ps0, ps1, fl
 #ifdef HIFAMD_PROBE
                            ,
                            probe.as<unsigned long long>(), (int)count
@@ -938,7 +947,7 @@ class Engine : public EngineBase {
                           bool rhs_ready = false);
   // the level's top rows: t_T = w_T - (sources outside T) by the chip-wide prefix pass, straight into the product's
   // right-hand side; then v_T = G t_T on the matrix cores (G = U_TT^{-1} D_T^{-1} L_TT^{-1}, rows scattered by L's row ids)
-  void launch_top(hipStream_t st, const DevLevel &L, int logR, int64_t &count) {
+  void launch_top(hipStream_t st, const DevLevel &L, int logR, int64_t &count, const FL &fl) {
     if constexpr (std::is_same<T, double>::value) {
       const DevCsr &M = L.L;
       const size_t b = (size_t)L.top_bandL;
@@ -947,20 +956,20 @@ class Engine : public EngineBase {
       hipLaunchKernelGGL((k_trsv_wide<double, true, true>), dim3(grid_for(s1 - s0, logR)), dim3(256), 0, st, s0, s1,
                          M.ptr.as<int32_t>(), M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<double>(),
                          M.rowid.as<int32_t>(), L.d.as<double>(), L.w.as<double>(), L.v.as<double>(), logR, 1,
-                         blk_tmp.as<double>(), (int32_t)s1);
-      hipLaunchKernelGGL(k_dense_gemm_d<4>, dim3((unsigned)((nt + 15) / 16), ((1u << logR) + 15) / 16), dim3(256), 0, st, nt, nt,
-                         nt, 0, L.topG.as<double>(), nt, (const double *)blk_tmp.as<double>(), logR,
-                         M.rowid.as<int32_t>() + s0, L.v.as<double>(), (const double *)nullptr, (double *)nullptr);
+                         blk_tmp.as<double>(), (int32_t)s1, fl);
+      const int ktop = (int)round_up32(nt);
+      hipLaunchKernelGGL(k_strip_gemm_d<4>, dim3((unsigned)((nt + 15) / 16)), dim3(1024), 0, st, nt, ktop, L.topG.as<double>(), ktop,
+                         (const double *)blk_tmp.as<double>(), M.rowid.as<int32_t>() + s0, L.v.as<double>());
       count += 2;
     } else {
-      (void)st, (void)L, (void)logR, (void)count;
+      (void)st, (void)L, (void)logR, (void)count, (void)fl;
       throw Error(HIFAMD_HIFIR_ERROR, "internal error: combined top operator on a complex handle");
     }
   }
   // one component-dense band (kernels.hip.hpp k_band_cd): real data, R = 64
   template <bool LOWER>
   void launch_band_cd(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t g0, int32_t g1, int pre, int32_t ps0,
-                      int32_t ps1, unsigned extra) {
+                      int32_t ps1, unsigned extra, const FL &fl) {
     if constexpr (std::is_same<T, double>::value) {
       // LDS: the component's right-hand sides + its row ids (the attribute for > 64 KB is set in bind_device)
       const size_t lds = (size_t)band_opt.cd_rows * (64 * sizeof(double) + sizeof(int32_t));
@@ -973,16 +982,16 @@ class Engine : public EngineBase {
                          M.col.as<int32_t>(), M.val.as<double>(), M.rowid.as<int32_t>(), L.d.as<double>(), L.w.as<double>(),
                          L.v.as<double>(), M.tinv.as<double>(), M.mid_col.as<int32_t>(), M.mid_val.as<double>(),
                          M.mid_lrow.as<uint8_t>(), pre ? 0 : 1, (int32_t)(g1 - g0), ps0, ps1, single_c0,
-                         (int32_t)band_opt.cd_rows, cd_dbg);
+                         (int32_t)band_opt.cd_rows, cd_dbg, fl);
     } else {
-      (void)st, (void)L, (void)M, (void)g0, (void)g1, (void)pre, (void)ps0, (void)ps1, (void)extra;
+      (void)st, (void)L, (void)M, (void)g0, (void)g1, (void)pre, (void)ps0, (void)ps1, (void)extra, (void)fl;
       throw Error(HIFAMD_HIFIR_ERROR, "internal error: component-dense band on a complex handle");
     }
   }
 
-  void launch_ldu(hipStream_t st, DevLevel &L, int logR, int64_t &count) {
+  void launch_ldu(hipStream_t st, DevLevel &L, int logR, int64_t &count, const FL *fl = nullptr) {
     if (!L.m) return;
-    launch_trsv<true>(st, L, logR, count);
+    launch_trsv<true>(st, L, logR, count, fl);
     launch_trsv<false>(st, L, logR, count);
   }
 
@@ -1037,13 +1046,16 @@ class Engine : public EngineBase {
     const int64_t R = 1LL << logR;
     D *w = L.w.as<D>(), *v = L.v.as<D>();
     const bool last = (l + 1 == lv.size());
-    if (m) {  // S1  :359
+    // S1 (:359, :402) fused into the L solve that follows it (kernels FirstL): the R = 64 band pipeline only
+    const bool fuse_s1 = fuse_gather && logR == 6 && band_pipe && m > 0;
+    const FL fl{bin, ldb, nrhs, L.p.as<int32_t>(), L.s.as<double>()};
+    if (m && !fuse_s1) {  // S1  :359
       hipLaunchKernelGGL((k_gather_scale<D>), dim3(grid_for(m, logR)), dim3(256), 0, st, bin, ldb, nrhs,
                          L.p.as<int32_t>(), L.s.as<double>(), m, w, logR);
       ++count;
     }
     if (nm) {
-      launch_ldu(st, L, logR, count);  // S2  :364
+      launch_ldu(st, L, logR, count, fuse_s1 ? &fl : nullptr);  // S2  :364
       // S3  :366-368  -> w[m:n] (becomes the child's rhs, :386)
       hipLaunchKernelGGL((k_spmm_epi<D>), dim3(grid_for(nm, logR)), dim3(256), 0, st, nm, L.E.ptr.as<int32_t>(),
                          L.E.col.as<int32_t>(), L.E.val.as<D>(), v, bin, ldb, nrhs, L.p.as<int32_t>(),
@@ -1059,14 +1071,16 @@ class Engine : public EngineBase {
           hipLaunchKernelGGL((k_spmm_epi<D>), dim3(grid_for(m, logR)), dim3(256), 0, st, m, L.F.ptr.as<int32_t>(),
                              L.F.col.as<int32_t>(), L.F.val.as<D>(), v + m * R, bin, ldb, nrhs,
                              L.p.as<int32_t>(), L.s.as<double>(), (int64_t)0, w, logR);
-        } else {
+          ++count;
+        } else if (!fuse_s1) {
           hipLaunchKernelGGL((k_gather_scale<D>), dim3(grid_for(m, logR)), dim3(256), 0, st, bin, ldb, nrhs,
                              L.p.as<int32_t>(), L.s.as<double>(), m, w, logR);
+          ++count;
         }
-        ++count;
       }
     }
-    launch_ldu(st, L, logR, count);  // S6  :406
+    // S6  :406  (its right-hand side is w = s b[p] - F y from S5, or -- no F, or no Schur complement at all -- S1 again)
+    launch_ldu(st, L, logR, count, (fuse_s1 && !(nm && L.F_ncols)) ? &fl : nullptr);
     // S7  :411
     hipLaunchKernelGGL((k_scatter_scale<D>), dim3(grid_for(n, logR)), dim3(256), 0, st, v, L.qinv.as<int32_t>(),
                        L.t.as<double>(), n, yout, ldy, nrhs, logR);

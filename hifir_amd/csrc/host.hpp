@@ -297,6 +297,7 @@ struct BandOptions {
   int64_t dense_min_rows = 96;   // thin bands shorter than this stay on the sequential workgroup
   int64_t cd_rows = 192;         // component-dense bands: rows per component (LDS-resident; 0 = scheme off)
   double cd_min_row_nnz = 4.0;   // ... only for triangles with at least this many nonzeros per row on average
+  int64_t cd_max_nnz = 0;        // ... and nonzeros per component (0 = no limit): spreads heavy rows over more units
   int64_t top_max = 4096;        // combined top operator (choose_top): at most this many rows (0 = off)
   int64_t top_few_wgs = 96;      // ... made of the last bands of L's plan that have at most this many workgroups
   double dense_max_growth = 1e4; // ... and so do bands whose block inverses grow beyond this
@@ -551,6 +552,7 @@ BandPlan plan_bands_cd(const Csr<T> &A, const Schedule &S, bool lower, const Ban
     remaining.swap(keep);
   }
   std::vector<int32_t> pass((size_t)m, -1), parent((size_t)m), crows((size_t)m);
+  std::vector<int64_t> cnnz((size_t)m);
   std::vector<uint8_t> deferred((size_t)m, 0);
   auto find = [&](int32_t x) {
     while (parent[(size_t)x] != x) {
@@ -571,7 +573,7 @@ BandPlan plan_bands_cd(const Csr<T> &A, const Schedule &S, bool lower, const Ban
       crows[(size_t)i] = 1;
       bool dfr = false;
       roots.clear();
-      int64_t r = 1;
+      int64_t r = 1, wsum = A.ptr[(size_t)i + 1] - A.ptr[(size_t)i];
       for (int32_t k = nptr[i]; k < nptr[i + 1] && !dfr; ++k) {
         const int32_t j = ncol[k];
         if (pass[(size_t)j] >= 0 && pass[(size_t)j] < np) continue;  // finished in an earlier pass
@@ -584,15 +586,17 @@ BandPlan plan_bands_cd(const Csr<T> &A, const Schedule &S, bool lower, const Ban
         if (std::find(roots.begin(), roots.end(), rt) == roots.end()) {
           roots.push_back(rt);
           r += crows[(size_t)rt];
+          wsum += cnnz[(size_t)rt];
         }
       }
-      if (dfr || r > opt.cd_rows) {
+      if (dfr || r > opt.cd_rows || (opt.cd_max_nnz > 0 && wsum > opt.cd_max_nnz && !roots.empty())) {
         deferred[(size_t)i] = 1;
         next.push_back(i);
         continue;
       }
       for (int32_t rt : roots) parent[(size_t)rt] = i;
       crows[(size_t)i] = (int32_t)r;
+      cnnz[(size_t)i] = wsum;
       pass[(size_t)i] = np;
       mine.push_back(i);
     }

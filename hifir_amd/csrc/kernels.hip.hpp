@@ -99,6 +99,25 @@ struct IoPtr {
   __device__ __forceinline__ T *get() const { return slot ? (*slot + off) : direct; }
 };
 
+// S1 fused into the triangular solve: the kernel that touches a row of L FIRST takes its right-hand side straight from
+// the level's input, rhs[i] = s[p[i]] * b[p[i]] (prec_solve.hpp:359), instead of from a w[] that k_gather_scale wrote --
+// one launch and one write + read of the level's rows less.  bin.direct == nullptr && bin.slot == nullptr: not fused.
+template <class T>
+struct FirstL {
+  IoPtr<const T> bin;
+  int64_t ldb;
+  int nrhs;
+  const int32_t *p;
+  const double *s;
+  __device__ __forceinline__ bool on() const { return bin.direct != nullptr || bin.slot != nullptr; }
+};
+template <class T>
+__device__ __forceinline__ T first_l_rhs(const T *__restrict__ bin, const FirstL<T> &f, int32_t i, int lane) {
+  const int32_t src = f.p[i];
+  const T b = bin[(int64_t)src * f.ldb + min(lane, f.nrhs - 1)];
+  return lane < f.nrhs ? vscale(f.s[src], b) : vzero(T());
+}
+
 // ---------------------------------------------------------------------------------------------
 // S1: w[i] = s[p[i]] * b[p[i]],  rows [0, cnt)
 // ---------------------------------------------------------------------------------------------
@@ -250,9 +269,11 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
                                                 const int32_t *__restrict__ rowid, const T *__restrict__ d, T *x,
                                                 const T *__restrict__ rhs_u, int lane, int *flag, int32_t slot0,
                                                 unsigned *errflag, bool first_u, T *tb = nullptr, int32_t tb_s0 = 0,
-                                                int32_t tb_s1 = 0 HIFAMD_PROBE_ARG) {
+                                                int32_t tb_s1 = 0, const T *fl_bin = nullptr,
+                                                const FirstL<T> *fl = nullptr HIFAMD_PROBE_ARG) {
   int32_t s = rfl(s_first);
   if (s >= s_end) return true;
+  const bool first_l = LOWER && fl_bin != nullptr;  // this kernel is the first to touch its L rows: S1 fused (FirstL)
 #ifdef HIFAMD_PROBE
   int prow = 0;
   bool pfirst = false;
@@ -282,7 +303,8 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
   }
   // U rows start from D^{-1} times the L solution (rhs_u = w) when this kernel is the first to touch them
   const bool div_u = !LOWER && first_u;
-  T acc = div_u ? vdiv(rhs_u[((int64_t)i_c << 6) + lane], d[i_c]) : x[((int64_t)i_c << 6) + lane];
+  T acc = div_u ? vdiv(rhs_u[((int64_t)i_c << 6) + lane], d[i_c])
+                : (first_l ? first_l_rhs(fl_bin, *fl, i_c, lane) : x[((int64_t)i_c << 6) + lane]);
   // head of the wave's next row: its first item, right-hand side, pivot, and the header two rows
   // ahead.  MODE 0 issues it while the current row is consumed; MODE 2 only AFTER the current row's
   // flag is up, because a workgroup-scope release waits for every outstanding vector-memory
@@ -295,7 +317,8 @@ __device__ __forceinline__ bool trsv_stream_r64(int32_t s_first, int32_t s_end, 
       valv2 = val[kk_];                                     \
       if (MODE == 2) ssv2 = srcslot[kk_];                   \
     }                                                       \
-    acc2 = div_u ? vdiv(rhs_u[((int64_t)i_n << 6) + lane], d[i_n]) : x[((int64_t)i_n << 6) + lane]; \
+    acc2 = div_u ? vdiv(rhs_u[((int64_t)i_n << 6) + lane], d[i_n])                                  \
+                 : (first_l ? first_l_rhs(fl_bin, *fl, i_n, lane) : x[((int64_t)i_n << 6) + lane]); \
     s_nn = s_n + stride;                                    \
     has_nn = s_nn < s_end;                                  \
     if (has_nn) {                                           \
@@ -423,14 +446,15 @@ __global__ void __launch_bounds__(256) k_trsv_wide(int64_t s0, int64_t s1, const
                                                    const T *__restrict__ val,
                                                    const int32_t *__restrict__ rowid,
                                                    const T *__restrict__ d, T *w, T *v, int logR, int first_u,
-                                                   T *tb, int32_t tb_s1) {
+                                                   T *tb, int32_t tb_s1, FirstL<T> fl) {
   const LaneMap lm = lane_map(logR);
   const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   if (logR == 6) {  // (tb: R = 64 only; rows [s0, tb_s1) deliver their result to tb, see trsv_stream_r64)
+    const T *fl_bin = (LOWER && fl.on()) ? fl.bin.get() : nullptr;
     trsv_stream_r64<T, 0, LOWER, PREFIX>((int32_t)(s0 + wave), (int32_t)s1, (int32_t)nwaves, ptr, split, col, val,
                                          nullptr, rowid, d, LOWER ? w : v, w, threadIdx.x & 63, nullptr, 0, nullptr,
-                                         first_u != 0, tb, (int32_t)s0, tb_s1);
+                                         first_u != 0, tb, (int32_t)s0, tb_s1, fl_bin, &fl);
     return;
   }
   for (int64_t slot = s0 + wave * lm.G + lm.g; slot < s1; slot += nwaves * lm.G)
@@ -584,8 +608,8 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
                                               const int32_t *__restrict__ srcslot,
                                               const int32_t *__restrict__ rowid, const T *__restrict__ d, T *x,
                                               const T *__restrict__ rhs_u, const int lane, int *flag,
-                                              const int32_t slot0, unsigned *errflag,
-                                              const bool first_u HIFAMD_PROBE_ARG) {
+                                              const int32_t slot0, unsigned *errflag, const bool first_u,
+                                              const T *fl_bin = nullptr, const FirstL<T> *fl = nullptr HIFAMD_PROBE_ARG) {
 #ifdef HIFAMD_PROBE
   int prow = 0;
   int pbatch = 0;
@@ -593,11 +617,17 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
 #endif
   const int32_t s_first = rfl(s_first_);  // (wave-uniform, which the compiler cannot see from threadIdx.x >> 6)
   const bool div_u = !LOWER && first_u;
-  const T *rhs = div_u ? rhs_u : (const T *)x;
+  // S1 fused (FirstL): this kernel touches its L rows first and reads rhs[i] = s[p[i]] * b[p[i]]; the row's source row
+  // p[i] and scale s[p[i]] travel in the header blocks, so the loop still issues ONE right-hand-side load per row
+  const bool first_l = LOWER && first_u && fl_bin != nullptr;
+  const T *rhs = div_u ? rhs_u : (first_l ? fl_bin : (const T *)x);
+  const int64_t rstride = first_l ? fl->ldb : 64;
+  const int rlane = first_l ? min(lane, fl->nrhs - 1) : lane;
   // header blocks: lane l holds the header of the wave's row number (64 * block + l)
-  int32_t h_i = 0, h_k = 0, h_e = 0, g_i = 0, g_k = 0, g_e = 0;
+  int32_t h_i = 0, h_k = 0, h_e = 0, g_i = 0, g_k = 0, g_e = 0, h_p = 0, g_p = 0;
   T h_d = vzero(T()), g_d = vzero(T());
-#define HIFAMD_LOAD_HDR(hi, hk, he, hd, base)            \
+  double h_s = 0.0, g_s = 0.0;
+#define HIFAMD_LOAD_HDR(hi, hk, he, hd, hp, hs, base)    \
   {                                                      \
     const int32_t sl_ = (base) + lane * stride;          \
     if (sl_ < s_end) {                                   \
@@ -605,8 +635,15 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
       hk = split[sl_];                                   \
       he = ptr[sl_ + 1];                                 \
       if (div_u) hd = d[hi];                             \
+      if (first_l) {                                     \
+        hp = fl->p[hi];                                  \
+        hs = fl->s[hp];                                  \
+      }                                                  \
     }                                                    \
   }
+  // right-hand side of row (id i, source row pr, scale sc) as loaded / as used
+#define HIFAMD_RHS_AT(i, pr) rhs[(int64_t)(first_l ? (pr) : (i)) * rstride + rlane]
+#define HIFAMD_RHS_FIX(val, sc) (first_l ? (lane < fl->nrhs ? vscale((sc), (val)) : vzero(T())) : (val))
   // wait until the leading `hi` nonzeros of the current item (item_cnt of them valid) have their in-band sources
   // finished.  ONE LDS instruction polls the flags of the whole item (source slots sit one per lane) and `ready`
   // remembers how many leading nonzeros were found ready, so that a row whose sources all finished before the
@@ -642,7 +679,7 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
     _Pragma("unroll") for (int b = 0; b < 8; ++b) acc = vsub(acc, vmul(a_[b], xv_[b]));      \
     HIFAMD_STAMP_BATCH(1) /* (all eight accumulated) */                                      \
   }
-  HIFAMD_LOAD_HDR(h_i, h_k, h_e, h_d, s_first)  // (requested first: in flight while the flags are cleared)
+  HIFAMD_LOAD_HDR(h_i, h_k, h_e, h_d, h_p, h_s, s_first)  // (requested first: in flight while the flags are cleared)
   // the workgroup's flags: one per slot of its range [slot0, s_end)
   for (int t_ = (int)threadIdx.x; t_ < s_end - slot0; t_ += (int)blockDim.x) flag[t_] = 0;
   __syncthreads();
@@ -652,30 +689,34 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
   int32_t i_c = rl32(h_i, 0), k_c = rl32(h_k, 0), e_c = rl32(h_e, 0);
   int32_t colv = col[k_c + lane], ssv = srcslot[k_c + lane];  // (80 padding elements: DevCsr::upload)
   T valv = val[k_c + lane];
-  T acc = rhs[((int64_t)i_c << 6) + lane];
+  T acc = HIFAMD_RHS_AT(i_c, rl32(h_p, 0));
+  acc = HIFAMD_RHS_FIX(acc, rl64(h_s, 0));
   if (div_u) acc = vdiv(acc, rlv(h_d, 0));
   for (;;) {  // one row per iteration
     // header of the wave's next row: registers only.  Without a next row the trailing loads re-read
     // the current row (valid, ignored).
     const int32_t s_n = s + stride;
     const bool has_n = s_n < s_end;
-    int32_t i_n = i_c, k_n = k_c, e_n = e_c;
+    int32_t i_n = i_c, k_n = k_c, e_n = e_c, p_n = rl32(h_p, hidx);
     T d_n = vzero(T());
+    double s_n2 = rl64(h_s, hidx);
     if (has_n) {
       if (hidx < 63) {
         i_n = rl32(h_i, hidx + 1);
         k_n = rl32(h_k, hidx + 1);
         e_n = rl32(h_e, hidx + 1);
         if (div_u) d_n = rlv(h_d, hidx + 1);
+        if (first_l) p_n = rl32(h_p, hidx + 1), s_n2 = rl64(h_s, hidx + 1);
       } else {
         i_n = rl32(g_i, 0);
         k_n = rl32(g_k, 0);
         e_n = rl32(g_e, 0);
         if (div_u) d_n = rlv(g_d, 0);
+        if (first_l) p_n = rl32(g_p, 0), s_n2 = rl64(g_s, 0);
       }
     }
     // the following header block is requested half a block ahead
-    if (hidx == 32 && s + 32 * stride < s_end) HIFAMD_LOAD_HDR(g_i, g_k, g_e, g_d, s + 32 * stride)
+    if (hidx == 32 && s + 32 * stride < s_end) HIFAMD_LOAD_HDR(g_i, g_k, g_e, g_d, g_p, g_s, s + 32 * stride)
     // ---- long rows: full 64-nonzero items in front of the row's last item
     while (e_c - k_c > 64) {
       const int32_t c2 = col[k_c + 64 + lane], s2 = srcslot[k_c + 64 + lane];
@@ -728,7 +769,7 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
     colv = col[k_n + lane];                                                                               \
     valv = val[k_n + lane];                                                                               \
     ssv = srcslot[k_n + lane];                                                                            \
-    T acc2 = rhs[((int64_t)i_n << 6) + lane];                                                             \
+    T acc2 = HIFAMD_RHS_AT(i_n, p_n);                                                                     \
     asm volatile("" ::: "memory"); /* pins the trailing loads HERE */                                     \
     _Pragma("unroll") for (int b = 0; b < NBT; ++b) {                                                     \
       const T pr = vmul(a[b], xv[b]);                                                                     \
@@ -738,7 +779,7 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
     /* release: the row's stores (all 64 lanes) are ordered before its flag */                            \
     if (lane == 0) __hip_atomic_store(&flag[s - slot0], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); \
     pin_here(acc2); /* the next row's data is first touched HERE, behind the flag */                      \
-    acc = div_u ? vdiv(acc2, d_n) : acc2;                                                                 \
+    acc = div_u ? vdiv(acc2, d_n) : HIFAMD_RHS_FIX(acc2, s_n2);                                           \
   }
       if (nb <= 0)
         HIFAMD_BAND_FINAL(0)
@@ -771,9 +812,13 @@ __device__ __forceinline__ bool trsv_band_r64(const int32_t s_first_, const int3
       h_k = g_k;
       h_e = g_e;
       h_d = g_d;
+      h_p = g_p;
+      h_s = g_s;
     }
   }
 #undef HIFAMD_LOAD_HDR
+#undef HIFAMD_RHS_AT
+#undef HIFAMD_RHS_FIX
 #undef HIFAMD_BAND_POLL
 #undef HIFAMD_BAND_FULL8
   return true;
@@ -787,7 +832,7 @@ __global__ void __launch_bounds__(1024) k_trsv_band_p(int32_t wg0, const int32_t
                                                       const int32_t *__restrict__ srcslot,
                                                       const int32_t *__restrict__ rowid, const T *__restrict__ d,
                                                       T *w, T *v, unsigned *errflag, int first_u, int32_t n_band,
-                                                      int32_t ps0, int32_t ps1
+                                                      int32_t ps0, int32_t ps1, FirstL<T> fl
 #ifdef HIFAMD_PROBE
                                                       ,
                                                       unsigned long long *ts, int probe_id
@@ -798,10 +843,11 @@ __global__ void __launch_bounds__(1024) k_trsv_band_p(int32_t wg0, const int32_t
   const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   // workgroups beyond the band's own: the carried prefix of the NEXT band, slots [ps0, ps1), over the sources older than
   // this band (host.hpp finish_band_plan) -- independent of everything this launch computes, on otherwise idle units
+  const T *fl_bin = (LOWER && fl.on()) ? fl.bin.get() : nullptr;
   if ((int32_t)blockIdx.x >= n_band) {
     const int32_t pw = __builtin_amdgcn_readfirstlane(((int32_t)blockIdx.x - n_band) * nw + wave);
     trsv_stream_r64<T, 0, LOWER, true>(ps0 + pw, ps1, ((int32_t)gridDim.x - n_band) * nw, ptr, split, col, val, nullptr, rowid,
-                                       d, LOWER ? w : v, w, lane, nullptr, 0, nullptr, true);
+                                       d, LOWER ? w : v, w, lane, nullptr, 0, nullptr, true, nullptr, 0, 0, fl_bin, &fl);
     return;
   }
 #ifdef HIFAMD_PROBE  // same record layout as k_trsv_band: 0 entry, 2 start of work, 3 exit, 4.. two rows x 6
@@ -813,11 +859,11 @@ __global__ void __launch_bounds__(1024) k_trsv_band_p(int32_t wg0, const int32_t
   const int32_t slot0 = wg_slot[wg0 + blockIdx.x], slot1 = wg_slot[wg0 + blockIdx.x + 1];
 #ifdef HIFAMD_PROBE
   trsv_band_r64<T, LOWER>(slot0 + wave, slot1, nw, ptr, split, col, val, srcslot, rowid, d, LOWER ? w : v, w, lane, flag,
-                          slot0, errflag, first_u != 0, tsw);
+                          slot0, errflag, first_u != 0, fl_bin, &fl, tsw);
   if (tsw && lane == 0) tsw[3] = wall_clock64();
 #else
   trsv_band_r64<T, LOWER>(slot0 + wave, slot1, nw, ptr, split, col, val, srcslot, rowid, d, LOWER ? w : v, w, lane, flag,
-                          slot0, errflag, first_u != 0);
+                          slot0, errflag, first_u != 0, fl_bin, &fl);
 #endif
 }
 
@@ -1326,6 +1372,76 @@ __global__ void __launch_bounds__(NW * 64) k_dense_gemm_d(int mrows_total, int m
 }
 
 // ---------------------------------------------------------------------------------------------
+// Full dense operator on a 64-column block (the combined top operator of a level, host.hpp build_top_operator):
+// Out[rowmap[r]] = sum_k A(r,k) X[k],  A strip-major (lda = kend = columns rounded up to 32, zero padded), X = [kend][64]
+// (rows beyond the operator's columns must be readable and finite).
+// One workgroup per 16-row strip: wave = (column tile 0..3) x (K split 0..KS-1), so the strip's A panel is fetched
+// from HBM ONCE (the four column-tile waves of a K split read the same fragments, they meet in the CU's L1) -- with a
+// workgroup per (strip, tile), k_dense_gemm_d, every tile refetched the panel: 3.3x the operator's bytes in FETCH_SIZE.
+// Operand sets of 8 k-steps double buffered, partial tiles of the K splits summed through LDS in a fixed order.
+// ---------------------------------------------------------------------------------------------
+template <int KS>
+__global__ void __launch_bounds__(256 * KS) k_strip_gemm_d(int nrows, int kend, const double *__restrict__ A, int lda,
+                                                           const double *__restrict__ X,
+                                                           const int32_t *__restrict__ rowmap,
+                                                           double *__restrict__ Out) {
+  __shared__ double red[KS > 1 ? KS - 1 : 1][4][4][64];  // partial tiles of K splits 1..KS-1: [split-1][tile][reg][lane]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int ct = wave & 3, ks = wave >> 2;
+  const int i0 = blockIdx.x * 16;
+  const int colx = ct * 16 + (lane & 15);
+  const int kq = lane >> 4;
+  v4f64 acc0 = v4f64{0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+  constexpr int KU = 8;
+  const int kstride = KS * (4 * KU);
+  double a0[KU], b0[KU], a1[KU], b1[KU];
+  const double *Ap = A + ((int64_t)blockIdx.x * lda) * 16 + (lane & 15);
+  // (unconditional loads -- kend is a multiple of 32, A zero-padded in k, X readable (finite) there: the compiler then
+  //  counts its waits exactly and the next set stays in flight behind the MFMAs of the current one)
+#define HIFAMD_SG_LOAD(aa, bb, kb_)                                  \
+  _Pragma("unroll") for (int u = 0; u < KU; ++u) {                   \
+    const int kk = (kb_) + 4 * u + kq;                               \
+    aa[u] = Ap[(int64_t)kk * 16];                                    \
+    bb[u] = X[((int64_t)kk << 6) + colx];                            \
+  }
+#define HIFAMD_SG_MFMA(aa, bb)                                                            \
+  _Pragma("unroll") for (int u = 0; u < KU; u += 2) {                                     \
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], bb[u], acc0, 0, 0, 0);             \
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u + 1], bb[u + 1], acc1, 0, 0, 0);     \
+  }
+  int kb = ks * (4 * KU);
+  if (kb < kend) { HIFAMD_SG_LOAD(a0, b0, kb) }
+  while (kb < kend) {
+    const int kb1 = kb + kstride;
+    if (kb1 < kend) { HIFAMD_SG_LOAD(a1, b1, kb1) }
+    HIFAMD_SG_MFMA(a0, b0)
+    if (kb1 >= kend) break;
+    const int kb2 = kb1 + kstride;
+    if (kb2 < kend) { HIFAMD_SG_LOAD(a0, b0, kb2) }
+    HIFAMD_SG_MFMA(a1, b1)
+    kb = kb2;
+  }
+#undef HIFAMD_SG_LOAD
+#undef HIFAMD_SG_MFMA
+  const v4f64 acc = acc0 + acc1;
+  if (ks > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[ks - 1][ct][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (ks != 0) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double val = acc[r];
+#pragma unroll
+    for (int q = 0; q < KS - 1; ++q) val += red[q][ct][r][lane];
+    const int row = i0 + kq + 4 * r;
+    if (row < nrows) Out[((int64_t)(rowmap ? rowmap[row] : row) << 6) + colx] = val;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Block-dense thin bands, step (2): Out[rowmap[r]] = sum_{k<=r} Tinv(r,k) X[k] for one diagonal block
 // (nb rows), Tinv = explicit inverse of the block's unit lower triangle, strip-major with
 // lda = nb rounded up to 32 (zero padded; everything right of the diagonal is zero too).
@@ -1457,20 +1573,25 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
                                                   const double *__restrict__ tinv, const int32_t *__restrict__ mid_col,
                                                   const double *__restrict__ mid_val, const uint8_t *__restrict__ mid_lrow,
                                                   int first_u, int32_t n_band, int32_t ps0, int32_t ps1, int32_t single_c0,
-                                                  int32_t lds_rows, int dbg) {
+                                                  int32_t lds_rows, int dbg, FirstL<double> fl) {
   extern __shared__ double cd_tbuf[];  // [lds_rows][64] right-hand sides, then lds_rows row ids
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
   if ((int32_t)blockIdx.x >= n_band) {  // carried prefix of the next band over the sources older than this band
     const int32_t pw = __builtin_amdgcn_readfirstlane(((int32_t)blockIdx.x - n_band) * nw + wave);
     if (dbg & 4) return;
+    const double *pf_bin = (LOWER && fl.on()) ? fl.bin.get() : nullptr;
     trsv_stream_r64<double, 0, LOWER, true>(ps0 + pw, ps1, ((int32_t)gridDim.x - n_band) * nw, ptr, split, col, val, nullptr,
-                                            rowid, d, LOWER ? w : v, w, lane, nullptr, 0, nullptr, true);
+                                            rowid, d, LOWER ? w : v, w, lane, nullptr, 0, nullptr, true, nullptr, 0, 0, pf_bin, &fl);
     return;
   }
   double *x = LOWER ? w : v;
   const bool div_u = !LOWER && first_u;
-  const double *rhs = div_u ? (const double *)w : (const double *)x;
+  // S1 fused (FirstL): a band that touches its L rows first takes rhs[i] = s[p[i]] * b[p[i]] from the level's input
+  const bool first_l = LOWER && first_u && fl.on();
+  const double *rhs = div_u ? (const double *)w : (first_l ? fl.bin.get() : (const double *)x);
+  const int64_t rstride = first_l ? fl.ldb : 64;
+  const int rlane = first_l ? min(lane, fl.nrhs - 1) : lane;
   // single_c0 >= 0: every workgroup of this band owns exactly ONE component, number single_c0 + blockIdx.x (saves the
   // dependent load of the workgroup's group range)
   int32_t c_first, c_last;
@@ -1506,12 +1627,16 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
       for (int u = 0; u < KU; ++u) a0[u] = ap_[u * 64];
     }
     // ---- phase 1a: right-hand sides of this wave's rows into LDS (row ids one per lane, eight loads in flight)
-    int32_t h_i = 0;
-    double h_d = 1.0;
+    int32_t h_i = 0, h_p = 0;
+    double h_d = 1.0;  // (U: the pivot; fused S1: the row's scale)
     if (lane < nr) {
       h_i = rowid[s0 + r0 + lane];
       cd_rowid[r0 + lane] = h_i;
       if (div_u) h_d = d[h_i];
+      if (first_l) {
+        h_p = fl.p[h_i];
+        h_d = fl.s[h_p];
+      }
     }
     // first item of the wave's entry stream: requested before the right-hand sides are waited for
     int32_t colv = 0, lrv = 0;
@@ -1525,12 +1650,16 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
       double t_[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int32_t i = rl32(h_i, min(j + q, 63));
-        t_[q] = (j + q < nr) ? rhs[((int64_t)i << 6) + lane] : 0.0;
+        const int32_t i = rl32(first_l ? h_p : h_i, min(j + q, 63));
+        t_[q] = (j + q < nr) ? rhs[(int64_t)i * rstride + rlane] : 0.0;
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q)
-        if (j + q < nr) cd_tbuf[((r0 + j + q) << 6) + lane] = div_u ? t_[q] / rl64(h_d, min(j + q, 63)) : t_[q];
+        if (j + q < nr) {
+          const double hd = rl64(h_d, min(j + q, 63));
+          cd_tbuf[((r0 + j + q) << 6) + lane] =
+              div_u ? t_[q] / hd : (first_l ? (lane < fl.nrhs ? hd * t_[q] : 0.0) : t_[q]);
+        }
     }
     // ---- phase 1b: the wave's entries, items of 64, eight gathers per batch; the running row's sum stays in a register
     int cur_r = -1;

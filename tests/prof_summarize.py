@@ -12,6 +12,24 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def stamp():
+    """What the numbers belong to: the library build that was profiled (bench.py only uses a summary whose sha256
+    equals the library it runs with) and the commit it was built from."""
+    import hashlib
+    import subprocess
+
+    so = os.path.join(ROOT, "hifir_amd", "libhifir_amd.so")
+    sha = hashlib.sha256(open(so, "rb").read()).hexdigest() if os.path.exists(so) else None
+    try:
+        head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip()
+        dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "hifir_amd/csrc", "include"], text=True).strip())
+    except Exception:
+        head, dirty = None, None
+    return {"lib_sha256": sha, "git_head": head, "csrc_dirty": dirty}
+
 
 
 def one(pattern):
@@ -64,15 +82,17 @@ if kt and os.path.exists(bj):
              "sum_of_kernel_durations_per_apply_ms_median": sorted(first)[len(first) // 2],
              "bench_apply_ms_hip_events": line["roofline"]["apply_ms_hip_events"],
              "bench_ms_per_step_wall": line["ms_per_step"]}
+    agree.update(stamp())
     json.dump(agree, open(dst + "_apply_time_agreement.json", "w"), indent=1)
     print(json.dumps(agree))
     # per-stage rooflines of the primary workload: kernel time per apply (same segmentation) against the
     # stage group's share of B_alg (bench.py "algorithmic_bytes_by_stage", SURVEY 8(d) terms)
     sb = line["roofline"].get("algorithmic_bytes_by_stage")
     if sb:
+        # (k_strip_gemm_d is the combined top operator of a level's triangular solves)
         group = {"k_gather_scale": "permute", "k_scatter_scale": "permute", "k_spmm_epi": "schur", "k_trsv_band": "ldu",
-                 "k_trsv_wide": "ldu", "k_thin_update": "ldu", "k_tri_gemm_d": "ldu", "k_dense_gemm": "dense",
-                 "k_row_gather": "dense"}
+                 "k_band_cd": "ldu", "k_trsv_wide": "ldu", "k_thin_update": "ldu", "k_tri_gemm_d": "ldu",
+                 "k_strip_gemm_d": "ldu", "k_dense_gemm": "dense", "k_row_gather": "dense"}
         tms = {g: 0.0 for g in sb}
         per_kernel = {}
         napp = 0
@@ -99,6 +119,7 @@ if kt and os.path.exists(bj):
                       "achieved_GBs": sb[g] / (tms[g] / napp * 1e-3) / 1e9 if tms[g] else None,
                       "frac_of_8TBs": sb[g] / (tms[g] / napp * 1e-3) / 8e12 if tms[g] else None} for g in sb}
         stages["kernels"] = {k_: {"launches_per_apply": v[0] / napp, "ms_per_apply": v[1] / napp} for k_, v in per_kernel.items()}
+        stages.update(stamp())
         json.dump(stages, open(dst + "_stage_roofline.json", "w"), indent=1)
         print(json.dumps(stages))
 
@@ -115,5 +136,6 @@ if f and w:
            "correction": "read bytes = 2 * FETCH_SIZE * 1024 (gfx950 counts 128-B requests at 64 B); "
                          "WRITE_SIZE exact (k_gather_scale: 499,709 KiB reported vs 499,709 KiB written)",
            "per_kernel_KiB": {k: {"FETCH_SIZE": bf.get(k, 0.0), "WRITE_SIZE": bw.get(k, 0.0)} for k in bf}}
+    out.update(stamp())
     json.dump(out, open(dst + "_pmc_summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
