@@ -148,6 +148,9 @@ struct DevCsr {
   std::vector<int32_t> band_blk_ptr, blk_slot0, blk_slot1;
   std::vector<int64_t> blk_inv_off;
   DevBuf tinv;  // explicit inverses of the diagonal blocks of block-dense thin bands
+  // tiled form of a coupling block (E, F) for k_spmm_tile (host.hpp SpmmTiles); nblk == 0: not built
+  DevBuf tl_gptr, tl_ucol, tl_coef;
+  int64_t tl_nblk = 0;
 
   void alias(const DevCsr &o) {  // share the device arrays, copy the (small) host-side launch metadata
     nrows = o.nrows;
@@ -172,6 +175,10 @@ struct DevCsr {
     band_old = o.band_old;
     host_wg_grp_ptr = o.host_wg_grp_ptr;
     tinv.alias(o.tinv);
+    tl_gptr.alias(o.tl_gptr);
+    tl_ucol.alias(o.tl_ucol);
+    tl_coef.alias(o.tl_coef);
+    tl_nblk = o.tl_nblk;
     band_wg_ptr = o.band_wg_ptr;
     band_slot_ptr = o.band_slot_ptr;
     band_prefix = o.band_prefix;
@@ -314,6 +321,8 @@ class Engine : public EngineBase {
   bool use_graph = true;
   int min_logR = 6;
   int gemm_waves = 16;   // split-K width of the block-inverse GEMM
+  bool spmm_tiles = true;       // E / F products on the matrix cores where rows share columns (HIFIR_AMD_SPMM_TILES=0: off)
+  double spmm_tile_reuse = 2.0; // ... when a 16-row block has at least this many nonzeros per distinct column
   bool fuse_gather = true;  // S1 fused into the L solve (HIFIR_AMD_FUSE_S1=0: separate k_gather_scale launches)
   int cd_dbg = 0;        // development aid (HIFIR_AMD_CD_DBG): phases of k_band_cd switched off for timing experiments
   int band_pipe = 1;     // 1: k_trsv_band_p (next row's head behind the last gathers), 0: k_trsv_band at R = 64 too
@@ -342,6 +351,7 @@ class Engine : public EngineBase {
     band_pipe = env_int("HIFIR_AMD_BAND_PIPE", 1);
     cd_dbg = env_int("HIFIR_AMD_CD_DBG", 0);
     fuse_gather = env_int("HIFIR_AMD_FUSE_S1", 1) != 0;
+    spmm_tiles = env_int("HIFIR_AMD_SPMM_TILES", 1) != 0;
     use_twin = env_int("HIFIR_AMD_TWIN", 1);
     band_opt.thin_rows = env_int("HIFIR_AMD_THIN_ROWS", 96);
     band_opt.band_depth = env_int("HIFIR_AMD_BAND_DEPTH", 32);
@@ -444,6 +454,7 @@ class Engine : public EngineBase {
       E->band_opt = band_opt;
       E->gemm_waves = gemm_waves;
       E->fuse_gather = fuse_gather;
+      E->spmm_tiles = spmm_tiles;
       for (const auto &P : host.levels) E->add_level_adjoint(P);
       if (host.has_dense && host.dense.kind == 2) {  // LUP: ?getrs 'T' / ?gemv 'C' (LUP.hpp:150,187)
         E->host.dense.kind = 2;
@@ -491,6 +502,7 @@ class Engine : public EngineBase {
       E->band_opt = band_opt;
       E->gemm_waves = gemm_waves;
       E->fuse_gather = fuse_gather;
+      E->spmm_tiles = spmm_tiles;
       E->max_nrhs = max_nrhs;
       E->Rmax = Rmax;
       E->host.has_dense = host.has_dense;
@@ -705,6 +717,18 @@ class Engine : public EngineBase {
       }
       L.E.upload(H.Er, nullptr);
       L.F.upload(H.Fr, nullptr);
+      if (spmm_tiles && sizeof(T) == sizeof(double) && band_opt.dense_block > 0)  // fast mode, real data
+        for (int which = 0; which < 2; ++which) {
+          const Csr<T> &Ah = which ? H.Fr : H.Er;
+          DevCsr &Md = which ? L.F : L.E;
+          if (Ah.nrows < 64 || Ah.col.size() < 8 * (size_t)Ah.nrows) continue;  // (sparse rows share too little)
+          SpmmTiles Tl = build_spmm_tiles(Ah);
+          if (Tl.reuse < spmm_tile_reuse) continue;
+          Md.tl_gptr.upload(Tl.blk_gptr);
+          Md.tl_ucol.upload(Tl.ucol);
+          Md.tl_coef.upload(Tl.coef);
+          Md.tl_nblk = Tl.nblk;
+        }
       L.d.upload(H.d);
       L.s.upload(H.s);
       L.t.upload(H.t);
@@ -1039,6 +1063,24 @@ class Engine : public EngineBase {
   static InP in_direct(const D *p) { return InP{p, nullptr, 0}; }
   static OutP out_direct(D *p) { return OutP{p, nullptr, 0}; }
 
+  // S3 / S5: out = s[p] b[p] - A x.  R = 64, fast mode, real data, rows that share columns: on the matrix cores
+  // (k_spmm_tile); otherwise the row-gather kernel in the reference's summation order (k_spmm_epi)
+  void launch_spmm(hipStream_t st, const DevCsr &A, int64_t nrows, const D *x, InP bin, int64_t ldb, int nrhs,
+                   const DevLevel &L, int64_t roff, D *out, int logR) {
+    if constexpr (std::is_same<T, double>::value) {
+      if (A.tl_nblk > 0 && logR == 6) {
+        const unsigned grid = (unsigned)std::min<int64_t>((A.tl_nblk + 3) / 4, 256 * 16);
+        hipLaunchKernelGGL(k_spmm_tile, dim3(grid), dim3(256), 0, st, nrows, A.tl_nblk, A.tl_gptr.as<int32_t>(),
+                           A.tl_ucol.as<int32_t>(), A.tl_coef.as<double>(), (const double *)x, bin, ldb, nrhs, L.p.as<int32_t>(),
+                           L.s.as<double>(), roff, out);
+        return;
+      }
+    }
+    hipLaunchKernelGGL((k_spmm_epi<D>), dim3(grid_for(nrows, logR)), dim3(256), 0, st, nrows, A.ptr.as<int32_t>(),
+                       A.col.as<int32_t>(), A.val.as<D>(), x, bin, ldb, nrhs, L.p.as<int32_t>(), L.s.as<double>(), roff, out,
+                       logR);
+  }
+
   void enqueue_level(hipStream_t st, size_t l, InP bin, int64_t ldb, OutP yout, int64_t ldy, int nrhs,
                      int logR, int64_t rank, int64_t &count) {
     DevLevel &L = *lv[l];
@@ -1057,9 +1099,7 @@ class Engine : public EngineBase {
     if (nm) {
       launch_ldu(st, L, logR, count, fuse_s1 ? &fl : nullptr);  // S2  :364
       // S3  :366-368  -> w[m:n] (becomes the child's rhs, :386)
-      hipLaunchKernelGGL((k_spmm_epi<D>), dim3(grid_for(nm, logR)), dim3(256), 0, st, nm, L.E.ptr.as<int32_t>(),
-                         L.E.col.as<int32_t>(), L.E.val.as<D>(), v, bin, ldb, nrhs, L.p.as<int32_t>(),
-                         L.s.as<double>(), m, w + m * R, logR);
+      launch_spmm(st, L.E, nm, v, bin, ldb, nrhs, L, m, w + m * R, logR);
       ++count;
       if (last)
         launch_dense(st, w + m * R, v + m * R, logR, rank, count);  // :371-381
@@ -1068,9 +1108,7 @@ class Engine : public EngineBase {
       // S5  :392-403   (v[m:n] already is "work[m:n] = y[m:n]")
       if (m) {
         if (L.F_ncols) {
-          hipLaunchKernelGGL((k_spmm_epi<D>), dim3(grid_for(m, logR)), dim3(256), 0, st, m, L.F.ptr.as<int32_t>(),
-                             L.F.col.as<int32_t>(), L.F.val.as<D>(), v + m * R, bin, ldb, nrhs,
-                             L.p.as<int32_t>(), L.s.as<double>(), (int64_t)0, w, logR);
+          launch_spmm(st, L.F, m, v + m * R, bin, ldb, nrhs, L, (int64_t)0, w, logR);
           ++count;
         } else if (!fuse_s1) {
           hipLaunchKernelGGL((k_gather_scale<D>), dim3(grid_for(m, logR)), dim3(256), 0, st, bin, ldb, nrhs,

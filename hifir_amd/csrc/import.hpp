@@ -149,15 +149,26 @@ void analyze_level(HostLevel<T> &H, const BandOptions &band_opt, bool dump = fal
         maxrows = std::max<int64_t>(maxrows, e - a);
         maxdepth = std::max<int64_t>(maxdepth, P.wg_grp_ptr[(size_t)g + 1] - P.wg_grp_ptr[(size_t)g]);
       }
+      int64_t distinct = 0;  // component-dense bands: distinct source rows per component, summed (reuse potential)
+      if (P.band_cd[(size_t)b]) {
+        std::vector<int32_t> u;
+        for (int32_t c = P.wg_grp_ptr[(size_t)g0]; c < P.wg_grp_ptr[(size_t)g1]; ++c) {
+          u.clear();
+          for (int32_t q = P.grp_slot_ptr[(size_t)c]; q < P.grp_slot_ptr[(size_t)c + 1]; ++q)
+            for (int32_t k = P.split[(size_t)q]; k < P.csplit[(size_t)q]; ++k) u.push_back(P.srcslot[(size_t)k]);
+          std::sort(u.begin(), u.end());
+          distinct += std::unique(u.begin(), u.end()) - u.begin();
+        }
+      }
       int64_t own = 0, prevb = 0;  // nonzeros inside the rows' own component / gathered by the band kernel itself
       for (int32_t q = s0; q < s1; ++q) {
         own += A.ptr[(size_t)q + 1] - P.csplit[(size_t)q];
         prevb += P.csplit[(size_t)q] - P.split[(size_t)q];
       }
-      std::fprintf(stderr, "PLAN level=%zu tri=%c band=%ld rows=%d nnz=%d wgs=%d prefix=%d dense=%d fused=%d cd=%d comps=%d own=%ld inband=%ld maxwg_nnz=%ld maxwg_rows=%ld maxdepth=%ld\n",
+      std::fprintf(stderr, "PLAN level=%zu tri=%c band=%ld rows=%d nnz=%d wgs=%d prefix=%d dense=%d fused=%d cd=%d comps=%d own=%ld inband=%ld distinct=%ld maxwg_nnz=%ld maxwg_rows=%ld maxdepth=%ld\n",
                    level_no, tri ? 'U' : 'L', (long)b, s1 - s0, A.ptr[(size_t)s1] - A.ptr[(size_t)s0], g1 - g0,
                    (int)P.band_prefix[(size_t)b], (int)P.band_dense[(size_t)b], (int)P.band_fused[(size_t)b],
-                   (int)P.band_cd[(size_t)b], P.wg_grp_ptr[(size_t)g1] - P.wg_grp_ptr[(size_t)g0], (long)own, (long)prevb,
+                   (int)P.band_cd[(size_t)b], P.wg_grp_ptr[(size_t)g1] - P.wg_grp_ptr[(size_t)g0], (long)own, (long)prevb, (long)distinct,
                    (long)maxnnz, (long)maxrows, (long)maxdepth);
     }
   }

@@ -34,6 +34,7 @@ namespace hifamd {
 struct cplx {
   double x, y;
 };
+typedef double v4f64 __attribute__((ext_vector_type(4)));  // accumulator tile of v_mfma_f64_16x16x4_f64
 
 // ---- value-type arithmetic, spelled out so that no contraction / reassociation can happen ------
 __device__ __forceinline__ double vzero(double) { return 0.0; }
@@ -1056,6 +1057,75 @@ __global__ void __launch_bounds__(256) k_spmm_epi(int64_t nrows, const int32_t *
 }
 
 // ---------------------------------------------------------------------------------------------
+// S3 / S5 on the matrix cores (host.hpp SpmmTiles): out[i] = s[p[roff+i]] * b[p[roff+i]] - sum_j A(i,j) x[j] with the
+// rows in blocks of 16 and each block's distinct columns in groups of 4.  One wave per block: per group ONE coalesced
+// load of the 16 x 4 coefficient tile (A operand), the 4 source rows gathered as the B operands of the four
+// 16-column tiles (lane l fetches x[ucol[4g + (l >> 4)]][16 ct + (l & 15)]), four MFMAs.  Two groups in flight.
+// Every distinct source row of a block is fetched once, not once per nonzero.  R = 64, real data, fast mode.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_spmm_tile(int64_t nrows, int64_t nblk, const int32_t *__restrict__ blk_gptr,
+                                                   const int32_t *__restrict__ ucol, const double *__restrict__ coef,
+                                                   const double *__restrict__ x, IoPtr<const double> bin_, int64_t ldb,
+                                                   int nrhs, const int32_t *__restrict__ p, const double *__restrict__ s,
+                                                   int64_t roff, double *__restrict__ out) {
+  const double *__restrict__ bin = bin_.get();
+  const int lane = threadIdx.x & 63;
+  const int kq = lane >> 4, jc = lane & 15;
+  const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t b = wave; b < nblk; b += nwaves) {
+    const int32_t g0 = rfl(blk_gptr[b]), g1 = rfl(blk_gptr[b + 1]);
+    v4f64 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = v4f64{0.0, 0.0, 0.0, 0.0};
+    // Software pipeline over the groups, all loads unconditional (indices clamped to the block's last group, whose
+    // coefficient is then zeroed): source-row indices run 7 groups ahead, coefficient + B fragments 3 groups ahead of the
+    // MFMAs -- the compiler counts its waits exactly, nothing but the oldest group is ever waited for.
+    if (g0 < g1) {
+      const int32_t gl = g1 - 1;
+      int32_t src[8];
+      double av[4], bv[4][4];
+#define HIFAMD_TL_SRC(slot, g) src[slot] = ucol[4 * (int64_t)min((g), gl) + kq];
+#define HIFAMD_TL_LOAD(slot, sslot, g)                                                         \
+  av[slot] = coef[64 * (int64_t)min((g), gl) + lane];                                          \
+  _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) bv[slot][ct] = x[((int64_t)src[sslot] << 6) + 16 * ct + jc];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) { HIFAMD_TL_SRC(q, g0 + q) }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { HIFAMD_TL_LOAD(q, q, g0 + q) }
+      for (int32_t g = g0; g < g1; g += 8) {
+#pragma unroll
+        for (int dd = 0; dd < 8; ++dd) {
+          const int32_t cur = g + dd;
+          HIFAMD_TL_LOAD((dd + 3) & 3, (dd + 3) & 7, cur + 3)
+          HIFAMD_TL_SRC((dd + 7) & 7, cur + 7)
+          const double am = cur < g1 ? av[dd & 3] : 0.0;
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bv[dd & 3][ct], acc[ct], 0, 0, 0);
+        }
+      }
+#undef HIFAMD_TL_SRC
+#undef HIFAMD_TL_LOAD
+    }
+    // epilogue: C layout col = l & 15, row = (l >> 4) + 4 * reg
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = 16 * b + kq + 4 * r;
+      if (i < nrows) {
+        const int32_t srow = p[roff + i];
+        const double sc = s[srow];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const int c = 16 * ct + jc;
+          const double rhs = c < nrhs ? sc * bin[(int64_t)srow * ldb + c] : 0.0;
+          out[(i << 6) + c] = rhs - acc[ct][r];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // outer CRS SpMM: y = A x (RESID = false) or r = b - A x (RESID = true), tmp = 0; tmp += a*x
 // ---------------------------------------------------------------------------------------------
 template <class T, bool RESID>
@@ -1295,8 +1365,6 @@ __global__ void __launch_bounds__(256) k_col_op(int op, int64_t n, int nrhs, dou
 // One wave owns a 16-row strip x all ceil(R/16) column tiles; v_mfma_f64_16x16x4_f64 lane maps:
 //   A: lane l holds A[i = l&15][k = l>>4]; B: B[k = l>>4][j = l&15]; C/D: col = l&15, row = (l>>4) + 4*reg.
 // ---------------------------------------------------------------------------------------------
-typedef double v4f64 __attribute__((ext_vector_type(4)));
-
 // tri: 0 full, 1 upper (k >= row tile start), 2 lower (k < row tile end).  dscale/Out2 (optional):
 // Out2[orow] = result / dscale[orow]  (the fused y /= d of the L solve, prec_solve.hpp:219).
 // A is stored STRIP-MAJOR (host.hpp to_strip_layout): strip s = rows [16 s, 16 s + 16), element
