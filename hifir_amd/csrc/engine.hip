@@ -143,6 +143,8 @@ struct DevCsr {
   DevBuf srcslot, split, wg_grp_ptr, grp_slot_ptr;
   DevBuf wg_slot;  // first slot of every workgroup (+ end): grp_slot_ptr[wg_grp_ptr[g]], one load level less at kernel start
   DevBuf csplit, grp_inv_off, cd_desc, mid_col, mid_val, mid_lrow;  // component-dense bands (host.hpp plan_bands_cd)
+  DevBuf own_val, own_lsrc, own_rptr, own_lvl;                        // ... sparse-own plans (BandPlan::cd_sparse)
+  bool cd_sparse = false;
   std::vector<int32_t> band_wg_ptr, band_slot_ptr, host_wg_grp_ptr;
   std::vector<uint8_t> band_prefix, band_dense, band_fused, band_cd, band_old;
   std::vector<int32_t> band_blk_ptr, blk_slot0, blk_slot1;
@@ -171,6 +173,11 @@ struct DevCsr {
     mid_col.alias(o.mid_col);
     mid_val.alias(o.mid_val);
     mid_lrow.alias(o.mid_lrow);
+    own_val.alias(o.own_val);
+    own_lsrc.alias(o.own_lsrc);
+    own_rptr.alias(o.own_rptr);
+    own_lvl.alias(o.own_lvl);
+    cd_sparse = o.cd_sparse;
     band_cd = o.band_cd;
     band_old = o.band_old;
     host_wg_grp_ptr = o.host_wg_grp_ptr;
@@ -218,6 +225,13 @@ struct DevCsr {
         mid_col.upload(mc, 80);
         mid_val.upload(mv, 80);
         mid_lrow.upload(P->mid_lrow, 80);
+        cd_sparse = P->cd_sparse;
+        std::vector<T> ov(P->own_k.size());
+        for (size_t e = 0; e < ov.size(); ++e) ov[e] = A.val[(size_t)P->own_k[e]];
+        own_val.upload(ov, 8);
+        own_lsrc.upload(P->own_lsrc, 8);
+        own_rptr.upload(P->own_rptr, 8);
+        own_lvl.upload(P->own_lvl, 8);
       }
       band_cd = P->band_cd;
       band_old = P->band_old;
@@ -367,6 +381,7 @@ class Engine : public EngineBase {
     // component-dense bands (host.hpp plan_bands_cd): real data, fast mode; HIFIR_AMD_CD_ROWS=0 keeps the depth-cut bands
     band_opt.cd_rows = (sizeof(T) == sizeof(double) && band_opt.dense_block > 0) ? env_int("HIFIR_AMD_CD_ROWS", 128) : 0;
     band_opt.cd_max_nnz = env_int("HIFIR_AMD_CD_NNZ", 0);
+    band_opt.cd_sparse_rows = std::min(192, env_int("HIFIR_AMD_CD_SPARSE_ROWS", 192));  // 0: thin triangles keep the flag bands
     band_opt.top_max = env_int("HIFIR_AMD_TOP_ROWS", 4096);      // combined top operator (host.hpp choose_top); 0 = off
     band_opt.top_few_wgs = env_int("HIFIR_AMD_TOP_WGS", 96);
     if (band_opt.cd_rows > 240) band_opt.cd_rows = 240;  // (local row ids are bytes; 120 KB of the CU's 160 KB LDS)
@@ -381,9 +396,10 @@ class Engine : public EngineBase {
     HIP_OK(hipSetDevice(device));
     if (!stream) HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (sizeof(T) == sizeof(double) && band_opt.cd_rows > 0) {  // k_band_cd keeps a component in up to 128 KB of LDS
-      const int lds = (int)(band_opt.cd_rows * (64 * sizeof(double) + sizeof(int32_t)));
-      HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(false)));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(false)));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(true)));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(true)));
     }
   }
 
@@ -991,22 +1007,33 @@ class Engine : public EngineBase {
     }
   }
   // one component-dense band (kernels.hip.hpp k_band_cd): real data, R = 64
+  // LDS of k_band_cd: the component's right-hand sides + row ids; sparse-own plans add the own nonzeros (value + source
+  // row, kCdOwnCap of them), the row offsets and the depth levels
+  size_t cd_lds_bytes(bool sparse) const {
+    const size_t rows = (size_t)(sparse ? band_opt.cd_sparse_rows : band_opt.cd_rows);
+    size_t b = rows * 64 * sizeof(double) + ((rows + 1) & ~(size_t)1) * sizeof(int32_t);
+    if (sparse) b += (size_t)kCdOwnCap * (sizeof(double) + 1) + 260 * sizeof(uint16_t) + 264;
+    return b;
+  }
   template <bool LOWER>
   void launch_band_cd(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t g0, int32_t g1, int pre, int32_t ps0,
                       int32_t ps1, unsigned extra, const FL &fl) {
     if constexpr (std::is_same<T, double>::value) {
       // LDS: the component's right-hand sides + its row ids (the attribute for > 64 KB is set in bind_device)
-      const size_t lds = (size_t)band_opt.cd_rows * (64 * sizeof(double) + sizeof(int32_t));
+      const size_t lds = cd_lds_bytes(M.cd_sparse);
+      const int32_t lds_rows = (int32_t)(M.cd_sparse ? band_opt.cd_sparse_rows : band_opt.cd_rows);
       // one component per workgroup (the usual case): the kernel derives the component from blockIdx
       const int32_t c0 = M.host_wg_grp_ptr[(size_t)g0], c1 = M.host_wg_grp_ptr[(size_t)g1];
       const int32_t single_c0 = (c1 - c0 == g1 - g0) ? c0 : -1;
       (void)pre;  // (the packed streams already start at split[] for a carried band, at ptr[] otherwise)
-      hipLaunchKernelGGL((k_band_cd<LOWER>), dim3((unsigned)(g1 - g0) + extra), dim3(1024), lds, st, g0,
+      auto kern = M.cd_sparse ? k_band_cd<LOWER, true> : k_band_cd<LOWER, false>;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(g1 - g0) + extra), dim3(1024), lds, st, g0,
                          M.wg_grp_ptr.as<int32_t>(), M.cd_desc.as<int32_t>(), M.ptr.as<int32_t>(), M.split.as<int32_t>(),
                          M.col.as<int32_t>(), M.val.as<double>(), M.rowid.as<int32_t>(), L.d.as<double>(), L.w.as<double>(),
                          L.v.as<double>(), M.tinv.as<double>(), M.mid_col.as<int32_t>(), M.mid_val.as<double>(),
                          M.mid_lrow.as<uint8_t>(), pre ? 0 : 1, (int32_t)(g1 - g0), ps0, ps1, single_c0,
-                         (int32_t)band_opt.cd_rows, cd_dbg, fl);
+                         lds_rows, cd_dbg, fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
+                         M.own_lvl.as<uint8_t>());
     } else {
       (void)st, (void)L, (void)M, (void)g0, (void)g1, (void)pre, (void)ps0, (void)ps1, (void)extra, (void)fl;
       throw Error(HIFAMD_HIFIR_ERROR, "internal error: component-dense band on a complex handle");

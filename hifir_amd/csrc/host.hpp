@@ -275,13 +275,23 @@ struct BandPlan {
   std::vector<int32_t> mid_k;
   std::vector<uint8_t> mid_lrow;
   // per group kCdDescWords int32 words (cd bands; zeros elsewhere): s0, nb, mid0, nmid, inv_off (2 words), then the
-  // 16 waves' row chunks wrow[17] (uint8) and their entry offsets wmid[17] (uint16, relative to mid0)
+  // 16 waves' row chunks wrow[17] (uint8) and their entry offsets wmid[17] (uint16, relative to mid0); sparse plans:
+  // words 20..24 = own0, nown, orp0 (into own_rptr), lvl0 (into own_lvl), nlvl
   std::vector<int32_t> cd_desc;
+  // cd_sparse: the components' OWN nonzeros are not inverted but solved in LDS, depth level by depth level (triangles
+  // with ~2 nonzeros per row: level 0 of a PDE hierarchy -- an inverse would cost 20x the matrix).  Per component the
+  // own nonzeros [csplit, end) of its rows as one packed stream (nonzero index own_k, local source row own_lsrc),
+  // row offsets own_rptr (nb + 1 per component) and the depth levels as row boundaries own_lvl (nlvl + 1 per component).
+  bool cd_sparse = false;
+  std::vector<int32_t> own_k;
+  std::vector<uint8_t> own_lsrc, own_lvl;
+  std::vector<uint16_t> own_rptr;
   int64_t nbands() const { return (int64_t)band_wg_ptr.size() - 1; }
   int64_t nwg() const { return (int64_t)wg_grp_ptr.size() - 1; }
 };
 
-constexpr int kCdDescWords = 20;  // 80 bytes per component descriptor (BandPlan::cd_desc)
+constexpr int kCdDescWords = 28;  // 112 bytes per component descriptor (BandPlan::cd_desc)
+constexpr int kCdOwnCap = 4096;   // own nonzeros of a sparse component that k_band_cd keeps in LDS
 
 struct BandOptions {
   int64_t thin_rows = 96;    // a wavefront this narrow belongs to a thin run
@@ -298,6 +308,9 @@ struct BandOptions {
   int64_t cd_rows = 192;         // component-dense bands: rows per component (LDS-resident; 0 = scheme off)
   double cd_min_row_nnz = 4.0;   // ... only for triangles with at least this many nonzeros per row on average
   int64_t cd_max_nnz = 0;        // ... and nonzeros per component (0 = no limit): spreads heavy rows over more units
+  int64_t cd_sparse_max_depth = 64;  // ... only for triangles with at most this many wavefronts
+  int64_t cd_sparse_rows = 192;  // sparse-own plans (BandPlan::cd_sparse) for the triangles below cd_min_row_nnz: rows per
+                                 // component (0 = those triangles keep the depth-cut flag bands)
   int64_t top_max = 4096;        // combined top operator (choose_top): at most this many rows (0 = off)
   int64_t top_few_wgs = 96;      // ... made of the last bands of L's plan that have at most this many workgroups
   double dense_max_growth = 1e4; // ... and so do bands whose block inverses grow beyond this
@@ -514,9 +527,15 @@ BandPlan plan_bands(const Csr<T> &A, const Schedule &S, bool lower, const BandOp
 // reverse order: a row's sources lie in the same component or in a pass that ran earlier.
 // ---------------------------------------------------------------------------------------------
 template <class T>
-BandPlan plan_bands_cd(const Csr<T> &A, const Schedule &S, bool lower, const BandOptions &opt,
-                       const std::vector<uint8_t> *top = nullptr) {
+BandPlan plan_bands_cd(const Csr<T> &A, const Schedule &S, bool lower, const BandOptions &opt_,
+                       const std::vector<uint8_t> *top = nullptr, bool sparse = false) {
+  BandOptions opt = opt_;
+  if (sparse) {  // own nonzeros stay sparse and LDS-resident: cap them, and the rows, per component
+    opt.cd_rows = opt_.cd_sparse_rows;
+    opt.cd_max_nnz = kCdOwnCap - 64;
+  }
   BandPlan P;
+  P.cd_sparse = sparse;
   const int64_t m = A.nrows;
   std::vector<int32_t> depth((size_t)m);
   for (int64_t w = 0; w < S.nwf(); ++w)
@@ -672,15 +691,24 @@ BandPlan plan_bands_cd(const Csr<T> &A, const Schedule &S, bool lower, const Ban
     {
       std::vector<std::vector<int32_t>> packed;
       std::vector<int32_t> bag;
+      // (sparse plans bag everything up to half a component; a pass with few rows gets smaller bags, so that its
+      //  gathers are spread over the whole chip instead of a few dozen workgroups)
+      const size_t small = sparse ? (size_t)opt.cd_rows / 2 : 8;
+      const size_t bagcap = sparse ? std::max<size_t>(16, std::min<size_t>((size_t)opt.cd_rows, rows.size() / 256)) : 32;
+      int64_t bagw = 0;
       for (auto &r : crow) {
-        if ((int64_t)r.size() > 8) {
+        if (r.size() > small) {
           packed.push_back(std::move(r));
           continue;
         }
-        if (bag.size() + r.size() > 32) {
+        int64_t rw = 0;
+        for (int32_t i : r) rw += A.ptr[(size_t)i + 1] - A.ptr[(size_t)i];
+        if (!bag.empty() && (bag.size() + r.size() > bagcap || (sparse && bagw + rw > opt.cd_max_nnz))) {
+          bagw = 0;
           packed.push_back(std::move(bag));
           bag.clear();
         }
+        bagw += rw;
         bag.insert(bag.end(), r.begin(), r.end());
       }
       if (!bag.empty()) packed.push_back(std::move(bag));
@@ -695,7 +723,7 @@ BandPlan plan_bands_cd(const Csr<T> &A, const Schedule &S, bool lower, const Ban
     for (int64_t c = 0; c < nc; ++c) idx[(size_t)c] = c;
     std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return cw[(size_t)a] > cw[(size_t)b]; });
     // workgroups: one component each up to max_wgs; beyond that the lightest are chained onto shared workgroups
-    const int64_t nw = std::min<int64_t>(nc, std::max<int64_t>(1, opt.max_wgs));
+    const int64_t nw = std::min<int64_t>(nc, std::max<int64_t>(1, 8 * opt.max_wgs));  // (the hardware balances them)
     std::vector<std::vector<int64_t>> wgc((size_t)nw);
     {
       std::vector<std::pair<int64_t, int64_t>> heap;
@@ -759,14 +787,19 @@ inline void put_operand(double *base, int64_t plane, int64_t idx, const zdouble 
   base[plane + idx] = v.imag();
 }
 
-// Packed gather streams and descriptors of the component-dense bands (BandPlan::mid_k / mid_lrow / cd_desc).  The
+// Packed gather streams and descriptors of the component-dense bands (BandPlan::mid_k / mid_lrow / cd_desc); call it
+// after plan_dense_blocks (the descriptors carry the inverse offsets).  The
 // rows of a component are dealt to the workgroup's 16 waves as CONTIGUOUS chunks balanced by (entries + rows); a wave
 // initialises its rows' right-hand sides in LDS and subtracts its entries, no other wave touches those rows in phase 1.
-inline void build_cd_streams(BandPlan &P) {
+inline void build_cd_streams(BandPlan &P, const std::vector<int32_t> &aptr /* row pointer of the slot-ordered CSR */) {
   const size_t ngrp = P.grp_slot_ptr.size() - 1;
   P.cd_desc.assign(ngrp * (size_t)kCdDescWords, 0);
   P.mid_k.clear();
   P.mid_lrow.clear();
+  P.own_k.clear();
+  P.own_lsrc.clear();
+  P.own_lvl.clear();
+  P.own_rptr.clear();
   if (P.band_cd.empty()) return;
   constexpr int NW = 16;
   for (int64_t b = 0; b < P.nbands(); ++b) {
@@ -811,6 +844,35 @@ inline void build_cd_streams(BandPlan &P) {
         }
         wrow[NW] = (uint8_t)nb;
         wmid[NW] = (uint16_t)nmid;
+        if (!P.cd_sparse) continue;
+        // own stream: the rows' nonzeros inside the component, row offsets, and the depth levels (a row's level =
+        // 1 + the deepest own source; rows are in dependency order, so one sweep suffices -- and levels must be
+        // contiguous row ranges: the rows were sorted by the triangle's depth, which dominates the own depth only
+        // up to ties, so the level of a row is forced to be at least its predecessor's)
+        const int64_t own0 = (int64_t)P.own_k.size(), orp0 = (int64_t)P.own_rptr.size(), lvl0 = (int64_t)P.own_lvl.size();
+        std::vector<int32_t> lev((size_t)nb, 0);
+        int32_t cur = 0;
+        P.own_lvl.push_back(0);
+        for (int32_t r = 0; r < nb; ++r) {
+          P.own_rptr.push_back((uint16_t)((int64_t)P.own_k.size() - own0));
+          int32_t need = 0;
+          for (int32_t k = P.csplit[(size_t)(s0 + r)]; k < aptr[(size_t)(s0 + r) + 1]; ++k) {
+            const int32_t q = P.srcslot[(size_t)k] - s0;
+            P.own_k.push_back(k);
+            P.own_lsrc.push_back((uint8_t)q);
+            need = std::max(need, lev[(size_t)q] + 1);
+          }
+          if (need > cur) {  // a new level starts at this row
+            cur = need;
+            P.own_lvl.push_back((uint8_t)r);
+          }
+          lev[(size_t)r] = cur;
+        }
+        P.own_rptr.push_back((uint16_t)((int64_t)P.own_k.size() - own0));
+        P.own_lvl.push_back((uint8_t)nb);
+        const int64_t nown = (int64_t)P.own_k.size() - own0, nlvl = (int64_t)P.own_lvl.size() - lvl0 - 1;
+        if (nown > kCdOwnCap) throw Error(4, "internal error: sparse component with too many own nonzeros");
+        dsc[20] = (int32_t)own0, dsc[21] = (int32_t)nown, dsc[22] = (int32_t)orp0, dsc[23] = (int32_t)lvl0, dsc[24] = (int32_t)nlvl;
       }
   }
 }
@@ -827,7 +889,9 @@ int64_t plan_dense_blocks(BandPlan &P, const BandOptions &opt) {
   int64_t total = 0;
   P.grp_inv_off.assign(P.grp_slot_ptr.size() - 1, -1);
   for (int64_t b = 0; b < P.nbands(); ++b) {
-    if (!P.band_cd.empty() && P.band_cd[(size_t)b]) {  // component-dense band: one inverse per component (group)
+    if (!P.band_cd.empty() && P.band_cd[(size_t)b] && P.cd_sparse) {
+      // sparse-own components: solved in LDS, nothing to invert
+    } else if (!P.band_cd.empty() && P.band_cd[(size_t)b]) {  // component-dense band: one inverse per component (group)
       for (int32_t g = P.band_wg_ptr[(size_t)b]; g < P.band_wg_ptr[(size_t)b + 1]; ++g)
         for (int32_t c = P.wg_grp_ptr[(size_t)g]; c < P.wg_grp_ptr[(size_t)g + 1]; ++c) {
           const int32_t r0 = P.grp_slot_ptr[(size_t)c], r1 = P.grp_slot_ptr[(size_t)c + 1];
@@ -850,7 +914,6 @@ int64_t plan_dense_blocks(BandPlan &P, const BandOptions &opt) {
     }
     P.band_blk_ptr.push_back((int32_t)P.blk_slot0.size());
   }
-  build_cd_streams(P);
   return total;
 }
 inline int64_t dense_block_elems(int64_t nb, bool cplx) { return (cplx ? 2 : 1) * plane_elems(nb, round_up32(nb)); }
@@ -953,6 +1016,16 @@ void finish_band_plan(BandPlan &P, Csr<T> &A /* rows in slot order */, const Ban
                  !P.band_cd[(size_t)b - 1] && wgs_prev <= opt.fuse_max_wgs)
         P.band_fused[(size_t)b] = 1;
     }
+  // ... and only where there IS something to carry: a band none of whose nonzeros is older than its predecessor would
+  // pay a pass over all its rows (the carrying pass does the first touch) for nothing
+  for (int64_t b = 1; b < nb_; ++b) {
+    if (!P.band_fused[(size_t)b]) continue;
+    const int32_t prev0 = band_first_slot(b - 1), s0b = band_first_slot(b);
+    const int32_t s1b = b + 1 < nb_ ? band_first_slot(b + 1) : (int32_t)m;
+    bool older = false;
+    for (int32_t k = A.ptr[(size_t)s0b]; k < A.ptr[(size_t)s1b] && !older; ++k) older = P.srcslot[(size_t)k] < prev0;
+    if (!older) P.band_fused[(size_t)b] = 0;
+  }
   std::vector<int32_t> idx, tcol, tsrc;
   std::vector<T> tval;
   // stable partition of the row's nonzeros [k0, k1) by class (0, 1, 2, ...): relative order inside a class is kept

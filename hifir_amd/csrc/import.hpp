@@ -122,8 +122,18 @@ void analyze_level(HostLevel<T> &H, const BandOptions &band_opt, bool dump = fal
       H.Up = plan_bands_cd(H.Ur, H.Us, false, band_opt);
     }
   } else {
-    H.Lp = use_cd(H.Lr) ? plan_bands_cd(H.Lr, H.Ls, true, band_opt) : plan_bands(H.Lr, H.Ls, true, band_opt);
-    H.Up = use_cd(H.Ur) ? plan_bands_cd(H.Ur, H.Us, false, band_opt) : plan_bands(H.Ur, H.Us, false, band_opt);
+    // thin triangles (level 0 of a PDE hierarchy): the same subtree plan with the components' own nonzeros solved
+    // sparsely in LDS (BandPlan::cd_sparse); exact mode and complex data keep the depth-cut flag bands
+    auto plan_one = [&](const Csr<T> &A, const Schedule &S, bool lower) {
+      if (use_cd(A)) return plan_bands_cd(A, S, lower, band_opt);
+      // (shallow triangles only: inside a component the sparse substitution pays a barrier per depth level)
+      if (band_opt.cd_rows > 0 && band_opt.cd_sparse_rows > 0 && band_opt.dense_block > 0 && A.nrows >= 4096 &&
+          S.nwf() <= band_opt.cd_sparse_max_depth)
+        return plan_bands_cd(A, S, lower, band_opt, nullptr, true);
+      return plan_bands(A, S, lower, band_opt);
+    };
+    H.Lp = plan_one(H.Lr, H.Ls, true);
+    H.Up = plan_one(H.Ur, H.Us, false);
   }
   double t2 = now();
   H.Lr = permute_rows(H.Lr, H.Lp.order);
@@ -133,6 +143,8 @@ void analyze_level(HostLevel<T> &H, const BandOptions &band_opt, bool dump = fal
   double t3 = now();
   H.Ltinv_elems = plan_dense_blocks<T>(H.Lp, band_opt);
   H.Utinv_elems = plan_dense_blocks<T>(H.Up, band_opt);
+  build_cd_streams(H.Lp, H.Lr.ptr);
+  build_cd_streams(H.Up, H.Ur.ptr);
   if (!dump) return;
   std::fprintf(stderr, "ANALYZE m=%ld: schedule %.2f s, band plan %.2f s, permute+finish %.2f s, block cutting %.2f s\n",
                (long)H.m, t1 - t0, t2 - t1, t3 - t2, now() - t3);
@@ -286,7 +298,7 @@ void check_band_plan(const BandPlan &P, const Csr<T> &A, const char *what, size_
         for (int32_t c = P.wg_grp_ptr[(size_t)g]; c < P.wg_grp_ptr[(size_t)g + 1]; ++c) {
           const int32_t nb = P.grp_slot_ptr[(size_t)c + 1] - P.grp_slot_ptr[(size_t)c];
           if (nb < 1 || nb > cd_rows_limit) fail("component size", c);
-          if (P.grp_inv_off[(size_t)c] < 0) fail("component without an inverse", c);
+          if (!P.cd_sparse && P.grp_inv_off[(size_t)c] < 0) fail("component without an inverse", c);
         }
       } else if (P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g + 1]] - P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]] > 16384 &&
                  !P.band_dense[(size_t)b])

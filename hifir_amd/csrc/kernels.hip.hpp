@@ -1632,7 +1632,7 @@ __global__ void __launch_bounds__(NW * 64) k_tri_gemm_d(int nb, const double *__
 // carried prefix of the NEXT band, exactly as in k_trsv_band_p.  The summation order differs from the reference's
 // (tolerance-level, like every block-dense band); exact mode never plans such bands.
 // ---------------------------------------------------------------------------------------------
-template <bool LOWER>
+template <bool LOWER, bool SPARSE>
 __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__restrict__ wg_grp_ptr,
                                                   const int32_t *__restrict__ cd_desc, const int32_t *__restrict__ ptr,
                                                   const int32_t *__restrict__ split, const int32_t *__restrict__ col,
@@ -1641,7 +1641,9 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
                                                   const double *__restrict__ tinv, const int32_t *__restrict__ mid_col,
                                                   const double *__restrict__ mid_val, const uint8_t *__restrict__ mid_lrow,
                                                   int first_u, int32_t n_band, int32_t ps0, int32_t ps1, int32_t single_c0,
-                                                  int32_t lds_rows, int dbg, FirstL<double> fl) {
+                                                  int32_t lds_rows, int dbg, FirstL<double> fl,
+                                                  const double *__restrict__ own_val, const uint8_t *__restrict__ own_lsrc,
+                                                  const uint16_t *__restrict__ own_rptr, const uint8_t *__restrict__ own_lvl) {
   extern __shared__ double cd_tbuf[];  // [lds_rows][64] right-hand sides, then lds_rows row ids
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
@@ -1673,8 +1675,13 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
   }
   const int kq = lane >> 4;
   int32_t *cd_rowid = reinterpret_cast<int32_t *>(cd_tbuf + (size_t)lds_rows * 64);  // the component's row ids, for phase 2
+  // SPARSE: the component's own nonzeros (value, local source row), their row offsets and the depth levels
+  double *ow_val = reinterpret_cast<double *>(cd_rowid + ((lds_rows + 1) & ~1));
+  uint8_t *ow_src = reinterpret_cast<uint8_t *>(ow_val + 4096);
+  uint16_t *ow_rptr = reinterpret_cast<uint16_t *>(ow_src + 4096);
+  uint8_t *ow_lvl = reinterpret_cast<uint8_t *>(ow_rptr + 260);
   for (int32_t c = c_first; c < c_last; ++c) {
-    const int32_t *dsc = cd_desc + (int64_t)c * 20;
+    const int32_t *dsc = cd_desc + (int64_t)c * 28;
     const int32_t s0 = dsc[0], nb = dsc[1], mid0 = dsc[2];
     const int64_t inv_off = ((int64_t)(uint32_t)dsc[5] << 32) | (uint32_t)dsc[4];
     const uint8_t *wrow = reinterpret_cast<const uint8_t *>(dsc + 6);
@@ -1689,7 +1696,16 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
     const int q_first = wrow4 * 4 + ((wrow4 & 1) ? 3 - wcol4 : wcol4);  // snake order over the SIMDs (wave % 4)
     constexpr int KU = 8;
     double a0[KU], a1[KU];
-    if (q_first < nunits) {
+    if (SPARSE) {  // own nonzeros, row offsets and levels into LDS (coalesced, in flight during phase 1)
+      const int32_t own0 = dsc[20], nown = dsc[21], orp0 = dsc[22], lvl0 = dsc[23], nlvl = dsc[24];
+      for (int32_t t = (int32_t)threadIdx.x; t < nown; t += (int32_t)blockDim.x) {
+        ow_val[t] = own_val[own0 + t];
+        ow_src[t] = own_lsrc[own0 + t];
+      }
+      for (int32_t t = (int32_t)threadIdx.x; t <= nb; t += (int32_t)blockDim.x) ow_rptr[t] = own_rptr[orp0 + t];
+      for (int32_t t = (int32_t)threadIdx.x; t <= nlvl; t += (int32_t)blockDim.x) ow_lvl[t] = own_lvl[lvl0 + t];
+    }
+    if (!SPARSE && q_first < nunits) {
       const double *ap_ = Ac + ((int64_t)(S - 1 - (q_first >> 1)) * lda) * 16 + (lane & 15) + (int64_t)kq * 16;
 #pragma unroll
       for (int u = 0; u < KU; ++u) a0[u] = ap_[u * 64];
@@ -1771,6 +1787,24 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
     }
     if (cur_r >= 0) cd_tbuf[(cur_r << 6) + lane] = acc;
     __syncthreads();
+    if (SPARSE) {
+      // ---- phase 2, sparse: substitution inside LDS, depth level by depth level.  The rows of a level are independent;
+      // every own source sits in an earlier level (host.hpp build_cd_streams).  A wave takes a row at a time: the row's
+      // (value, source) pairs come from LDS, so do the source rows -- no global access on the dependent path.
+      const int nlvl = dsc[24];
+      for (int lv = 0; lv < nlvl; ++lv) {
+        const int r_lo = ow_lvl[lv], r_hi = ow_lvl[lv + 1];
+        for (int r = r_lo + wave; r < r_hi; r += nw) {
+          double a2 = cd_tbuf[(r << 6) + lane];
+          const int eb = ow_rptr[r], ee = ow_rptr[r + 1];
+          for (int e = eb; e < ee; ++e) a2 = a2 - ow_val[e] * cd_tbuf[((int)ow_src[e] << 6) + lane];
+          if (ee > eb) cd_tbuf[(r << 6) + lane] = a2;
+          x[((int64_t)cd_rowid[r] << 6) + lane] = a2;
+        }
+        __syncthreads();
+      }
+      continue;
+    }
     // ---- phase 2: x = Tinv * t (units are handed out heaviest first)
     for (int q = q_first; q < ((dbg & 2) ? 0 : nunits); q += nw) {
       const int strip = S - 1 - (q >> 1), ch = q & 1;

@@ -96,9 +96,10 @@ static int run(int64_t m, int fan, int64_t dense_block) {
 // ([ptr, csplit)), then the product with the component's explicit inverse read from the operand layout the kernels
 // use; dense rest bands block by block -- and compared with the plain sequential substitution.
 template <class T>
-static int run_cd(int64_t m, int fan, int64_t cd_rows, int64_t dense_block) {
+static int run_cd(int64_t m, int fan, int64_t cd_rows, int64_t dense_block, bool sparse = false) {
   BandOptions opt;
   opt.cd_rows = cd_rows;
+  opt.cd_sparse_rows = cd_rows;
   opt.dense_block = dense_block;
   opt.max_wg_rows = 16384;
   int bad = 0;
@@ -118,10 +119,11 @@ static int run_cd(int64_t m, int fan, int64_t cd_rows, int64_t dense_block) {
       R = ccs_to_csr(U, true);
     }
     Schedule S = level_schedule(R, !upper);
-    BandPlan P = plan_bands_cd(R, S, !upper, opt);
+    BandPlan P = plan_bands_cd(R, S, !upper, opt, nullptr, sparse);
     Csr<T> Rs = permute_rows(R, P.order);
     finish_band_plan(P, Rs, opt);  // (re-checks every dependency against the executed order, throws otherwise)
     const int64_t elems = plan_dense_blocks<T>(P, opt);
+    build_cd_streams(P, Rs.ptr);
     std::vector<double> ops((size_t)elems, 0.0);
     for (size_t q = 0; q < P.blk_slot0.size(); ++q) build_dense_block(P, Rs, q, ops.data() + P.blk_inv_off[q], true);
     // reference: plain substitution in the natural order
@@ -196,6 +198,42 @@ static int run_cd(int64_t m, int fan, int64_t cd_rows, int64_t dense_block) {
           x[(size_t)Rs.rowid[(size_t)(r0 + r)]] = acc;
         }
       }
+      if (P.band_cd[(size_t)bnd] && P.cd_sparse) {
+        // sparse-own components: old sources, then substitution inside the component level by level, exactly as the
+        // kernel walks the own stream (build_cd_streams): every source of a level's rows lies in an earlier level
+        for (int32_t gg = P.band_wg_ptr[(size_t)bnd]; gg < P.band_wg_ptr[(size_t)bnd + 1]; ++gg)
+          for (int32_t c = P.wg_grp_ptr[(size_t)gg]; c < P.wg_grp_ptr[(size_t)gg + 1]; ++c) {
+            const int32_t *dsc = &P.cd_desc[(size_t)c * kCdDescWords];
+            const int32_t r0 = dsc[0], nb = dsc[1], own0 = dsc[20], nown = dsc[21], orp0 = dsc[22], lvl0 = dsc[23], nlvl = dsc[24];
+            ++ncomp, maxcomp = std::max<int64_t>(maxcomp, nb);
+            std::vector<T> t((size_t)nb);
+            for (int32_t r = 0; r < nb; ++r) {
+              const int32_t s = r0 + r;
+              T acc = x[(size_t)Rs.rowid[(size_t)s]];
+              for (int32_t k = Rs.ptr[(size_t)s]; k < P.csplit[(size_t)s]; ++k) acc -= Rs.val[(size_t)k] * x[(size_t)Rs.col[(size_t)k]];
+              t[(size_t)r] = acc;
+            }
+            if (P.own_rptr[(size_t)orp0] != 0 || P.own_rptr[(size_t)(orp0 + nb)] != nown || P.own_lvl[(size_t)lvl0] != 0 ||
+                P.own_lvl[(size_t)(lvl0 + nlvl)] != nb)
+              ++bad;
+            std::vector<uint8_t> done((size_t)nb, 0);
+            for (int32_t lv = 0; lv < nlvl; ++lv) {
+              const int32_t lo = P.own_lvl[(size_t)(lvl0 + lv)], hi = P.own_lvl[(size_t)(lvl0 + lv + 1)];
+              std::vector<T> fresh;
+              for (int32_t r = lo; r < hi; ++r) {
+                T acc = t[(size_t)r];
+                for (int32_t e = P.own_rptr[(size_t)(orp0 + r)]; e < P.own_rptr[(size_t)(orp0 + r + 1)]; ++e) {
+                  const int32_t q = P.own_lsrc[(size_t)(own0 + e)];
+                  if (!done[(size_t)q] || P.srcslot[(size_t)P.own_k[(size_t)(own0 + e)]] != r0 + q) ++bad;  // (an earlier level)
+                  acc -= Rs.val[(size_t)P.own_k[(size_t)(own0 + e)]] * t[(size_t)q];
+                }
+                fresh.push_back(acc);
+              }
+              for (int32_t r = lo; r < hi; ++r) t[(size_t)r] = fresh[(size_t)(r - lo)], done[(size_t)r] = 1;
+            }
+            for (int32_t r = 0; r < nb; ++r) x[(size_t)Rs.rowid[(size_t)(r0 + r)]] = t[(size_t)r];
+          }
+      }
     }
     double err = 0.0, nrm = 0.0;
     for (int64_t i = 0; i < m; ++i) err = std::max(err, abs_(x[(size_t)i] - xr[(size_t)i])), nrm = std::max(nrm, abs_(xr[(size_t)i]));
@@ -213,6 +251,8 @@ int main() {
   bad += run_cd<double>(9000, 3, 64, 512);
   bad += run_cd<double>(20000, 6, 192, 2048);
   bad += run_cd<double>(700, 1, 32, 64);
+  bad += run_cd<double>(20000, 2, 192, 2048, true);  // sparse-own components (thin triangles)
+  bad += run_cd<double>(6000, 1, 64, 512, true);
   bad += run<double>(3000, 2, 2048);
   bad += run<double>(9000, 3, 2048);
   bad += run<double>(9000, 3, 512);
