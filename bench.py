@@ -175,6 +175,8 @@ def main():
                          "(examples/advanced/demo_gmreshif.cpp:63-65)")
     ap.add_argument("--secondary", type=int, default=1, help="also time the other parameter set (N=1 only)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of each CPU baseline sample")
+    ap.add_argument("--extras", type=int, default=1, help="0: skip the side measurements (exact engine mode, 128-column "
+                                                          "batch, nrhs = 1) -- counter passes want the timed kernels only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                                                       "rehearse the N > 1 flow on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
@@ -260,7 +262,7 @@ def main():
         # BASELINE configs[1]: the same hierarchy with ONE right-hand side (latency-bound; reported, not the metric)
         b1 = B[:, :1].contiguous()
         x1 = torch.empty_like(b1)
-        nrhs1_ms = M.time_apply(b1, x1, warmup=1, reps=5) if world == 1 else None
+        nrhs1_ms = M.time_apply(b1, x1, warmup=1, reps=5) if (world == 1 and args.extras) else None
         st = M.stats()
         # one end-of-batch gather of the solution blocks (not in the per-step data path)
         gather_ms = None
@@ -298,7 +300,7 @@ def main():
         # the EXACT engine mode (HIFIR_AMD_DENSE_BLOCK=0: reference summation order everywhere, thin runs on one
         # workgroup) on the same hierarchy: its time next to the default (fast) mode's, and bit-exactness of column 0
         exact = None
-        if rank == 0 and want_cpu and levels is not None:
+        if rank == 0 and want_cpu and levels is not None and args.extras:
             os.environ["HIFIR_AMD_DENSE_BLOCK"] = "0"
             try:
                 Me = hifir_amd.HIF.from_levels(levels, max_nrhs=args.nrhs, device=local_rank)
@@ -316,7 +318,7 @@ def main():
         # arena + stream, shared matrices) and hide each other's latency-bound phases; reported next to the
         # metric, never as the metric
         pipelined = None
-        if world == 1 and want_cpu:
+        if world == 1 and want_cpu and args.extras:
             B2 = torch.cat([B, B.flip(1)], dim=1).contiguous()
             X2 = torch.empty_like(B2)
             M.solve_mrhs(B2, X2)

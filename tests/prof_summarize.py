@@ -59,22 +59,21 @@ def pmc(path, counter):
 # the same command vs the HIP-event time bench.py reports in its JSON line
 kt = one("stats/*/*kernel_trace.csv")
 if kt and os.path.exists(bj):
-    rows = sorted(csv.DictReader(open(kt)), key=lambda r: int(r["Start_Timestamp"]))
+    rows = sorted((r for r in csv.DictReader(open(kt)) if "hifamd" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
     # one apply = from the level-0 S1 gather (a k_gather_scale NOT preceded by the S3 k_spmm_epi of the
     # level above) to the level-0 S7 scatter (a k_scatter_scale NOT followed by an S5 k_spmm_epi).
     # Graph replays run the nodes back to back, so the span is the sum of the node durations.  The
     # primary workload's applies come first in the run (bench.py order).
-    spans, cnts, start, n = [], [], None, 0
+    # (S1 is fused into the first L kernel since round 2: an apply starts with whatever follows the previous apply's
+    #  level-0 scatter, and ends with a k_scatter_scale that is NOT followed by an S5 product.)
+    is_spmm = lambda nm: "k_spmm_epi" in nm or "k_spmm_tile" in nm
+    spans, cnts, bounds, start = [], [], [], 0
     for i, r in enumerate(rows):
-        name = r["Kernel_Name"]
-        if "k_gather_scale" in name and (i == 0 or "k_spmm_epi" not in rows[i - 1]["Kernel_Name"]):
-            start, n = int(r["Start_Timestamp"]), 0
-        n += 1
-        if start is not None and "k_scatter_scale" in name and \
-                (i + 1 == len(rows) or "k_spmm_epi" not in rows[i + 1]["Kernel_Name"]):
-            spans.append((int(r["End_Timestamp"]) - start) / 1e6)
-            cnts.append(n)
-            start = None
+        if "k_scatter_scale" in r["Kernel_Name"] and (i + 1 == len(rows) or not is_spmm(rows[i + 1]["Kernel_Name"])):
+            spans.append((int(r["End_Timestamp"]) - int(rows[start]["Start_Timestamp"])) / 1e6)
+            cnts.append(i - start + 1)
+            bounds.append((start, i))
+            start = i + 1
     first = [s_ for s_, c_ in zip(spans, cnts) if c_ == cnts[0]]
     cnt = cnts
     line = json.loads(open(bj).read().strip().splitlines()[-1])
@@ -90,31 +89,25 @@ if kt and os.path.exists(bj):
     sb = line["roofline"].get("algorithmic_bytes_by_stage")
     if sb:
         # (k_strip_gemm_d is the combined top operator of a level's triangular solves)
-        group = {"k_gather_scale": "permute", "k_scatter_scale": "permute", "k_spmm_epi": "schur", "k_trsv_band": "ldu",
+        group = {"k_gather_scale": "permute", "k_scatter_scale": "permute", "k_spmm_epi": "schur", "k_spmm_tile": "schur", "k_trsv_band": "ldu",
                  "k_band_cd": "ldu", "k_trsv_wide": "ldu", "k_thin_update": "ldu", "k_tri_gemm_d": "ldu",
                  "k_strip_gemm_d": "ldu", "k_dense_gemm": "dense", "k_row_gather": "dense"}
         tms = {g: 0.0 for g in sb}
         per_kernel = {}
         napp = 0
-        start = None
-        for i, r in enumerate(rows):
-            name = r["Kernel_Name"]
-            if "k_gather_scale" in name and (i == 0 or "k_spmm_epi" not in rows[i - 1]["Kernel_Name"]):
-                start = i
-            if start is not None and "k_scatter_scale" in name and \
-                    (i + 1 == len(rows) or "k_spmm_epi" not in rows[i + 1]["Kernel_Name"]):
-                if i - start + 1 == cnts[0]:
-                    napp += 1
-                    for q in rows[start:i + 1]:
-                        d_ = (int(q["End_Timestamp"]) - int(q["Start_Timestamp"])) / 1e6
-                        for k_, g_ in group.items():
-                            if k_ in q["Kernel_Name"]:
-                                tms[g_] += d_
-                                e = per_kernel.setdefault(k_, [0, 0.0])
-                                e[0] += 1
-                                e[1] += d_
-                                break
-                start = None
+        for (a_, b_) in bounds:
+            if b_ - a_ + 1 != cnts[0]:
+                continue
+            napp += 1
+            for q in rows[a_:b_ + 1]:
+                d_ = (int(q["End_Timestamp"]) - int(q["Start_Timestamp"])) / 1e6
+                for k_, g_ in group.items():
+                    if k_ in q["Kernel_Name"]:
+                        tms[g_] += d_
+                        e = per_kernel.setdefault(k_, [0, 0.0])
+                        e[0] += 1
+                        e[1] += d_
+                        break
         stages = {g: {"algorithmic_bytes": sb[g], "ms_per_apply": tms[g] / napp,
                       "achieved_GBs": sb[g] / (tms[g] / napp * 1e-3) / 1e9 if tms[g] else None,
                       "frac_of_8TBs": sb[g] / (tms[g] / napp * 1e-3) / 8e12 if tms[g] else None} for g in sb}
@@ -129,7 +122,7 @@ if f and w:
     nf, bf = pmc(f, "FETCH_SIZE")
     nw, bw = pmc(w, "WRITE_SIZE")
     tf, tw = sum(bf.values()), sum(bw.values())
-    out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --secondary 0",
+    out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --secondary 0 --extras 0",
            "applies_profiled": [nf, nw], "unit": "KiB per 64-RHS apply (default-parameter hierarchy)",
            "FETCH_SIZE_KiB": tf, "WRITE_SIZE_KiB": tw,
            "hbm_bytes_per_apply_corrected": (2.0 * tf + tw) * 1024.0,

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 $R/bench.py \
   > $OUT/bench_stats.json 2> $OUT/bench_stats.err
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch --output-format csv -- python3 $R/bench.py \
-  --steps 3 --warmup 1 --secondary 0 > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
+  --steps 3 --warmup 1 --secondary 0 --extras 0 > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write --output-format csv -- python3 $R/bench.py \
-  --steps 3 --warmup 1 --secondary 0 > $OUT/bench_write.json 2> $OUT/bench_write.err
+  --steps 3 --warmup 1 --secondary 0 --extras 0 > $OUT/bench_write.json 2> $OUT/bench_write.err
 tail -c 600 $OUT/bench_plain.json
