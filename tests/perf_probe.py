@@ -26,17 +26,21 @@ if mode.endswith("-3d"):  # e.g. "tuned-3d": 3-D 7-pt Poisson nx^3 (BASELINE con
     A = (sp.kron(sp.kron(I, I), T) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(T, I), I)).tocsr()
     A.sort_indices()
     mode = mode[:-3]
+elif mode == "kkt":  # BASELINE config 5: complex saddle point (tests/util.py stokes_kkt), nx = 816 -> 1,997,568 rows
+    from util import stokes_kkt
+
+    A = stokes_kkt(nx)
 else:
     A = poisson2d(nx)
-cplx = mode.endswith("-z")  # e.g. "default-z": complex shifted Laplacian (BASELINE config 5 stand-in)
-if cplx:
+cplx = mode.endswith("-z") or mode == "kkt"  # e.g. "default-z": complex shifted Laplacian (BASELINE config 5 stand-in)
+if cplx and mode != "kkt":
     import scipy.sparse as sp
 
     A = (A - (0.3 + 0.2j) * sp.identity(A.shape[0])).tocsr()
     A.sort_indices()
     mode = mode[:-2]
 n = A.shape[0]
-P = None if mode == "default" else ref.make_params(tau=1e-2, kappa=5.0, alpha=3.0)
+P = None if mode == "default" else ref.make_params(tau=1e-2, kappa=3.0 if mode == "kkt" else 5.0, alpha=3.0)
 t0 = time.time()
 R = ref.RefHIF(A.indptr, A.indices, A.data, P)
 t1 = time.time()
