@@ -405,6 +405,7 @@ class Engine : public EngineBase {
 
   ~Engine() override {
     if (stream) (void)hipSetDevice(device);
+    if (gm_ctl_host) (void)hipHostFree(gm_ctl_host);
 #ifdef HIFAMD_PROBE
     if (probe.p && getenv("HIFIR_AMD_PROBE_OUT")) {
       std::vector<unsigned long long> h(probe.bytes / 8);
@@ -1589,185 +1590,143 @@ class Engine : public EngineBase {
   // ---- right-preconditioned restarted GMRES, batched over columns ----------------------------------
   // The reference's driver (examples/advanced/gmres.hpp:19-123: MGS Arnoldi, Givens rotations, relative
   // residual |y_{j+1}| / ||b||, flags 0 converged / 1 stagnated / 2 reached maxit) run for up to 64
-  // columns in lock step: the vectors stay in HBM, one apply + one SpMM + j+1 fused column-dots per
-  // inner step serve every column, and only the per-column scalars (Hessenberg column, rotations,
-  // residuals) live on the host.  A column that leaves the inner loop keeps a zero basis vector.
-  void col_dots(const double *x, int64_t ldx, const double *y, int64_t ldy, int64_t n, int nc, double *out) {
-    const int nblk = 512;
-    if (ir_part.bytes < (size_t)nblk * 64 * sizeof(double)) ir_part.alloc((size_t)nblk * 64 * sizeof(double));
-    std::vector<double> part((size_t)nblk * nc);
-    hipLaunchKernelGGL(k_coldot_partial, dim3(nblk), dim3(256), 0, stream, n, nc, x, ldx, y, ldy, ir_part.as<double>());
-    HIP_OK(hipMemcpyAsync(part.data(), ir_part.p, (size_t)nblk * nc * sizeof(double), hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipStreamSynchronize(stream));
-    for (int c = 0; c < nc; ++c) {
-      double tot = 0.0;
-      for (int b = 0; b < nblk; ++b) tot += part[(size_t)b * nc + c];
-      out[c] = tot;
-    }
+  // columns in lock step.  Everything lives in HBM: the vectors, the Krylov basis, AND the per-column
+  // scalars (Hessenberg column, rotations, residuals, iteration counts, flags: GmState, kernels.hip.hpp).
+  // One inner step = one batched apply + one SpMM + j+2 fused axpy/dot passes (k_gm_step) each followed
+  // by a one-workgroup finishing kernel, and ONE 12-byte read-back (how many columns are still active).
+  // A column that leaves the inner loop keeps a zero basis vector.  Real and complex handles (Hermitian
+  // inner product; for real data identical to the reference's hif::inner).
+  static constexpr int kGmBlocks = 1024;
+  GmState<D> gm_state(int nc, int restart, int maxit, double rtol) {
+    const size_t rs = (size_t)restart;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+      const size_t o = off;
+      off += (bytes + 255) & ~(size_t)255;
+      return o;
+    };
+    const size_t o_w2 = take(nc * rs * sizeof(D)), o_jc = take(nc * rs * sizeof(D)), o_js = take(nc * rs * sizeof(double)),
+                 o_y = take(nc * (rs + 1) * sizeof(D)), o_R = take(nc * rs * rs * sizeof(D)),
+                 o_res = take(nc * sizeof(double)), o_b0 = take(nc * sizeof(double)), o_int = take(6 * (size_t)nc * sizeof(int)),
+                 o_al = take(nc * sizeof(D)), o_ctl = take(4 * sizeof(int));
+    if (gm_alpha.bytes < off) gm_alpha.alloc(off);
+    HIP_OK(hipMemsetAsync(gm_alpha.p, 0, off, stream));
+    char *b = gm_alpha.as<char>();
+    GmState<D> S;
+    S.w2 = (D *)(b + o_w2);
+    S.Jc = (D *)(b + o_jc);
+    S.Js = (double *)(b + o_js);
+    S.y = (D *)(b + o_y);
+    S.R = (D *)(b + o_R);
+    S.resid = (double *)(b + o_res);
+    S.beta0 = (double *)(b + o_b0);
+    int *ib = (int *)(b + o_int);
+    S.iter = ib;
+    S.flag = ib + nc;
+    S.active = ib + 2 * nc;
+    S.jfin = ib + 3 * nc;
+    S.done = ib + 4 * nc;
+    S.sweeps = ib + 5 * nc;
+    S.alpha = (D *)(b + o_al);
+    S.ctl = (int *)(b + o_ctl);
+    S.restart = restart;
+    S.maxit = maxit;
+    S.rtol = rtol;
+    return S;
   }
-  void col_op(int op, int64_t n, int nc, double *y, int64_t ldy, const double *x, int64_t ldx, const double *alpha_host) {
-    // coefficients travel through a small ring of device slots so that consecutive launches never race
-    const size_t slots = 256;
-    if (gm_alpha.bytes < slots * 64 * sizeof(double)) gm_alpha.alloc(slots * 64 * sizeof(double));
-    double *dst = gm_alpha.as<double>() + (size_t)(gm_slot++ % slots) * 64;
-    HIP_OK(hipMemcpyAsync(dst, alpha_host, (size_t)nc * sizeof(double), hipMemcpyHostToDevice, stream));
-    HIP_OK(hipStreamSynchronize(stream));  // alpha_host is pageable and reused by the caller
+  // v -= h q_prev (h = S.alpha, from the previous finish) fused with the reduction against q (nullptr: |v|^2)
+  void gm_step(int64_t n, int nc, D *v, const D *qp, const D *q, const GmState<D> &S) {
+    if (ir_part.bytes < (size_t)kGmBlocks * 64 * sizeof(D)) ir_part.alloc((size_t)kGmBlocks * 64 * sizeof(D));
+    hipLaunchKernelGGL((k_gm_step<D>), dim3(kGmBlocks), dim3(256), 0, stream, n, nc, v, qp, (const D *)S.alpha, q, ir_part.as<D>());
+  }
+  void gm_finish(int nc, int mode, int k, int nirs, const GmState<D> &S) {
+    hipLaunchKernelGGL((k_gm_finish<D>), dim3(1), dim3(256), 0, stream, (const D *)ir_part.as<D>(), kGmBlocks, nc, mode, k, nirs, S);
+  }
+  void gm_colop(int op, int64_t n, int nc, D *y, int64_t ldy, const D *x, int64_t ldx, const GmState<D> &S) {
     int64_t g = (n * nc + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_col_op, dim3((unsigned)g), dim3(256), 0, stream, op, n, nc, y, ldy, x, ldx, (const double *)dst);
+    hipLaunchKernelGGL((k_gm_colop<D>), dim3((unsigned)g), dim3(256), 0, stream, op, n, nc, y, ldy, x, ldx, (const D *)S.alpha);
   }
-  uint64_t gm_slot = 0;
+  int *gm_ctl_host = nullptr;  // pinned: [0] active columns [1] max jfin [2] columns not done
+  void gm_read_ctl(const GmState<D> &S) {
+    if (!gm_ctl_host) HIP_OK(hipHostMalloc((void **)&gm_ctl_host, 4 * sizeof(int), hipHostMallocDefault));
+    HIP_OK(hipMemcpyAsync(gm_ctl_host, S.ctl, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+  }
 
-  void gmres_tile(const double *dB, int64_t ldb, double *dX, int64_t ldx, int nc, int restart, double rtol, int maxit,
+  void gmres_tile(const D *dB, int64_t ldb, D *dX, int64_t ldx, int nc, int restart, double rtol, int maxit,
                   int64_t rank, int *flags, int *iters, bool flexible, int *sweeps) {
     const int64_t n = lv[0]->n;
-    const size_t vec = (size_t)n * nc * sizeof(double);
+    const size_t vec = (size_t)n * nc * sizeof(D);
     if (gm_v.bytes < vec) gm_v.alloc(vec);
     if (gm_w.bytes < vec) gm_w.alloc(vec);
     if (gm_Q.bytes < vec * (size_t)restart) gm_Q.alloc(vec * (size_t)restart);
     // flexible variant (fgmres_hifir, gmres.hpp:127-231): the preconditioned vectors are kept as well
     if (flexible && gm_Z.bytes < vec * (size_t)restart) gm_Z.alloc(vec * (size_t)restart);
-    double *v = gm_v.as<double>(), *w = gm_w.as<double>(), *Q = gm_Q.as<double>(), *Z = gm_Z.as<double>();
+    D *v = gm_v.as<D>(), *w = gm_w.as<D>(), *Q = gm_Q.as<D>(), *Z = gm_Z.as<D>();
     auto Qk = [&](int k) { return Q + (size_t)k * (size_t)n * nc; };
     auto Zk = [&](int k) { return Z + (size_t)k * (size_t)n * nc; };
-    std::vector<int> num_mv((size_t)nc, 0);
-    std::vector<double> beta0, beta, tmp((size_t)nc), alpha((size_t)nc);
-    std::vector<double> y((size_t)nc * (restart + 1)), w2((size_t)nc * restart), R((size_t)nc * restart * restart),
-        J((size_t)nc * restart * 2), resid((size_t)nc, 1.0);
-    std::vector<int> iter((size_t)nc, 0), flag((size_t)nc, 0), jfin((size_t)nc);
-    std::vector<char> done((size_t)nc, 0), active((size_t)nc);
-    col_norms((const D *)dB, ldb, n, nc, beta0);
-    vec_op(0, n, nc, (D *)dX, ldx, nullptr, 0, nullptr, 0);  // x = 0  (:33-34)
-    for (int c = 0; c < nc; ++c) done[(size_t)c] = (beta0[(size_t)c] == 0.0);  // quick return (:36)
+    const GmState<D> S = gm_state(nc, restart, maxit, rtol);
+    int64_t grid = (n * nc + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    vec_op(1, n, nc, v, nc, dB, ldb, nullptr, 0);  // v = b (contiguous copy: the first residual, :52)
+    gm_step(n, nc, v, nullptr, nullptr, S);
+    gm_finish(nc, 3, 0, 0, S);                     // beta0, quick return (:30-36)
+    vec_op(0, n, nc, dX, ldx, nullptr, 0, nullptr, 0);  // x = 0  (:33-34)
+    gm_read_ctl(S);
     const int max_outer = (maxit + restart - 1) / restart;  // :43
-    for (int outer = 0; outer < max_outer; ++outer) {
-      bool any = false;
-      for (int c = 0; c < nc; ++c) any = any || !done[(size_t)c];
-      if (!any) break;
-      if (outer)
-        resid_dev((const D *)dB, ldb, (const D *)dX, ldx, (D *)v, nc, nc);  // v = b - A x  (:48-50)
-      else
-        vec_op(1, n, nc, (D *)v, nc, (const D *)dB, ldb, nullptr, 0);
-      col_norms((const D *)v, nc, n, nc, beta);
-      for (int c = 0; c < nc; ++c) {
-        if (!done[(size_t)c] && beta[(size_t)c] == 0.0) done[(size_t)c] = 1;  // exact solution reached
-        y[(size_t)c * (restart + 1)] = beta[(size_t)c];                        // :54
-        alpha[(size_t)c] = done[(size_t)c] ? 0.0 : beta[(size_t)c];
-        active[(size_t)c] = !done[(size_t)c];
-        jfin[(size_t)c] = -1;
-      }
-      col_op(1, n, nc, Qk(0), nc, v, nc, alpha.data());  // Q(:,0) = v / beta  (:55)
+    for (int outer = 0; outer < max_outer && gm_ctl_host[2] > 0; ++outer) {
+      if (outer) {
+        resid_dev(dB, ldb, (const D *)dX, ldx, v, nc, nc);  // v = b - A x  (:48-50)
+        gm_step(n, nc, v, nullptr, nullptr, S);
+      }  // (outer == 0: the partial sums of |b|^2 are still in place)
+      gm_finish(nc, 2, 0, 0, S);                        // beta, y[0], active mask  (:53-54)
+      gm_colop(1, n, nc, Qk(0), nc, v, nc, S);          // Q(:,0) = v / beta  (:55)
       int j = 0;
       const int nirs = 1 << std::min(outer, 20);  // :157
       for (;;) {
-        vec_op(1, n, nc, (D *)v, nc, (const D *)Qk(j), nc, nullptr, 0);  // :58
         if (flexible) {
-          // w = hifir(A, v, 2^outer sweeps)  (:160); kept in Z (:164)
-          hifir_dev((const D *)v, nc, (D *)w, nc, nc, nirs, nullptr, rank < 0 ? -1 : rank, nullptr);
-          vec_op(1, n, nc, (D *)Zk(j), nc, (const D *)w, nc, nullptr, 0);
-          for (int c = 0; c < nc; ++c)
-            if (active[(size_t)c]) num_mv[(size_t)c] += nirs;
+          // w = hifir(A, Q(:,j), 2^outer sweeps)  (:160); kept in Z (:164)
+          hifir_dev((const D *)Qk(j), nc, w, nc, nc, nirs, nullptr, rank < 0 ? -1 : rank, nullptr);
+          vec_op(1, n, nc, Zk(j), nc, (const D *)w, nc, nullptr, 0);
         } else {
-          solve_dev((const D *)v, nc, (D *)w, nc, nc, rank, nullptr);  // w = M^{-1} v  (:59)
+          solve_dev((const D *)Qk(j), nc, w, nc, nc, rank, nullptr);  // w = M^{-1} Q(:,j)  (:58-59)
         }
-        spmv_dev((const D *)w, nc, (D *)v, nc, nc, nullptr);            // v = A w       (:60)
-        for (int k = 0; k <= j; ++k) {                                   // modified Gram-Schmidt (:63-66)
-          col_dots(v, nc, Qk(k), nc, n, nc, tmp.data());
-          for (int c = 0; c < nc; ++c) {
-            w2[(size_t)c * restart + k] = tmp[(size_t)c];
-            alpha[(size_t)c] = -tmp[(size_t)c];
-          }
-          col_op(0, n, nc, v, nc, Qk(k), nc, alpha.data());
+        spmv_dev((const D *)w, nc, v, nc, nc, nullptr);  // v = A w  (:60)
+        for (int k = 0; k <= j; ++k) {                    // modified Gram-Schmidt (:63-66)
+          gm_step(n, nc, v, k ? Qk(k - 1) : nullptr, Qk(k), S);
+          gm_finish(nc, 0, k, 0, S);
         }
-        col_dots(v, nc, v, nc, n, nc, tmp.data());  // v_norm2  (:67)
-        if (j + 1 < restart) {
-          for (int c = 0; c < nc; ++c) alpha[(size_t)c] = active[(size_t)c] ? std::sqrt(tmp[(size_t)c]) : 0.0;
-          col_op(1, n, nc, Qk(j + 1), nc, v, nc, alpha.data());  // :69-70
-        }
-        bool any_active = false;
-        for (int c = 0; c < nc; ++c) {
-          if (!active[(size_t)c]) continue;
-          double *yc = &y[(size_t)c * (restart + 1)], *wc = &w2[(size_t)c * restart];
-          double *Rc = &R[(size_t)c * restart * restart], *Jc = &J[(size_t)c * restart * 2];
-          const double v_norm2 = tmp[(size_t)c], v_norm = std::sqrt(v_norm2);
-          for (int cj = 0; cj + 1 <= j; ++cj) {  // Givens rotations on the new column (:73-78)
-            const double t0 = wc[cj];
-            wc[cj] = Jc[cj] * t0 + Jc[restart + cj] * wc[cj + 1];
-            wc[cj + 1] = -Jc[restart + cj] * t0 + Jc[cj] * wc[cj + 1];
-          }
-          const double rho = std::sqrt(wc[j] * wc[j] + v_norm2);  // :79
-          Jc[j] = wc[j] / rho;
-          Jc[restart + j] = v_norm / rho;
-          yc[j + 1] = -Jc[restart + j] * yc[j];
-          yc[j] = Jc[j] * yc[j];
-          wc[j] = rho;
-          for (int i = 0; i <= j; ++i) Rc[(size_t)j * restart + i] = wc[i];  // R(:,j)  (:85)
-          const double resid_prev = resid[(size_t)c];
-          resid[(size_t)c] = std::fabs(yc[j + 1]) / beta0[(size_t)c];  // :89
-          bool brk = false;
-          if (resid[(size_t)c] >= resid_prev * (1.0 - 1e-8)) {  // :90-93
-            flag[(size_t)c] = 1;
-            brk = true;
-          } else if (iter[(size_t)c] >= maxit) {  // :94-97
-            flag[(size_t)c] = 2;
-            brk = true;
-          } else {
-            ++iter[(size_t)c];
-            if (resid[(size_t)c] <= rtol || j + 1 >= restart) brk = true;  // :102
-          }
-          if (brk) {
-            jfin[(size_t)c] = j;
-            active[(size_t)c] = 0;
-          } else {
-            any_active = true;
-          }
-        }
-        if (!any_active) break;
+        gm_step(n, nc, v, Qk(j), nullptr, S);  // last axpy + |v|^2  (:65,67)
+        gm_finish(nc, 1, j, flexible ? nirs : 0, S);  // rotations, residual, stopping rules  (:73-103)
+        if (j + 1 < restart) gm_colop(1, n, nc, Qk(j + 1), nc, v, nc, S);  // :69-70
+        gm_read_ctl(S);
+        if (gm_ctl_host[0] == 0) break;
         ++j;
       }
-      int jmax = -1;
-      for (int c = 0; c < nc; ++c) {  // back substitution R y = g  (:106-110)
-        const int jf = jfin[(size_t)c];
-        if (jf < 0) continue;
-        jmax = std::max(jmax, jf);
-        double *yc = &y[(size_t)c * (restart + 1)];
-        const double *Rc = &R[(size_t)c * restart * restart];
-        for (int k = jf; k > -1; --k) {
-          yc[k] /= Rc[(size_t)k * restart + k];
-          const double t0 = yc[k];
-          for (int i = k - 1; i > -1; --i) yc[i] -= t0 * Rc[(size_t)k * restart + i];
-        }
-      }
+      hipLaunchKernelGGL((k_gm_backsolve<D>), dim3(1), dim3(64), 0, stream, nc, S);  // :106-110, :120
+      gm_read_ctl(S);
+      const int jmax = gm_ctl_host[1];
       if (flexible) {  // x += Z y  (:214-218)
-        for (int i = 0; i <= jmax; ++i) {
-          for (int c = 0; c < nc; ++c)
-            alpha[(size_t)c] = (jfin[(size_t)c] >= i) ? y[(size_t)c * (restart + 1) + i] : 0.0;
-          col_op(0, n, nc, dX, ldx, Zk(i), nc, alpha.data());
-        }
+        hipLaunchKernelGGL((k_gm_combine<D>), dim3((unsigned)grid), dim3(256), 0, stream, n, nc, dX, ldx, 1, (const D *)Z, jmax, S);
       } else {
-        vec_op(0, n, nc, (D *)v, nc, nullptr, 0, nullptr, 0);  // v = Q y  (:112-116)
-        for (int i = 0; i <= jmax; ++i) {
-          for (int c = 0; c < nc; ++c)
-            alpha[(size_t)c] = (jfin[(size_t)c] >= i) ? y[(size_t)c * (restart + 1) + i] : 0.0;
-          col_op(0, n, nc, v, nc, Qk(i), nc, alpha.data());
-        }
-        solve_dev((const D *)v, nc, (D *)w, nc, nc, rank, nullptr);  // :118
-        for (int c = 0; c < nc; ++c) alpha[(size_t)c] = (jfin[(size_t)c] >= 0) ? 1.0 : 0.0;
-        col_op(0, n, nc, dX, ldx, w, nc, alpha.data());  // x += w  (:119)
+        hipLaunchKernelGGL((k_gm_combine<D>), dim3((unsigned)grid), dim3(256), 0, stream, n, nc, v, (int64_t)nc, 0, (const D *)Q, jmax, S);  // v = Q y  (:112-116)
+        solve_dev((const D *)v, nc, w, nc, nc, rank, nullptr);  // :118
+        gm_colop(0, n, nc, dX, ldx, (const D *)w, nc, S);       // x += w  (:119; alpha = 1 for the columns that took part)
       }
-      for (int c = 0; c < nc; ++c)
-        if (jfin[(size_t)c] >= 0 && (resid[(size_t)c] <= rtol || flag[(size_t)c] != 0)) done[(size_t)c] = 1;  // :120
     }
+    std::vector<int> st((size_t)6 * nc);
+    HIP_OK(hipMemcpyAsync(st.data(), S.iter, st.size() * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
     check_device_error();
     for (int c = 0; c < nc; ++c) {
-      if (flags) flags[c] = flag[(size_t)c];
-      if (iters) iters[c] = iter[(size_t)c];
-      if (sweeps) sweeps[c] = num_mv[(size_t)c];
+      if (iters) iters[c] = st[(size_t)c];
+      if (flags) flags[c] = st[(size_t)nc + c];
+      if (sweeps) sweeps[c] = st[(size_t)5 * nc + c];
     }
   }
 
-  void gmres_dev(const double *dB, int64_t ldb, double *dX, int64_t ldx, int64_t nrhs, int restart, double rtol,
+  void gmres_dev(const D *dB, int64_t ldb, D *dX, int64_t ldx, int64_t nrhs, int restart, double rtol,
                  int maxit, int64_t rank, int *flags, int *iters, bool flexible = false, int *sweeps = nullptr) {
     check_batch(dB, ldb, dX, ldx, nrhs);
     if (!has_A) throw Error(HIFAMD_BAD_PREC, "GMRES needs the matrix (hifamd_set_matrix)");
@@ -1780,19 +1739,19 @@ class Engine : public EngineBase {
     }
   }
 
-  void gmres_host(const double *B, int64_t ldb, double *X, int64_t ldx, int64_t nrhs, int restart, double rtol,
+  void gmres_host(const T *B, int64_t ldb, T *X, int64_t ldx, int64_t nrhs, int restart, double rtol,
                   int maxit, int64_t rank, int *flags, int *iters, bool flexible = false, int *sweeps = nullptr) {
     check_batch(B, ldb, X, ldx, nrhs);
     HIP_OK(hipSetDevice(device));
     const int64_t n = lv[0]->n;
-    const size_t need = (size_t)n * nrhs * sizeof(double);
+    const size_t need = (size_t)n * nrhs * sizeof(T);
     if (stage_b.bytes < need) stage_b.alloc(need);
     if (stage_x.bytes < need) stage_x.alloc(need);
-    HIP_OK(hipMemcpy2DAsync(stage_b.p, nrhs * sizeof(double), B, ldb * sizeof(double), nrhs * sizeof(double), n,
+    HIP_OK(hipMemcpy2DAsync(stage_b.p, nrhs * sizeof(T), B, ldb * sizeof(T), nrhs * sizeof(T), n,
                             hipMemcpyHostToDevice, stream));
-    gmres_dev(stage_b.as<double>(), nrhs, stage_x.as<double>(), nrhs, nrhs, restart, rtol, maxit, rank, flags, iters, flexible,
+    gmres_dev(stage_b.as<D>(), nrhs, stage_x.as<D>(), nrhs, nrhs, restart, rtol, maxit, rank, flags, iters, flexible,
               sweeps);
-    HIP_OK(hipMemcpy2DAsync(X, ldx * sizeof(double), stage_x.p, nrhs * sizeof(double), nrhs * sizeof(double), n,
+    HIP_OK(hipMemcpy2DAsync(X, ldx * sizeof(T), stage_x.p, nrhs * sizeof(T), nrhs * sizeof(T), n,
                             hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
   }
@@ -2484,24 +2443,24 @@ HifAmdStatus hifamd_apply_batch_dev(HifAmdHdl h, HifAmdOp op, const void *dB, in
 HifAmdStatus hifamd_gmres_batch(HifAmdHdl h, const void *B, int64_t ldb, void *X, int64_t ldx, int64_t nrhs, int restart,
                                 double rtol, int maxit, int64_t rank, int *flags, int *iters) {
   API_BEGIN
-  if (h->vt != HIFAMD_D) throw Error(HIFAMD_HIFIR_ERROR, "the GMRES driver is real-valued (the reference example's inner product is not Hermitian)");
-  ENG_D->gmres_host((const double *)B, ldb, (double *)X, ldx, nrhs, restart, rtol, maxit, rank, flags, iters);
+  DISPATCH(ENG_D->gmres_host((const double *)B, ldb, (double *)X, ldx, nrhs, restart, rtol, maxit, rank, flags, iters),
+           ENG_Z->gmres_host((const zdouble *)B, ldb, (zdouble *)X, ldx, nrhs, restart, rtol, maxit, rank, flags, iters))
   API_END
 }
 
 HifAmdStatus hifamd_gmres_batch_dev(HifAmdHdl h, const void *dB, int64_t ldb, void *dX, int64_t ldx, int64_t nrhs,
                                     int restart, double rtol, int maxit, int64_t rank, int *flags, int *iters) {
   API_BEGIN
-  if (h->vt != HIFAMD_D) throw Error(HIFAMD_HIFIR_ERROR, "the GMRES driver is real-valued (the reference example's inner product is not Hermitian)");
-  ENG_D->gmres_dev((const double *)dB, ldb, (double *)dX, ldx, nrhs, restart, rtol, maxit, rank, flags, iters);
+  DISPATCH(ENG_D->gmres_dev((const double *)dB, ldb, (double *)dX, ldx, nrhs, restart, rtol, maxit, rank, flags, iters),
+           ENG_Z->gmres_dev((const cplx *)dB, ldb, (cplx *)dX, ldx, nrhs, restart, rtol, maxit, rank, flags, iters))
   API_END
 }
 
 HifAmdStatus hifamd_fgmres_batch(HifAmdHdl h, const void *B, int64_t ldb, void *X, int64_t ldx, int64_t nrhs, int restart,
                                  double rtol, int maxit, int64_t rank, int *flags, int *iters, int *sweeps) {
   API_BEGIN
-  if (h->vt != HIFAMD_D) throw Error(HIFAMD_HIFIR_ERROR, "the GMRES drivers are real-valued (the reference example's inner product is not Hermitian)");
-  ENG_D->gmres_host((const double *)B, ldb, (double *)X, ldx, nrhs, restart, rtol, maxit, rank, flags, iters, true, sweeps);
+  DISPATCH(ENG_D->gmres_host((const double *)B, ldb, (double *)X, ldx, nrhs, restart, rtol, maxit, rank, flags, iters, true, sweeps),
+           ENG_Z->gmres_host((const zdouble *)B, ldb, (zdouble *)X, ldx, nrhs, restart, rtol, maxit, rank, flags, iters, true, sweeps))
   API_END
 }
 

@@ -24,7 +24,8 @@
 //   k_thin_update + k_tri_gemm_d   the thin tail of a triangle in block-dense form (host.hpp plan_dense_blocks)
 //   k_gather_div / k_prod_rows / k_spmm_prod / k_scatter_div   prec_prod, alg/prec_prod.hpp:55-147
 //   k_zcombine       complex products as two real MFMA products
-//   k_coldot_partial / k_col_op / k_colsum_partial / k_sub_colmean   GMRES and null-space-filter BLAS-1
+//   k_gm_step / k_gm_finish / k_gm_backsolve / k_gm_combine / k_gm_colop   device-resident Arnoldi process of GMRES
+//   k_colsum_partial / k_sub_colmean   null-space-filter BLAS-1
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -1317,43 +1318,232 @@ __global__ void __launch_bounds__(256) k_sub_colmean(int64_t r0, int64_t r1, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// BLAS-1 helpers of the batched GMRES driver (the reference's examples/advanced/gmres.hpp:19-123,
-// real arithmetic): per-column dot products, axpy and scaling with one coefficient per column.
+// Device-resident Arnoldi process of the batched GMRES driver (examples/advanced/gmres.hpp:57-103 for up to
+// 64 columns in lock step): the Hessenberg column, the rotations, the residuals and the per-column state
+// (iteration count, flag, active mask) live in HBM; the host sees three integers per inner step.
+// The inner product is the Hermitian one, h = sum conj(q_i) v_i (for real data this IS hif::inner,
+// utils/math.hpp:83; for complex data the example's sum conj(v_i) q_i would not orthogonalize).
 // ---------------------------------------------------------------------------------------------
-// partial[block][c] = sum over the block's rows of x[i][c] * y[i][c]   (hif::inner, utils/math.hpp:83)
-__global__ void __launch_bounds__(256) k_coldot_partial(int64_t n, int nrhs, const double *x, int64_t ldx,
-                                                        const double *y, int64_t ldy, double *partial) {
-  __shared__ double sm[256];
-  const int cpad = nrhs;  // nrhs <= 64 here
-  const int rows_per_pass = 256 / cpad;
-  const int c = threadIdx.x % cpad, rloc = threadIdx.x / cpad;
-  double acc = 0.0;
-  if (rloc < rows_per_pass)
-    for (int64_t i = (int64_t)blockIdx.x * rows_per_pass + rloc; i < n; i += (int64_t)gridDim.x * rows_per_pass)
-      acc += x[i * ldx + c] * y[i * ldy + c];
-  sm[threadIdx.x] = (rloc < rows_per_pass) ? acc : 0.0;
+__device__ __forceinline__ double vconj(double a) { return a; }
+__device__ __forceinline__ cplx vconj(cplx a) { return cplx{a.x, -a.y}; }
+__device__ __forceinline__ double vreal(double a) { return a; }
+__device__ __forceinline__ double vreal(cplx a) { return a.x; }
+__device__ __forceinline__ double vfromreal(double r, double) { return r; }
+__device__ __forceinline__ cplx vfromreal(double r, cplx) { return cplx{r, 0.0}; }
+__device__ __forceinline__ double vabs1(double a) { return fabs(a); }
+__device__ __forceinline__ double vabs1(cplx a) { return sqrt(a.x * a.x + a.y * a.y); }
+__device__ __forceinline__ bool viszero(double a) { return a == 0.0; }
+__device__ __forceinline__ bool viszero(cplx a) { return a.x == 0.0 && a.y == 0.0; }
+
+template <class T>
+struct GmState {
+  T *w2;          // [nc][restart]           Hessenberg column of the running step (gmres.hpp:64,73-78)
+  T *Jc;          // [nc][restart]           J(:,0)
+  double *Js;     // [nc][restart]           J(:,1) (real)
+  T *y;           // [nc][restart + 1]
+  T *R;           // [nc][restart][restart]  column j of column c at R + (c * restart + j) * restart
+  double *resid, *beta0;
+  int *iter, *flag, *active, *jfin, *done, *sweeps;
+  T *alpha;       // [nc] coefficient of the next column operation
+  int *ctl;       // [0] columns still active after the step  [1] max jfin  [2] columns not done
+  int restart, maxit;
+  double rtol;
+};
+
+// One modified-Gram-Schmidt step, fused: first v -= h_prev q_prev (the axpy of the PREVIOUS step, :65), then the
+// block's share of sum conj(q_i) v_i (:64) -- or of sum |v_i|^2 (:67) when q == nullptr.  v, q: [n][nc] contiguous.
+template <class T>
+__global__ void __launch_bounds__(256) k_gm_step(int64_t n, int nc, T *__restrict__ v, const T *__restrict__ qp,
+                                                 const T *__restrict__ hp, const T *__restrict__ q,
+                                                 T *__restrict__ partial /* [gridDim.x][nc] */) {
+  __shared__ T sm[256];
+  const int rpp = 256 / nc;
+  const int c = threadIdx.x % nc, rloc = threadIdx.x / nc;
+  T acc = vzero(T());
+  if (rloc < rpp) {
+    const T h = qp ? hp[c] : vzero(T());
+    const int64_t step = (int64_t)gridDim.x * rpp;
+    for (int64_t i = (int64_t)blockIdx.x * rpp + rloc; i < n; i += step) {
+      T x = v[i * nc + c];
+      if (qp) {
+        x = vsub(x, vmul(h, qp[i * nc + c]));
+        v[i * nc + c] = x;
+      }
+      acc = vadd(acc, q ? vmul(vconj(q[i * nc + c]), x) : vfromreal(vabs2(x), T()));
+    }
+  }
+  sm[threadIdx.x] = acc;
   __syncthreads();
-  if (threadIdx.x < cpad) {
-    double tot = 0.0;
-    for (int r = 0; r < rows_per_pass; ++r) tot += sm[r * cpad + threadIdx.x];
-    partial[(int64_t)blockIdx.x * nrhs + threadIdx.x] = tot;
+  if (threadIdx.x < nc) {
+    T tot = vzero(T());
+    for (int r = 0; r < rpp; ++r) tot = vadd(tot, sm[r * nc + threadIdx.x]);
+    partial[(int64_t)blockIdx.x * nc + threadIdx.x] = tot;
   }
 }
 
-// op 0: y[:,c] += alpha[c] * x[:,c] | 1: y[:,c] = x[:,c] / alpha[c] (0 where alpha[c] == 0: a column
-// that has left the iteration keeps a zero basis vector)
-__global__ void __launch_bounds__(256) k_col_op(int op, int64_t n, int nrhs, double *y, int64_t ldy, const double *x,
-                                                int64_t ldx, const double *__restrict__ alpha) {
-  const int64_t total = n * nrhs;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = e / nrhs;
-    const int c = (int)(e - i * nrhs);
-    const double a = alpha[c];
+// Finishes a reduction (fixed order: deterministic) and does the per-column scalar work of the driver.
+//   mode 0: h_k of step k -> w2[k], alpha                                       (:64)
+//   mode 1: |v|^2 of step j: rotations, residual, stopping rules                 (:67-103); alpha = |v| for :69-70
+//   mode 2: start of an outer cycle: beta, y[0], active mask                    (:53-55)
+//   mode 3: start of the solve: beta0, quick return                              (:30-36)
+template <class T>
+__global__ void __launch_bounds__(256) k_gm_finish(const T *__restrict__ partial, int nblk, int nc, int mode, int k,
+                                                   int nirs, GmState<T> S) {
+  __shared__ T sm[256];
+  __shared__ int cnt[2];
+  const int rpp = 256 / nc;
+  const int c = threadIdx.x % nc, g = threadIdx.x / nc;
+  T acc = vzero(T());
+  if (g < rpp)
+    for (int b = g; b < nblk; b += rpp) acc = vadd(acc, partial[(int64_t)b * nc + c]);
+  sm[threadIdx.x] = acc;
+  if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x < nc) {
+    T tot = vzero(T());
+    for (int r = 0; r < rpp; ++r) tot = vadd(tot, sm[r * nc + c]);
+    const int rs = S.restart;
+    if (mode == 0) {
+      S.w2[(size_t)c * rs + k] = tot;
+      S.alpha[c] = tot;
+    } else if (mode == 3) {
+      const double b0 = sqrt(vreal(tot));
+      S.beta0[c] = b0;
+      S.done[c] = (b0 == 0.0);
+      S.resid[c] = 1.0;
+      S.iter[c] = 0;
+      S.flag[c] = 0;
+      S.sweeps[c] = 0;
+      S.active[c] = 0;
+      S.jfin[c] = -1;
+      if (b0 != 0.0) atomicAdd(&cnt[1], 1);
+    } else if (mode == 2) {
+      const double beta = sqrt(vreal(tot));
+      int dn = S.done[c];
+      if (!dn && beta == 0.0) dn = 1;  // exact solution reached
+      S.done[c] = dn;
+      S.y[(size_t)c * (rs + 1)] = vfromreal(beta, T());
+      S.alpha[c] = vfromreal(dn ? 0.0 : beta, T());
+      S.active[c] = !dn;
+      S.jfin[c] = -1;
+      if (!dn) atomicAdd(&cnt[0], 1);
+    } else {
+      const int j = k;
+      const double v_norm2 = vreal(tot), v_norm = sqrt(v_norm2);
+      const int act = S.active[c];
+      S.alpha[c] = vfromreal(act ? v_norm : 0.0, T());
+      if (act) {
+        S.sweeps[c] += nirs;
+        T *wc = S.w2 + (size_t)c * rs, *yc = S.y + (size_t)c * (rs + 1), *Jc = S.Jc + (size_t)c * rs;
+        double *Js = S.Js + (size_t)c * rs;
+        T *Rc = S.R + (size_t)c * rs * rs;
+        for (int cj = 0; cj + 1 <= j; ++cj) {  // :73-78
+          const T t0 = wc[cj], t1 = wc[cj + 1];
+          wc[cj] = vadd(vmul(vconj(Jc[cj]), t0), vscale(Js[cj], t1));
+          wc[cj + 1] = vadd(vscale(-Js[cj], t0), vmul(Jc[cj], t1));
+        }
+        const double rho = sqrt(vabs2(wc[j]) + v_norm2);  // :79
+        Jc[j] = vdivr(wc[j], rho);
+        Js[j] = v_norm / rho;
+        yc[j + 1] = vscale(-Js[j], yc[j]);
+        yc[j] = vmul(vconj(Jc[j]), yc[j]);
+        wc[j] = vfromreal(rho, T());
+        for (int i = 0; i <= j; ++i) Rc[(size_t)j * rs + i] = wc[i];  // :85
+        const double resid_prev = S.resid[c];
+        const double resid = vabs1(yc[j + 1]) / S.beta0[c];  // :89
+        S.resid[c] = resid;
+        bool brk = false;
+        if (resid >= resid_prev * (1.0 - 1e-8)) {  // :90-93
+          S.flag[c] = 1;
+          brk = true;
+        } else if (S.iter[c] >= S.maxit) {  // :94-97
+          S.flag[c] = 2;
+          brk = true;
+        } else {
+          S.iter[c] += 1;
+          if (resid <= S.rtol || j + 1 >= rs) brk = true;  // :102
+        }
+        if (brk) {
+          S.jfin[c] = j;
+          S.active[c] = 0;
+        } else {
+          atomicAdd(&cnt[0], 1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (mode == 1 || mode == 2) S.ctl[0] = cnt[0];
+    if (mode == 3) S.ctl[2] = cnt[1];
+  }
+}
+
+// End of an outer cycle: back substitution R y = g per column (:106-110), alpha = 1 for the columns that took part,
+// done flags (:120); ctl[1] = max jfin, ctl[2] = columns not done.
+template <class T>
+__global__ void __launch_bounds__(64) k_gm_backsolve(int nc, GmState<T> S) {
+  __shared__ int red[2];
+  if (threadIdx.x < 2) red[threadIdx.x] = threadIdx.x ? 0 : -1;
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c < nc) {
+    const int rs = S.restart, jf = S.jfin[c];
+    if (jf >= 0) {
+      T *yc = S.y + (size_t)c * (rs + 1);
+      const T *Rc = S.R + (size_t)c * rs * rs;
+      for (int k = jf; k > -1; --k) {
+        yc[k] = vdiv(yc[k], Rc[(size_t)k * rs + k]);
+        const T t0 = yc[k];
+        for (int i = k - 1; i > -1; --i) yc[i] = vsub(yc[i], vmul(t0, Rc[(size_t)k * rs + i]));
+      }
+      atomicMax(&red[0], jf);
+      if (S.resid[c] <= S.rtol || S.flag[c] != 0) S.done[c] = 1;
+    }
+    S.alpha[c] = vfromreal(jf >= 0 ? 1.0 : 0.0, T());
+    if (!S.done[c]) atomicAdd(&red[1], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    S.ctl[1] = red[0];
+    S.ctl[2] = red[1];
+  }
+}
+
+// out = (accumulate ? out : 0) + sum_{k <= jmax} coef_k Q_k, coef_k[c] = y[c][k] for the columns with jfin >= k, in
+// the order of :112-116 / :214-218; Q_k = Q + k * n * nc, [n][nc] contiguous
+template <class T>
+__global__ void __launch_bounds__(256) k_gm_combine(int64_t n, int nc, T *__restrict__ out, int64_t ldo, int accumulate,
+                                                    const T *__restrict__ Q, int jmax, GmState<T> S) {
+  const int64_t total = n * nc;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / nc;
+    const int c = (int)(e - i * nc);
+    const int jf = S.jfin[c];
+    const T *yc = S.y + (size_t)c * (S.restart + 1);
+    T r = accumulate ? out[i * ldo + c] : vzero(T());
+    for (int k = 0; k <= jmax; ++k) {
+      const T a = (jf >= k) ? yc[k] : vzero(T());
+      r = vadd(r, vmul(a, Q[(size_t)k * (size_t)total + (size_t)e]));
+    }
+    out[i * ldo + c] = r;
+  }
+}
+
+// op 0: y[:,c] += alpha[c] x[:,c] | 1: y[:,c] = x[:,c] / real(alpha[c]) (0 where alpha[c] == 0: a column that has
+// left the iteration keeps a zero basis vector); alpha on the device
+template <class T>
+__global__ void __launch_bounds__(256) k_gm_colop(int op, int64_t n, int nc, T *__restrict__ y, int64_t ldy,
+                                                  const T *__restrict__ x, int64_t ldx, const T *__restrict__ alpha) {
+  const int64_t total = n * nc;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / nc;
+    const int c = (int)(e - i * nc);
+    const T a = alpha[c];
     if (op == 0)
-      y[i * ldy + c] = y[i * ldy + c] + a * x[i * ldx + c];
+      y[i * ldy + c] = vadd(y[i * ldy + c], vmul(a, x[i * ldx + c]));
     else
-      y[i * ldy + c] = (a == 0.0) ? 0.0 : x[i * ldx + c] / a;
+      y[i * ldy + c] = viszero(a) ? vzero(T()) : vdivr(x[i * ldx + c], vreal(a));
   }
 }
 

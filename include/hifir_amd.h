@@ -193,8 +193,12 @@ HifAmdStatus hifamd_apply_batch_dev(HifAmdHdl h, HifAmdOp op, const void *dB, in
 /* ---- right-preconditioned restarted GMRES, batched (the caller of the hot path) ------------- */
 /* The reference's driver gmres_hif (examples/advanced/gmres.hpp:19-123: x0 = 0, modified Gram-Schmidt,
  * Givens rotations, stop on |y_{j+1}| / ||b|| <= rtol) for nrhs columns in lock step; all vectors
- * stay in HBM, one batched apply and one SpMM per inner step serve every column.  Needs
- * hifamd_set_matrix; real-valued handles only.  rank: 0 numerical rank (the example's default),
+ * stay in HBM -- and so do the Hessenberg columns, rotations, residuals and per-column iteration state;
+ * one batched apply, one SpMM and j + 2 fused axpy/dot passes per inner step serve every column, and the host
+ * reads back three integers per step.  Needs hifamd_set_matrix.  Real and complex handles: the Hessenberg
+ * entries are Hermitian products sum conj(q_i) v_i (for real data that IS the example's hif::inner; for
+ * complex data the example's sum conj(v_i) q_i is the conjugate and would not orthogonalize), the rotations
+ * follow gmres.hpp:75-83 with their conjugates.  rank: 0 numerical rank (the example's default),
  * -1 full.  Per column: flags[c] = 0 converged / 1 stagnated / 2 reached maxit, iters[c] = inner
  * iterations (either may be NULL).  Host pointers; the _dev variant takes device pointers for B, X. */
 HifAmdStatus hifamd_gmres_batch(HifAmdHdl h, const void *B, int64_t ldb, void *X, int64_t ldx, int64_t nrhs,

@@ -193,7 +193,7 @@ class HIF {
                                      detail::rank_arg(r), nullptr));
   }
 
-  // ---- the example driver of examples/advanced/gmres.hpp:19-123 on the device (real-valued only) ----
+  // ---- the example driver of examples/advanced/gmres.hpp:19-123 on the device (real or complex; Hermitian inner product) ----
   template <class Matrix, class ArrayType>
   std::tuple<ArrayType, int, int> gmres(const Matrix &A, const ArrayType &b, const int restart, const double rtol,
                                         const int maxit, const bool full_rank = false) {

@@ -231,26 +231,33 @@ def fgmres(O, indptr, indices, vals, b, restart=30, rtol=1e-6, maxit=500, full_r
 
 def gmres(O, indptr, indices, vals, b, restart=30, rtol=1e-6, maxit=500, full_rank=False, flexible=False):
     """numpy restatement of the reference's right-preconditioned GMRES driver gmres_hif
-    (examples/advanced/gmres.hpp:19-123; real arithmetic) around the oracle's apply `O.solve`:
+    (examples/advanced/gmres.hpp:19-123) around the oracle's apply `O.solve`:
     x0 = 0, modified Gram-Schmidt, Givens rotations, relative residual |y_{j+1}| / ||b||.
-    Returns (x, flag, iterations); flag 0 converged / 1 stagnated / 2 reached maxit."""
+    Returns (x, flag, iterations); flag 0 converged / 1 stagnated / 2 reached maxit.
+    Real data: the driver line by line (pinned to the compiled driver in tests/test_oracle_vs_ref.py).
+    Complex data: the same lines, rotations with the conjugates of :75-83, but the Hessenberg entry is the
+    Hermitian product h = sum conj(q_i) v_i; the example's hif::inner(v, q) = sum conj(v_i) q_i
+    (utils/math.hpp:83-90) is its conjugate and does not orthogonalize v against q, so there is no
+    reference behaviour to pin for complex systems (checked by the true residual instead)."""
     import scipy.sparse as sp
 
-    b = np.ascontiguousarray(b, dtype=np.float64)
+    cplx = np.iscomplexobj(vals) or np.iscomplexobj(b)
+    dt = np.complex128 if cplx else np.float64
+    b = np.ascontiguousarray(b, dtype=dt)
     n = len(b)
-    A = sp.csr_matrix((np.asarray(vals, dtype=np.float64), indices, indptr), shape=(n, n))
+    A = sp.csr_matrix((np.asarray(vals, dtype=dt), indices, indptr), shape=(n, n))
     rr = -1 if full_rank else 0                                     # :26
     it, flag, num_mv = 0, 0, 0
     beta0 = np.linalg.norm(b)                                        # :30
-    x = np.zeros(n)
+    x = np.zeros(n, dtype=dt)
     if beta0 == 0.0:                                                 # :36
         return (x, 0, 0, 0) if flexible else (x, 0, 0)
-    Q = np.zeros((n, restart))
-    Z = np.zeros((n, restart)) if flexible else None
-    R = np.zeros((restart, restart))
-    J = np.zeros((restart, 2))
-    y = np.zeros(restart + 1)
-    w2 = np.zeros(restart)
+    Q = np.zeros((n, restart), dtype=dt)
+    Z = np.zeros((n, restart), dtype=dt) if flexible else None
+    R = np.zeros((restart, restart), dtype=dt)
+    J = np.zeros((restart, 2), dtype=dt)
+    y = np.zeros(restart + 1, dtype=dt)
+    w2 = np.zeros(restart, dtype=dt)
     resid = 1.0
     for outer in range(int(np.ceil(maxit / restart))):               # :43-45
         v = b - A @ x if it else b.copy()                            # :48-52
@@ -268,21 +275,21 @@ def gmres(O, indptr, indices, vals, b, restart=30, rtol=1e-6, maxit=500, full_ra
                 w = O.solve(Q[:, j].copy(), rank=rr)                 # :59
             v = A @ w                                                # :60
             for k in range(j + 1):                                   # :63-66
-                w2[k] = v @ Q[:, k]
+                w2[k] = np.vdot(Q[:, k], v) if cplx else v @ Q[:, k]
                 v = v - w2[k] * Q[:, k]
-            v_norm2 = v @ v
+            v_norm2 = float(np.vdot(v, v).real)
             v_norm = np.sqrt(v_norm2)
             if j + 1 < restart:
                 Q[:, j + 1] = v / v_norm
             for cj in range(j):                                      # :73-78
                 t0 = w2[cj]
-                w2[cj] = J[cj, 0] * t0 + J[cj, 1] * w2[cj + 1]
+                w2[cj] = np.conj(J[cj, 0]) * t0 + np.conj(J[cj, 1]) * w2[cj + 1]
                 w2[cj + 1] = -J[cj, 1] * t0 + J[cj, 0] * w2[cj + 1]
-            rho = np.sqrt(w2[j] * w2[j] + v_norm2)                   # :79
+            rho = np.sqrt((np.conj(w2[j]) * w2[j]).real + v_norm2)   # :79
             J[j, 0] = w2[j] / rho
             J[j, 1] = v_norm / rho
             y[j + 1] = -J[j, 1] * y[j]
-            y[j] = J[j, 0] * y[j]
+            y[j] = np.conj(J[j, 0]) * y[j]
             w2[j] = rho
             R[:j + 1, j] = w2[:j + 1]
             resid_prev = resid
