@@ -74,4 +74,17 @@ ms = M.time_apply(Bd, Xd, warmup=2, reps=reps)
 balg = M.algorithmic_bytes(nrhs)
 print(f"RESULT nx={nx} mode={mode} nrhs={nrhs}: {ms:.3f} ms/batch  {nrhs / ms * 1e3:.0f} RHS-applies/s  "
       f"B_alg={balg / 1e9:.3f} GB  {balg / ms / 1e6:.1f} GB/s  frac_of_8TB/s={balg / ms / 1e6 / 8000:.4f}", flush=True)
+import os  # noqa: E402
+
+if os.environ.get("GMRES"):  # GMRES(30) on all columns: time per inner step (apply + SpMM + Gram-Schmidt)
+    M.set_matrix(A.indptr, A.indices, A.data)
+    for maxit in (10, 30):
+        M.gmres(Bd, restart=30, rtol=1e-300, maxit=maxit)  # warm-up (buffers)
+        M.sync()
+        t0 = time.time()
+        Xg, fl, it = M.gmres(Bd, restart=30, rtol=1e-300, maxit=maxit)
+        M.sync()
+        el = time.time() - t0
+        print(f"GMRES(30) nrhs={nrhs} maxit={maxit}: {el * 1e3:.1f} ms total, iters={int(it.max())}, "
+              f"{el * 1e3 / max(1, int(it.max())):.2f} ms per inner step for all columns", flush=True)
 M.close()
