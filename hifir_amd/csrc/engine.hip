@@ -101,6 +101,12 @@ struct DevBuf {
     bytes = o.bytes;
     owner = false;
   }
+  void view(const DevBuf &o, size_t offset, size_t b) {  // a window of another buffer (not owned)
+    release();
+    p = (char *)o.p + offset;
+    bytes = b;
+    owner = false;
+  }
   void alloc(size_t b) {
     release();
     bytes = b;
@@ -144,6 +150,8 @@ struct DevCsr {
   DevBuf wg_slot;  // first slot of every workgroup (+ end): grp_slot_ptr[wg_grp_ptr[g]], one load level less at kernel start
   DevBuf csplit, grp_inv_off, cd_desc, mid_col, mid_val, mid_lrow;  // component-dense bands (host.hpp plan_bands_cd)
   DevBuf own_val, own_lsrc, own_rptr, own_lvl;                        // ... sparse-own plans (BandPlan::cd_sparse)
+  DevBuf f_desc, f_col, f_val, f_lrow;  // L only: the streams with the level's F entries appended (host.hpp build_cd_streams_fused)
+  bool f_fused = false;
   bool cd_sparse = false;
   std::vector<int32_t> band_wg_ptr, band_slot_ptr, host_wg_grp_ptr;
   std::vector<uint8_t> band_prefix, band_dense, band_fused, band_cd, band_old;
@@ -177,6 +185,11 @@ struct DevCsr {
     own_lsrc.alias(o.own_lsrc);
     own_rptr.alias(o.own_rptr);
     own_lvl.alias(o.own_lvl);
+    f_desc.alias(o.f_desc);
+    f_col.alias(o.f_col);
+    f_val.alias(o.f_val);
+    f_lrow.alias(o.f_lrow);
+    f_fused = o.f_fused;
     cd_sparse = o.cd_sparse;
     band_cd = o.band_cd;
     band_old = o.band_old;
@@ -256,7 +269,14 @@ struct DevLevel {
   bool E_void = false;  // adjoint of a level without F: the restriction F^H does not exist (not merely empty)
   DevCsr L, U, E, F;
   DevBuf d, s, t, p, qinv;
-  DevBuf w, v;  // arena: n * Rmax each
+  DevBuf w, v;  // arena: n * Rmax each, v right behind w in ONE allocation (row n + i of w is row i of v: the fused
+                // F streams address the child's solution through the L solve's vector)
+  DevBuf arena;
+  void alloc_arena(size_t bytes_each) {
+    arena.alloc(2 * bytes_each);
+    w.view(arena, 0, bytes_each);
+    v.view(arena, bytes_each, bytes_each);
+  }
   // combined top operator G = U_TT^{-1} D_T^{-1} L_TT^{-1} (host.hpp choose_top / build_top_operator), MFMA operand
   DevBuf topG;
   int64_t top_n = 0;
@@ -338,6 +358,8 @@ class Engine : public EngineBase {
   bool spmm_tiles = true;       // E / F products on the matrix cores where rows share columns (HIFIR_AMD_SPMM_TILES=0: off)
   double spmm_tile_reuse = 2.0; // ... when a 16-row block has at least this many nonzeros per distinct column
   bool fuse_gather = true;  // S1 fused into the L solve (HIFIR_AMD_FUSE_S1=0: separate k_gather_scale launches)
+  bool fuse_f = true;    // S5 fused into the second L solve where the plan allows (HIFIR_AMD_FUSE_F=0: separate k_spmm_epi launch)
+  int top_gemm = 2;      // top operator product: 1 k_strip_gemm_d<4>, 2 k_strip_gemm4_d<2>, 3 k_strip_gemm4_d<4> (HIFIR_AMD_TOP_GEMM)
   int cd_dbg = 0;        // development aid (HIFIR_AMD_CD_DBG): phases of k_band_cd switched off for timing experiments
   int band_pipe = 1;     // 1: k_trsv_band_p (next row's head behind the last gathers), 0: k_trsv_band at R = 64 too
   BandOptions band_opt;  // how triangles are cut into bands (host.hpp)
@@ -364,6 +386,8 @@ class Engine : public EngineBase {
     gemm_waves = env_int("HIFIR_AMD_GEMM_WAVES", 16);
     band_pipe = env_int("HIFIR_AMD_BAND_PIPE", 1);
     cd_dbg = env_int("HIFIR_AMD_CD_DBG", 0);
+    top_gemm = env_int("HIFIR_AMD_TOP_GEMM", 2);
+    fuse_f = env_int("HIFIR_AMD_FUSE_F", 1) != 0;
     fuse_gather = env_int("HIFIR_AMD_FUSE_S1", 1) != 0;
     spmm_tiles = env_int("HIFIR_AMD_SPMM_TILES", 1) != 0;
     use_twin = env_int("HIFIR_AMD_TWIN", 1);
@@ -472,6 +496,9 @@ class Engine : public EngineBase {
       E->gemm_waves = gemm_waves;
       E->fuse_gather = fuse_gather;
       E->spmm_tiles = spmm_tiles;
+      E->top_gemm = top_gemm;
+      E->fuse_f = fuse_f;
+      E->cd_dbg = cd_dbg;
       for (const auto &P : host.levels) E->add_level_adjoint(P);
       if (host.has_dense && host.dense.kind == 2) {  // LUP: ?getrs 'T' / ?gemv 'C' (LUP.hpp:150,187)
         E->host.dense.kind = 2;
@@ -520,6 +547,9 @@ class Engine : public EngineBase {
       E->gemm_waves = gemm_waves;
       E->fuse_gather = fuse_gather;
       E->spmm_tiles = spmm_tiles;
+      E->top_gemm = top_gemm;
+      E->fuse_f = fuse_f;
+      E->cd_dbg = cd_dbg;
       E->max_nrhs = max_nrhs;
       E->Rmax = Rmax;
       E->host.has_dense = host.has_dense;
@@ -544,8 +574,7 @@ class Engine : public EngineBase {
         L.t.alias(Pl->t);
         L.p.alias(Pl->p);
         L.qinv.alias(Pl->qinv);
-        L.w.alloc(Pl->w.bytes);
-        L.v.alloc(Pl->v.bytes);
+        L.alloc_arena(Pl->w.bytes);
         if (L.w.bytes) zero_dev(L.w.p, L.w.bytes);
         if (L.v.bytes) zero_dev(L.v.p, L.v.bytes);
         E->lv.push_back(std::move(Lp));
@@ -746,13 +775,27 @@ class Engine : public EngineBase {
           Md.tl_coef.upload(Tl.coef);
           Md.tl_nblk = Tl.nblk;
         }
+      // S5 fused into the second L solve (host.hpp build_cd_streams_fused): thin F rows only -- rows that share columns
+      // are better served by the tiled product
+      if constexpr (std::is_same<T, double>::value) {
+        if (fuse_f && fuse_gather && band_pipe && Rmax == 64 && band_opt.dense_block > 0 && H.F_ncols > 0 && H.m > 0 &&
+            L.top_n == 0 && L.F.tl_nblk == 0 && cd_f_fusable(H.Lp)) {
+          CdFusedStreams<T> S;
+          if (build_cd_streams_fused(H.Lp, H.Lr, H.Fr, H.n + H.m, S)) {
+            L.L.f_desc.upload(S.desc);
+            L.L.f_col.upload(S.col, 80);
+            L.L.f_val.upload(S.val, 80);
+            L.L.f_lrow.upload(S.lrow, 80);
+            L.L.f_fused = true;
+          }
+        }
+      }
       L.d.upload(H.d);
       L.s.upload(H.s);
       L.t.upload(H.t);
       L.p.upload(H.p);
       L.qinv.upload(H.q_inv);
-      L.w.alloc((size_t)H.n * Rmax * sizeof(T));
-      L.v.alloc((size_t)H.n * Rmax * sizeof(T));
+      L.alloc_arena((size_t)H.n * Rmax * sizeof(T));
       zero_dev(L.w.p, L.w.bytes);
       zero_dev(L.v.p, L.v.bytes);
 
@@ -902,7 +945,7 @@ class Engine : public EngineBase {
   static FL no_fl() { return FL{IoPtr<const D>{nullptr, nullptr, 0}, 0, 0, nullptr, nullptr}; }
   // flp != NULL: S1 is fused into this L solve -- whichever kernel touches a row first reads s[p] * b[p] (kernels FirstL)
   template <bool LOWER>
-  void launch_trsv(hipStream_t st, const DevLevel &L, int logR, int64_t &count, const FL *flp = nullptr) {
+  void launch_trsv(hipStream_t st, const DevLevel &L, int logR, int64_t &count, const FL *flp = nullptr, bool with_f = false) {
     const DevCsr &M = LOWER ? L.L : L.U;
     if (M.nrows == 0) return;
     const FL fl = (LOWER && flp) ? *flp : no_fl();
@@ -954,7 +997,7 @@ class Engine : public EngineBase {
           carried = true;
         }
         if (cdb) {
-          launch_band_cd<LOWER>(st, L, M, g0, g1, pre, ps0, ps1, extra, fl);
+          launch_band_cd<LOWER>(st, L, M, g0, g1, pre, ps0, ps1, extra, fl, LOWER && with_f);
           ++count;
           continue;
         }
@@ -999,8 +1042,15 @@ class Engine : public EngineBase {
                          M.rowid.as<int32_t>(), L.d.as<double>(), L.w.as<double>(), L.v.as<double>(), logR, 1,
                          blk_tmp.as<double>(), (int32_t)s1, fl);
       const int ktop = (int)round_up32(nt);
-      hipLaunchKernelGGL(k_strip_gemm_d<4>, dim3((unsigned)((nt + 15) / 16)), dim3(1024), 0, st, nt, ktop, L.topG.as<double>(), ktop,
-                         (const double *)blk_tmp.as<double>(), M.rowid.as<int32_t>() + s0, L.v.as<double>());
+      if (top_gemm == 1)
+        hipLaunchKernelGGL(k_strip_gemm_d<4>, dim3((unsigned)((nt + 15) / 16)), dim3(1024), 0, st, nt, ktop, L.topG.as<double>(), ktop,
+                           (const double *)blk_tmp.as<double>(), M.rowid.as<int32_t>() + s0, L.v.as<double>());
+      else if (top_gemm == 2)
+        hipLaunchKernelGGL(k_strip_gemm4_d<2>, dim3((unsigned)((nt + 15) / 16)), dim3(1024), 0, st, nt, ktop, L.topG.as<double>(), ktop,
+                           (const double *)blk_tmp.as<double>(), M.rowid.as<int32_t>() + s0, L.v.as<double>());
+      else
+        hipLaunchKernelGGL(k_strip_gemm4_d<4>, dim3((unsigned)((nt + 15) / 16)), dim3(1024), 0, st, nt, ktop, L.topG.as<double>(), ktop,
+                           (const double *)blk_tmp.as<double>(), M.rowid.as<int32_t>() + s0, L.v.as<double>());
       count += 2;
     } else {
       (void)st, (void)L, (void)logR, (void)count, (void)fl;
@@ -1018,7 +1068,7 @@ class Engine : public EngineBase {
   }
   template <bool LOWER>
   void launch_band_cd(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t g0, int32_t g1, int pre, int32_t ps0,
-                      int32_t ps1, unsigned extra, const FL &fl) {
+                      int32_t ps1, unsigned extra, const FL &fl, bool with_f = false) {
     if constexpr (std::is_same<T, double>::value) {
       // LDS: the component's right-hand sides + its row ids (the attribute for > 64 KB is set in bind_device)
       const size_t lds = cd_lds_bytes(M.cd_sparse);
@@ -1029,10 +1079,11 @@ class Engine : public EngineBase {
       (void)pre;  // (the packed streams already start at split[] for a carried band, at ptr[] otherwise)
       auto kern = M.cd_sparse ? k_band_cd<LOWER, true> : k_band_cd<LOWER, false>;
       hipLaunchKernelGGL(kern, dim3((unsigned)(g1 - g0) + extra), dim3(1024), lds, st, g0,
-                         M.wg_grp_ptr.as<int32_t>(), M.cd_desc.as<int32_t>(), M.ptr.as<int32_t>(), M.split.as<int32_t>(),
-                         M.col.as<int32_t>(), M.val.as<double>(), M.rowid.as<int32_t>(), L.d.as<double>(), L.w.as<double>(),
-                         L.v.as<double>(), M.tinv.as<double>(), M.mid_col.as<int32_t>(), M.mid_val.as<double>(),
-                         M.mid_lrow.as<uint8_t>(), pre ? 0 : 1, (int32_t)(g1 - g0), ps0, ps1, single_c0,
+                         M.wg_grp_ptr.as<int32_t>(), (with_f ? M.f_desc : M.cd_desc).template as<int32_t>(), M.ptr.as<int32_t>(),
+                         M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<double>(), M.rowid.as<int32_t>(), L.d.as<double>(),
+                         L.w.as<double>(), L.v.as<double>(), M.tinv.as<double>(), (with_f ? M.f_col : M.mid_col).template as<int32_t>(),
+                         (with_f ? M.f_val : M.mid_val).template as<double>(), (with_f ? M.f_lrow : M.mid_lrow).template as<uint8_t>(),
+                         pre ? 0 : 1, (int32_t)(g1 - g0), ps0, ps1, single_c0,
                          lds_rows, cd_dbg, fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
                          M.own_lvl.as<uint8_t>());
     } else {
@@ -1041,9 +1092,9 @@ class Engine : public EngineBase {
     }
   }
 
-  void launch_ldu(hipStream_t st, DevLevel &L, int logR, int64_t &count, const FL *fl = nullptr) {
+  void launch_ldu(hipStream_t st, DevLevel &L, int logR, int64_t &count, const FL *fl = nullptr, bool with_f = false) {
     if (!L.m) return;
-    launch_trsv<true>(st, L, logR, count, fl);
+    launch_trsv<true>(st, L, logR, count, fl, with_f);
     launch_trsv<false>(st, L, logR, count);
   }
 
@@ -1119,6 +1170,7 @@ class Engine : public EngineBase {
     // S1 (:359, :402) fused into the L solve that follows it (kernels FirstL): the R = 64 band pipeline only
     const bool fuse_s1 = fuse_gather && logR == 6 && band_pipe && m > 0;
     const FL fl{bin, ldb, nrhs, L.p.as<int32_t>(), L.s.as<double>()};
+    const bool fuse_f_lv = fuse_s1 && L.L.f_fused;  // S5 fused as well (level with thin F rows, all-component L plan)
     if (m && !fuse_s1) {  // S1  :359
       hipLaunchKernelGGL((k_gather_scale<D>), dim3(grid_for(m, logR)), dim3(256), 0, st, bin, ldb, nrhs,
                          L.p.as<int32_t>(), L.s.as<double>(), m, w, logR);
@@ -1135,7 +1187,9 @@ class Engine : public EngineBase {
         enqueue_level(st, l + 1, in_direct(w + m * R), R, out_direct(v + m * R), R, (int)R, logR, rank, count);  // :383-388
       // S5  :392-403   (v[m:n] already is "work[m:n] = y[m:n]")
       if (m) {
-        if (L.F_ncols) {
+        if (L.F_ncols && fuse_f_lv) {
+          // fused into the first touch of the L solve below: rhs = s b[p] - sum F v[m + k] (FirstL + the F streams)
+        } else if (L.F_ncols) {
           launch_spmm(st, L.F, m, v + m * R, bin, ldb, nrhs, L, (int64_t)0, w, logR);
           ++count;
         } else if (!fuse_s1) {
@@ -1146,7 +1200,7 @@ class Engine : public EngineBase {
       }
     }
     // S6  :406  (its right-hand side is w = s b[p] - F y from S5, or -- no F, or no Schur complement at all -- S1 again)
-    launch_ldu(st, L, logR, count, (fuse_s1 && !(nm && L.F_ncols)) ? &fl : nullptr);
+    launch_ldu(st, L, logR, count, (fuse_s1 && (!(nm && L.F_ncols) || fuse_f_lv)) ? &fl : nullptr, fuse_f_lv && nm && L.F_ncols);
     // S7  :411
     hipLaunchKernelGGL((k_scatter_scale<D>), dim3(grid_for(n, logR)), dim3(256), 0, st, v, L.qinv.as<int32_t>(),
                        L.t.as<double>(), n, yout, ldy, nrhs, logR);

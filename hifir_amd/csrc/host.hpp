@@ -791,6 +791,86 @@ inline void put_operand(double *base, int64_t plane, int64_t idx, const zdouble 
 // after plan_dense_blocks (the descriptors carry the inverse offsets).  The
 // rows of a component are dealt to the workgroup's 16 waves as CONTIGUOUS chunks balanced by (entries + rows); a wave
 // initialises its rows' right-hand sides in LDS and subtracts its entries, no other wave touches those rows in phase 1.
+// chunk boundaries of a component's packed stream (descriptor words 6.. wrow[17] uint8, 11.. wmid[17] uint16): wave w
+// takes rows while the cost so far (an entry = 1, a row = 2) stays within its share; at most 64 rows per wave (its row
+// ids sit one per lane)
+inline void cd_balance_chunks(int32_t *dsc, const std::vector<int32_t> &rowstart, int32_t nb, int32_t nmid) {
+  constexpr int NW = 16;
+  uint8_t *wrow = reinterpret_cast<uint8_t *>(&dsc[6]);
+  uint16_t *wmid = reinterpret_cast<uint16_t *>(&dsc[11]);
+  const double total = (double)nmid + 2.0 * nb;
+  int32_t r = 0;
+  for (int w = 0; w < NW; ++w) {
+    wrow[w] = (uint8_t)r;
+    wmid[w] = (uint16_t)rowstart[(size_t)r];
+    const double goal = (w == NW - 1) ? total + 1.0 : total * (w + 1) / NW;
+    const int32_t first = r;
+    while (r < nb && r - first < 64 && (double)rowstart[(size_t)r + 1] + 2.0 * (r + 1) <= goal + 1e-9) ++r;
+  }
+  if (r < nb) {  // (a chunk ran into the 64-row limit: spread the rows evenly instead -- nb <= 255: <= 16 rows per wave)
+    for (int w = 0; w < NW; ++w) {
+      const int32_t rr = (int32_t)((int64_t)nb * w / NW);
+      wrow[w] = (uint8_t)rr, wmid[w] = (uint16_t)rowstart[(size_t)rr];
+    }
+  }
+  wrow[NW] = (uint8_t)nb;
+  wmid[NW] = (uint16_t)nmid;
+}
+
+// S5 fused into the second L solve of a level (prec_solve.hpp:397-399 + :406): the streams of build_cd_streams with the
+// row's F entries appended -- a gather from the child's solution v[m + k] IS an "older source" of the row, and
+// rhs = s b[p] - sum L_old x - sum F v has the form the kernel already computes.  Sources are row numbers relative to
+// the L solve's vector w; the arena keeps v right behind w, so v[m + k] is row src_row0 + k with src_row0 = n + m.
+// Possible when every row of the triangle is first touched by the main phase of a component band (no prefix pass, no
+// carried prefix, no dense block band, no combined top): cd_f_fusable.
+inline bool cd_f_fusable(const BandPlan &P) {
+  if (P.band_cd.empty() || P.nbands() == 0) return false;
+  for (int64_t b = 0; b < P.nbands(); ++b) {
+    if (!P.band_cd[(size_t)b] || P.band_dense[(size_t)b] || P.band_prefix[(size_t)b]) return false;
+    if (!P.band_fused.empty() && P.band_fused[(size_t)b]) return false;
+  }
+  return true;
+}
+template <class T>
+struct CdFusedStreams {
+  std::vector<int32_t> desc, col;
+  std::vector<T> val;
+  std::vector<uint8_t> lrow;
+};
+template <class T>
+bool build_cd_streams_fused(const BandPlan &P, const Csr<T> &Lr, const Csr<T> &Fr, int64_t src_row0, CdFusedStreams<T> &S) {
+  S.desc = P.cd_desc;
+  S.col.clear(), S.val.clear(), S.lrow.clear();
+  if (src_row0 + Fr.ncols > (int64_t)std::numeric_limits<int32_t>::max() / 64) return false;
+  for (int64_t b = 0; b < P.nbands(); ++b)
+    for (int32_t g = P.band_wg_ptr[(size_t)b]; g < P.band_wg_ptr[(size_t)b + 1]; ++g)
+      for (int32_t c = P.wg_grp_ptr[(size_t)g]; c < P.wg_grp_ptr[(size_t)g + 1]; ++c) {
+        const int32_t s0 = P.grp_slot_ptr[(size_t)c], nb = P.grp_slot_ptr[(size_t)c + 1] - s0;
+        const int64_t mid0 = (int64_t)S.col.size();
+        std::vector<int32_t> rowstart((size_t)nb + 1, 0);
+        for (int32_t r = 0; r < nb; ++r) {
+          for (int32_t k = P.split[(size_t)(s0 + r)]; k < P.csplit[(size_t)(s0 + r)]; ++k) {
+            S.col.push_back(Lr.col[(size_t)k]);
+            S.val.push_back(Lr.val[(size_t)k]);
+            S.lrow.push_back((uint8_t)r);
+          }
+          const int32_t i = Lr.rowid[(size_t)(s0 + r)];
+          for (int32_t k = Fr.ptr[(size_t)i]; k < Fr.ptr[(size_t)i + 1]; ++k) {
+            S.col.push_back((int32_t)(src_row0 + Fr.col[(size_t)k]));
+            S.val.push_back(Fr.val[(size_t)k]);
+            S.lrow.push_back((uint8_t)r);
+          }
+          rowstart[(size_t)r + 1] = (int32_t)((int64_t)S.col.size() - mid0);
+        }
+        const int32_t nmid = rowstart[(size_t)nb];
+        if (nmid > 65535 || mid0 + nmid > (int64_t)std::numeric_limits<int32_t>::max()) return false;  // (keep S5 separate)
+        int32_t *dsc = &S.desc[(size_t)c * kCdDescWords];
+        dsc[2] = (int32_t)mid0, dsc[3] = nmid;
+        cd_balance_chunks(dsc, rowstart, nb, nmid);
+      }
+  return true;
+}
+
 inline void build_cd_streams(BandPlan &P, const std::vector<int32_t> &aptr /* row pointer of the slot-ordered CSR */) {
   const size_t ngrp = P.grp_slot_ptr.size() - 1;
   P.cd_desc.assign(ngrp * (size_t)kCdDescWords, 0);
@@ -801,7 +881,6 @@ inline void build_cd_streams(BandPlan &P, const std::vector<int32_t> &aptr /* ro
   P.own_lvl.clear();
   P.own_rptr.clear();
   if (P.band_cd.empty()) return;
-  constexpr int NW = 16;
   for (int64_t b = 0; b < P.nbands(); ++b) {
     if (!P.band_cd[(size_t)b]) continue;
     for (int32_t g = P.band_wg_ptr[(size_t)b]; g < P.band_wg_ptr[(size_t)b + 1]; ++g)
@@ -823,27 +902,7 @@ inline void build_cd_streams(BandPlan &P, const std::vector<int32_t> &aptr /* ro
         int32_t *dsc = &P.cd_desc[(size_t)c * kCdDescWords];
         dsc[0] = s0, dsc[1] = nb, dsc[2] = (int32_t)mid0, dsc[3] = nmid;
         std::memcpy(&dsc[4], &P.grp_inv_off[(size_t)c], 8);
-        uint8_t *wrow = reinterpret_cast<uint8_t *>(&dsc[6]);
-        uint16_t *wmid = reinterpret_cast<uint16_t *>(&dsc[11]);
-        // chunk boundaries: wave w takes rows while the cost so far (an entry = 1, a row = 2) stays within its share;
-        // at most 64 rows per wave (its row ids sit one per lane)
-        const double total = (double)nmid + 2.0 * nb;
-        int32_t r = 0;
-        for (int w = 0; w < NW; ++w) {
-          wrow[w] = (uint8_t)r;
-          wmid[w] = (uint16_t)rowstart[(size_t)r];
-          const double goal = (w == NW - 1) ? total + 1.0 : total * (w + 1) / NW;
-          const int32_t first = r;
-          while (r < nb && r - first < 64 && (double)rowstart[(size_t)r + 1] + 2.0 * (r + 1) <= goal + 1e-9) ++r;
-        }
-        if (r < nb) {  // (a chunk ran into the 64-row limit: spread the rows evenly instead -- nb <= 255: <= 16 rows per wave)
-          for (int w = 0; w < NW; ++w) {
-            const int32_t rr = (int32_t)((int64_t)nb * w / NW);
-            wrow[w] = (uint8_t)rr, wmid[w] = (uint16_t)rowstart[(size_t)rr];
-          }
-        }
-        wrow[NW] = (uint8_t)nb;
-        wmid[NW] = (uint16_t)nmid;
+        cd_balance_chunks(dsc, rowstart, nb, nmid);
         if (!P.cd_sparse) continue;
         // own stream: the rows' nonzeros inside the component, row offsets, and the depth levels (a row's level =
         // 1 + the deepest own source; rows are in dependency order, so one sweep suffices -- and levels must be

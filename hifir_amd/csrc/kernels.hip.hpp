@@ -1699,6 +1699,91 @@ __global__ void __launch_bounds__(256 * KS) k_strip_gemm_d(int nrows, int kend, 
   }
 }
 
+// The same product with ONE A-fragment load per four MFMAs: a wave owns a K split (16 of them) and ALL four column
+// tiles of the strip, so that per 4-k step it issues 1 load of A (HBM stream, every byte used once) and 4 loads of X
+// (2 MB, L2-resident) for 4 MFMAs -- 1.25 wave-loads per MFMA instead of 2 (k_strip_gemm_d: the four column-tile waves
+// of a K split load the same A fragment).  The product is bound by how many 512-byte wave-loads a compute unit gets
+// issued (~180 per us), not by the matrix cores (tests/microbench/mfma_bench.hip).  Partial tiles are summed in two
+// LDS rounds in a fixed order (deterministic).  kend: multiple of 8 * KU... of 32; A zero-padded in k; X finite there.
+template <int KU>
+__global__ void __launch_bounds__(1024) k_strip_gemm4_d(int nrows, int kend, const double *__restrict__ A, int lda,
+                                                        const double *__restrict__ X, const int32_t *__restrict__ rowmap,
+                                                        double *__restrict__ Out) {
+  __shared__ double red[8][4][4][64];  // [wave][tile][reg][lane], 64 KB
+  const int lane = threadIdx.x & 63;
+  const int ks = threadIdx.x >> 6;  // 0..15
+  const int cl = lane & 15, kq = lane >> 4;
+  const int i0 = blockIdx.x * 16;
+  v4f64 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
+  const int kstride = 16 * (4 * KU);
+  double a0[KU], b0[KU][4], a1[KU], b1[KU][4];
+  const double *Ap = A + ((int64_t)blockIdx.x * lda) * 16 + cl;
+  const double *Xp = X + cl;
+#define HIFAMD_SG_LOAD(aa, bb, kb_)                                                   \
+  _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                    \
+    const int kk = (kb_) + 4 * u + kq;                                                \
+    aa[u] = Ap[(int64_t)kk * 16];                                                     \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) bb[u][t] = Xp[((int64_t)kk << 6) + 16 * t]; \
+  }
+#define HIFAMD_SG_MFMA(aa, bb)                                                                    \
+  _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                                \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                 \
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], bb[u][t], acc[t], 0, 0, 0);          \
+  }
+  int kb = ks * (4 * KU);
+  if (kb < kend) { HIFAMD_SG_LOAD(a0, b0, kb) }
+  while (kb < kend) {
+    const int kb1 = kb + kstride;
+    if (kb1 < kend) { HIFAMD_SG_LOAD(a1, b1, kb1) }
+    HIFAMD_SG_MFMA(a0, b0)
+    if (kb1 >= kend) break;
+    const int kb2 = kb1 + kstride;
+    if (kb2 < kend) { HIFAMD_SG_LOAD(a0, b0, kb2) }
+    HIFAMD_SG_MFMA(a1, b1)
+    kb = kb2;
+  }
+#undef HIFAMD_SG_LOAD
+#undef HIFAMD_SG_MFMA
+  // round 1: waves 8..15 hand their tiles to waves 0..7; round 2: waves 1..7 to wave 0 (fixed order)
+  if (ks >= 8) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[ks - 8][t][r][lane] = acc[t][r];
+  }
+  __syncthreads();
+  if (ks < 8) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] += red[ks][t][r][lane];
+  }
+  __syncthreads();
+  if (ks >= 1 && ks < 8) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[ks][t][r][lane] = acc[t][r];
+  }
+  __syncthreads();
+  if (ks != 0) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = i0 + kq + 4 * r;
+    if (row >= nrows) continue;
+    const int64_t orow = (int64_t)(rowmap ? rowmap[row] : row) << 6;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      double val = acc[t][r];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) val += red[q][t][r][lane];
+      Out[orow + 16 * t + cl] = val;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Block-dense thin bands, step (2): Out[rowmap[r]] = sum_{k<=r} Tinv(r,k) X[k] for one diagonal block
 // (nb rows), Tinv = explicit inverse of the block's unit lower triangle, strip-major with
