@@ -358,6 +358,7 @@ class Engine : public EngineBase {
   bool spmm_tiles = true;       // E / F products on the matrix cores where rows share columns (HIFIR_AMD_SPMM_TILES=0: off)
   double spmm_tile_reuse = 2.0; // ... when a 16-row block has at least this many nonzeros per distinct column
   bool fuse_gather = true;  // S1 fused into the L solve (HIFIR_AMD_FUSE_S1=0: separate k_gather_scale launches)
+  int carry_wgs = 256;   // workgroups a band's launch may add for the carried prefix of the next band (HIFIR_AMD_CARRY_WGS)
   bool fuse_f = true;    // S5 fused into the second L solve where the plan allows (HIFIR_AMD_FUSE_F=0: separate k_spmm_epi launch)
   int top_gemm = 2;      // top operator product: 1 k_strip_gemm_d<4>, 2 k_strip_gemm4_d<2>, 3 k_strip_gemm4_d<4> (HIFIR_AMD_TOP_GEMM)
   int cd_dbg = 0;        // development aid (HIFIR_AMD_CD_DBG): phases of k_band_cd switched off for timing experiments
@@ -388,6 +389,7 @@ class Engine : public EngineBase {
     cd_dbg = env_int("HIFIR_AMD_CD_DBG", 0);
     top_gemm = env_int("HIFIR_AMD_TOP_GEMM", 2);
     fuse_f = env_int("HIFIR_AMD_FUSE_F", 1) != 0;
+    carry_wgs = std::max(1, env_int("HIFIR_AMD_CARRY_WGS", 256));
     fuse_gather = env_int("HIFIR_AMD_FUSE_S1", 1) != 0;
     spmm_tiles = env_int("HIFIR_AMD_SPMM_TILES", 1) != 0;
     use_twin = env_int("HIFIR_AMD_TWIN", 1);
@@ -498,6 +500,7 @@ class Engine : public EngineBase {
       E->spmm_tiles = spmm_tiles;
       E->top_gemm = top_gemm;
       E->fuse_f = fuse_f;
+      E->carry_wgs = carry_wgs;
       E->cd_dbg = cd_dbg;
       for (const auto &P : host.levels) E->add_level_adjoint(P);
       if (host.has_dense && host.dense.kind == 2) {  // LUP: ?getrs 'T' / ?gemv 'C' (LUP.hpp:150,187)
@@ -549,6 +552,7 @@ class Engine : public EngineBase {
       E->spmm_tiles = spmm_tiles;
       E->top_gemm = top_gemm;
       E->fuse_f = fuse_f;
+      E->carry_wgs = carry_wgs;
       E->cd_dbg = cd_dbg;
       E->max_nrhs = max_nrhs;
       E->Rmax = Rmax;
@@ -993,7 +997,7 @@ class Engine : public EngineBase {
         if (b + 1 < nb && !M.band_fused.empty() && M.band_fused[b + 1]) {
           ps0 = M.band_slot_ptr[b + 1];
           ps1 = M.band_slot_ptr[b + 2];
-          extra = (unsigned)std::min<int64_t>(256, std::max<int64_t>(1, ((int64_t)ps1 - ps0 + 15) / 16));
+          extra = (unsigned)std::min<int64_t>(carry_wgs, std::max<int64_t>(1, ((int64_t)ps1 - ps0 + 15) / 16));
           carried = true;
         }
         if (cdb) {
