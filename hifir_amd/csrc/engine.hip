@@ -1694,8 +1694,19 @@ class Engine : public EngineBase {
   }
   // v -= h q_prev (h = S.alpha, from the previous finish) fused with the reduction against q (nullptr: |v|^2)
   void gm_step(int64_t n, int nc, D *v, const D *qp, const D *q, const GmState<D> &S) {
-    if (ir_part.bytes < (size_t)kGmBlocks * 64 * sizeof(D)) ir_part.alloc((size_t)kGmBlocks * 64 * sizeof(D));
+    const size_t need = (size_t)kGmBlocks * kGmVals * 64 * sizeof(D);  // (what k_gm_block needs: no reallocation between the passes)
+    if (ir_part.bytes < need) ir_part.alloc(need);
     hipLaunchKernelGGL((k_gm_step<D>), dim3(kGmBlocks), dim3(256), 0, stream, n, nc, v, qp, (const D *)S.alpha, q, ir_part.as<D>());
+  }
+  DevBuf gm_red, gm_hb;  // reduced value list of a Gram-Schmidt block; its coefficients h[kGmBlock][64]
+  void gm_block(int64_t n, int nc, D *v, const D *Qp, int mp, const D *Qn, int mn, const GmState<D> &S) {
+    (void)S;
+    const size_t need = (size_t)kGmBlocks * kGmVals * 64 * sizeof(D);
+    if (ir_part.bytes < need) ir_part.alloc(need);
+    if (!gm_red.p) gm_red.alloc((size_t)kGmVals * 64 * sizeof(D));
+    if (!gm_hb.p) gm_hb.alloc((size_t)kGmBlock * 64 * sizeof(D));
+    hipLaunchKernelGGL((k_gm_block<D>), dim3(kGmBlocks), dim3(256), 0, stream, n, nc, v, Qp, mp, (const D *)gm_hb.as<D>(), Qn, mn,
+                       ir_part.as<D>());
   }
   void gm_finish(int nc, int mode, int k, int nirs, const GmState<D> &S) {
     hipLaunchKernelGGL((k_gm_finish<D>), dim3(1), dim3(256), 0, stream, (const D *)ir_part.as<D>(), kGmBlocks, nc, mode, k, nirs, S);
@@ -1751,11 +1762,18 @@ class Engine : public EngineBase {
           solve_dev((const D *)Qk(j), nc, w, nc, nc, rank, nullptr);  // w = M^{-1} Q(:,j)  (:58-59)
         }
         spmv_dev((const D *)w, nc, v, nc, nc, nullptr);  // v = A w  (:60)
-        for (int k = 0; k <= j; ++k) {                    // modified Gram-Schmidt (:63-66)
-          gm_step(n, nc, v, k ? Qk(k - 1) : nullptr, Qk(k), S);
-          gm_finish(nc, 0, k, 0, S);
+        // modified Gram-Schmidt (:63-66), kGmBlock basis vectors per pass over v (k_gm_block)
+        int kl = 0, ml = 0;
+        for (int k = 0; k <= j; k += kGmBlock) {
+          const int mn = std::min(kGmBlock, j + 1 - k);
+          gm_block(n, nc, v, k ? Qk(k - kGmBlock) : nullptr, k ? kGmBlock : 0, Qk(k), mn, S);
+          const int nv = mn + mn * (mn - 1) / 2;
+          hipLaunchKernelGGL((k_gm_reduce<D>), dim3((unsigned)nv), dim3(256), 0, stream, (const D *)ir_part.as<D>(), kGmBlocks, nv, nc,
+                             gm_red.as<D>());
+          hipLaunchKernelGGL((k_gm_hblock<D>), dim3(1), dim3(64), 0, stream, (const D *)gm_red.as<D>(), nc, k, mn, S, gm_hb.as<D>());
+          kl = k, ml = mn;
         }
-        gm_step(n, nc, v, Qk(j), nullptr, S);  // last axpy + |v|^2  (:65,67)
+        gm_block(n, nc, v, Qk(kl), ml, nullptr, 0, S);  // the last block's update + |v|^2  (:65,67)
         gm_finish(nc, 1, j, flexible ? nirs : 0, S);  // rotations, residual, stopping rules  (:73-103)
         if (j + 1 < restart) gm_colop(1, n, nc, Qk(j + 1), nc, v, nc, S);  // :69-70
         gm_read_ctl(S);

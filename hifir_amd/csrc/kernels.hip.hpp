@@ -1381,6 +1381,119 @@ __global__ void __launch_bounds__(256) k_gm_step(int64_t n, int nc, T *__restric
   }
 }
 
+// Modified Gram-Schmidt against a BLOCK of MB basis vectors in one pass over v (the orthogonalization is bound by
+// the bytes of v and Q it moves: 4 vector passes per basis vector one at a time, (2 MB + 2) / MB in blocks).  In exact
+// arithmetic the coefficients of modified Gram-Schmidt satisfy
+//     h_{k+a} = q_{k+a}^H v^(k+a) = q_{k+a}^H v^(k) - sum_{l<a} h_{k+l} (q_{k+a}^H q_{k+l}),
+// so one pass delivers b_a = q_{k+a}^H v^(k) and the block's Gram entries g_{a,l} = q_{k+a}^H q_{k+l} (l < a) -- the
+// basis vectors are being read anyway -- and a finishing kernel runs the recursion (k_gm_hblock).  The same pass first
+// applies the PREVIOUS block's update v -= sum_l h_l q_l (gmres.hpp:65).  Value list of a block: b_0..b_{mn-1}, then
+// g_{1,0}, g_{2,0}, g_{2,1}, ...; mn == 0: |v|^2 only (the pass behind the last block, :67).
+constexpr int kGmBlock = 4;
+constexpr int kGmVals = kGmBlock + kGmBlock * (kGmBlock - 1) / 2;
+template <class T>
+__global__ void __launch_bounds__(256) k_gm_block(int64_t n, int nc, T *__restrict__ v, const T *__restrict__ Qp, int mp,
+                                                  const T *__restrict__ hp /* [kGmBlock][64] */, const T *__restrict__ Qn,
+                                                  int mn, T *__restrict__ partial /* [gridDim.x][nv][nc] */) {
+  __shared__ T sm[256];
+  const int rpp = 256 / nc;
+  const int c = threadIdx.x % nc, rloc = threadIdx.x / nc;
+  const int64_t vec = n * nc;
+  T acc[kGmVals];
+#pragma unroll
+  for (int a = 0; a < kGmVals; ++a) acc[a] = vzero(T());
+  if (rloc < rpp) {
+    T h[kGmBlock];
+#pragma unroll
+    for (int l = 0; l < kGmBlock; ++l) h[l] = (l < mp) ? hp[l * 64 + c] : vzero(T());
+    const int64_t step = (int64_t)gridDim.x * rpp;
+    for (int64_t i = (int64_t)blockIdx.x * rpp + rloc; i < n; i += step) {
+      const int64_t o = i * nc + c;
+      T x = v[o];
+      if (mp) {
+#pragma unroll
+        for (int l = 0; l < kGmBlock; ++l)
+          if (l < mp) x = vsub(x, vmul(h[l], Qp[(int64_t)l * vec + o]));
+        v[o] = x;
+      }
+      if (mn == 0) {
+        acc[0] = vadd(acc[0], vfromreal(vabs2(x), T()));
+      } else {
+        T q[kGmBlock];
+#pragma unroll
+        for (int a = 0; a < kGmBlock; ++a) q[a] = (a < mn) ? Qn[(int64_t)a * vec + o] : vzero(T());
+#pragma unroll
+        for (int a = 0; a < kGmBlock; ++a) {
+          const T qc = vconj(q[a]);
+          acc[a] = vadd(acc[a], vmul(qc, x));
+#pragma unroll
+          for (int l = 0; l < a; ++l) acc[kGmBlock + a * (a - 1) / 2 + l] = vadd(acc[kGmBlock + a * (a - 1) / 2 + l], vmul(qc, q[l]));
+        }
+      }
+    }
+  }
+  // value a of the block lives at slot (a < kGmBlock ? a : mn + (a - kGmBlock)) of the launch's value list
+  const int nv = mn ? mn + mn * (mn - 1) / 2 : 1;
+#pragma unroll
+  for (int a = 0; a < kGmVals; ++a) {
+    int slot;
+    if (a < kGmBlock) {
+      slot = (a < mn || (mn == 0 && a == 0)) ? a : -1;
+    } else {
+      // (a - kGmBlock) enumerates pairs (row, l) with row = 1.., l < row in the order above
+      int row = 1, rem = a - kGmBlock;
+      while (rem >= row) rem -= row, ++row;
+      slot = row < mn ? mn + row * (row - 1) / 2 + rem : -1;
+    }
+    if (slot < 0) continue;  // (block-uniform)
+    __syncthreads();
+    sm[threadIdx.x] = acc[a];
+    __syncthreads();
+    if (threadIdx.x < nc) {
+      T tot = vzero(T());
+      for (int r = 0; r < rpp; ++r) tot = vadd(tot, sm[r * nc + threadIdx.x]);
+      partial[((int64_t)blockIdx.x * nv + slot) * nc + threadIdx.x] = tot;
+    }
+  }
+}
+
+// red[val][c] = sum over the blocks' partials, fixed order; one workgroup per value of the list
+template <class T>
+__global__ void __launch_bounds__(256) k_gm_reduce(const T *__restrict__ partial, int nblk, int nv, int nc, T *__restrict__ red) {
+  __shared__ T sm[256];
+  const int val = blockIdx.x;
+  const int rpp = 256 / nc;
+  const int c = threadIdx.x % nc, g = threadIdx.x / nc;
+  T acc = vzero(T());
+  if (g < rpp)
+    for (int b = g; b < nblk; b += rpp) acc = vadd(acc, partial[((int64_t)b * nv + val) * nc + c]);
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < nc) {
+    T tot = vzero(T());
+    for (int r = 0; r < rpp; ++r) tot = vadd(tot, sm[r * nc + c]);
+    red[val * 64 + c] = tot;
+  }
+}
+
+// the recursion of a block (see k_gm_block): h_{k+a} into the Hessenberg column and into hb[a][c] for the next pass
+template <class T>
+__global__ void __launch_bounds__(64) k_gm_hblock(const T *__restrict__ red, int nc, int k, int mn, GmState<T> S,
+                                                  T *__restrict__ hb /* [kGmBlock][64] */) {
+  const int c = threadIdx.x;
+  if (c >= nc) return;
+  T h[kGmBlock];
+#pragma unroll
+  for (int a = 0; a < kGmBlock; ++a) {
+    if (a >= mn) break;
+    T t = red[a * 64 + c];
+    for (int l = 0; l < a; ++l) t = vsub(t, vmul(h[l], red[(mn + a * (a - 1) / 2 + l) * 64 + c]));
+    h[a] = t;
+    S.w2[(size_t)c * S.restart + k + a] = t;
+    hb[a * 64 + c] = t;
+  }
+}
+
 // Finishes a reduction (fixed order: deterministic) and does the per-column scalar work of the driver.
 //   mode 0: h_k of step k -> w2[k], alpha                                       (:64)
 //   mode 1: |v|^2 of step j: rotations, residual, stopping rules                 (:67-103); alpha = |v| for :69-70
