@@ -358,6 +358,7 @@ class Engine : public EngineBase {
   bool spmm_tiles = true;       // E / F products on the matrix cores where rows share columns (HIFIR_AMD_SPMM_TILES=0: off)
   double spmm_tile_reuse = 2.0; // ... when a 16-row block has at least this many nonzeros per distinct column
   bool fuse_gather = true;  // S1 fused into the L solve (HIFIR_AMD_FUSE_S1=0: separate k_gather_scale launches)
+  bool spmm_split = true;  // tiled Schur products: one 16-row block per workgroup (k_spmm_tile4); HIFIR_AMD_SPMM_SPLIT=0: per wave
   int carry_wgs = 256;   // workgroups a band's launch may add for the carried prefix of the next band (HIFIR_AMD_CARRY_WGS)
   bool fuse_f = true;    // S5 fused into the second L solve where the plan allows (HIFIR_AMD_FUSE_F=0: separate k_spmm_epi launch)
   int top_gemm = 2;      // top operator product: 1 k_strip_gemm_d<4>, 2 k_strip_gemm4_d<2>, 3 k_strip_gemm4_d<4> (HIFIR_AMD_TOP_GEMM)
@@ -390,6 +391,7 @@ class Engine : public EngineBase {
     top_gemm = env_int("HIFIR_AMD_TOP_GEMM", 2);
     fuse_f = env_int("HIFIR_AMD_FUSE_F", 1) != 0;
     carry_wgs = std::max(1, env_int("HIFIR_AMD_CARRY_WGS", 256));
+    spmm_split = env_int("HIFIR_AMD_SPMM_SPLIT", 1) != 0;
     fuse_gather = env_int("HIFIR_AMD_FUSE_S1", 1) != 0;
     spmm_tiles = env_int("HIFIR_AMD_SPMM_TILES", 1) != 0;
     use_twin = env_int("HIFIR_AMD_TWIN", 1);
@@ -501,6 +503,7 @@ class Engine : public EngineBase {
       E->top_gemm = top_gemm;
       E->fuse_f = fuse_f;
       E->carry_wgs = carry_wgs;
+      E->spmm_split = spmm_split;
       E->cd_dbg = cd_dbg;
       for (const auto &P : host.levels) E->add_level_adjoint(P);
       if (host.has_dense && host.dense.kind == 2) {  // LUP: ?getrs 'T' / ?gemv 'C' (LUP.hpp:150,187)
@@ -553,6 +556,7 @@ class Engine : public EngineBase {
       E->top_gemm = top_gemm;
       E->fuse_f = fuse_f;
       E->carry_wgs = carry_wgs;
+      E->spmm_split = spmm_split;
       E->cd_dbg = cd_dbg;
       E->max_nrhs = max_nrhs;
       E->Rmax = Rmax;
@@ -1151,6 +1155,14 @@ class Engine : public EngineBase {
   void launch_spmm(hipStream_t st, const DevCsr &A, int64_t nrows, const D *x, InP bin, int64_t ldb, int nrhs,
                    const DevLevel &L, int64_t roff, D *out, int logR) {
     if constexpr (std::is_same<T, double>::value) {
+      // one block per workgroup, its groups dealt to the four waves: where the per-wave kernel would leave the chip short
+      // of waves (with more blocks the product runs at the fabric's gather bandwidth either way: 95 vs 100 us, 101 vs 123 us)
+      if (A.tl_nblk > 0 && A.tl_nblk < 4096 && logR == 6 && spmm_split) {
+        hipLaunchKernelGGL(k_spmm_tile4, dim3((unsigned)A.tl_nblk), dim3(256), 0, st, nrows, A.tl_nblk, A.tl_gptr.as<int32_t>(),
+                           A.tl_ucol.as<int32_t>(), A.tl_coef.as<double>(), (const double *)x, bin, ldb, nrhs, L.p.as<int32_t>(),
+                           L.s.as<double>(), roff, out);
+        return;
+      }
       if (A.tl_nblk > 0 && logR == 6) {
         const unsigned grid = (unsigned)std::min<int64_t>((A.tl_nblk + 3) / 4, 256 * 16);
         hipLaunchKernelGGL(k_spmm_tile, dim3(grid), dim3(256), 0, st, nrows, A.tl_nblk, A.tl_gptr.as<int32_t>(),

@@ -1126,6 +1126,78 @@ __global__ void __launch_bounds__(256) k_spmm_tile(int64_t nrows, int64_t nblk, 
   }
 }
 
+// The same product with ONE 16-row block per workgroup, its column groups dealt round-robin to the four waves (wave w
+// takes groups g0 + w, g0 + w + 4, ...).  A block is a sequential chain of groups (each waits for its gathers), and the
+// blocks of the reference's coupling matrices are long and uneven (level 2 of the 1M-row default hierarchy: 86 groups
+// on average, 188 at most, 1,987 blocks -- fewer waves than the chip holds, and the launch lasts as long as the longest
+// chain): four waves per block cut every chain to a quarter and quadruple the gathers in flight.  Partial tiles meet
+// in LDS; wave w finishes column tile w of the block (fixed order: deterministic).
+__global__ void __launch_bounds__(256) k_spmm_tile4(int64_t nrows, int64_t nblk, const int32_t *__restrict__ blk_gptr,
+                                                    const int32_t *__restrict__ ucol, const double *__restrict__ coef,
+                                                    const double *__restrict__ x, IoPtr<const double> bin_, int64_t ldb,
+                                                    int nrhs, const int32_t *__restrict__ p, const double *__restrict__ s,
+                                                    int64_t roff, double *__restrict__ out) {
+  __shared__ double red[4][4][4][64];  // [wave][tile][reg][lane], 32 KB
+  const double *__restrict__ bin = bin_.get();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int kq = lane >> 4, jc = lane & 15;
+  const int64_t b = (int64_t)xcd_block();
+  if (b >= nblk) return;
+  const int32_t g0 = rfl(blk_gptr[b]), g1 = rfl(blk_gptr[b + 1]);
+  v4f64 acc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) acc[ct] = v4f64{0.0, 0.0, 0.0, 0.0};
+  // this wave's groups: g0 + wave + 4 k, k = 0 .. ng - 1; same software pipeline as k_spmm_tile (loads unconditional,
+  // indices clamped to the wave's last group, whose coefficient is then zeroed)
+  const int32_t ng = (g1 - g0 > wave) ? (g1 - g0 - wave + 3) / 4 : 0;
+  if (ng > 0) {
+    const int32_t kl = ng - 1;
+    int32_t src[8];
+    double av[4], bv[4][4];
+#define HIFAMD_TL_GID(k) (g0 + wave + 4 * min((k), kl))
+#define HIFAMD_TL_SRC(slot, k) src[slot] = ucol[4 * (int64_t)HIFAMD_TL_GID(k) + kq];
+#define HIFAMD_TL_LOAD(slot, sslot, k)                                                         \
+  av[slot] = coef[64 * (int64_t)HIFAMD_TL_GID(k) + lane];                                      \
+  _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) bv[slot][ct] = x[((int64_t)src[sslot] << 6) + 16 * ct + jc];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) { HIFAMD_TL_SRC(q, q) }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { HIFAMD_TL_LOAD(q, q, q) }
+    for (int32_t k = 0; k < ng; k += 8) {
+#pragma unroll
+      for (int dd = 0; dd < 8; ++dd) {
+        const int32_t cur = k + dd;
+        HIFAMD_TL_LOAD((dd + 3) & 3, (dd + 3) & 7, cur + 3)
+        HIFAMD_TL_SRC((dd + 7) & 7, cur + 7)
+        const double am = cur < ng ? av[dd & 3] : 0.0;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bv[dd & 3][ct], acc[ct], 0, 0, 0);
+      }
+    }
+#undef HIFAMD_TL_GID
+#undef HIFAMD_TL_SRC
+#undef HIFAMD_TL_LOAD
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][ct][r][lane] = acc[ct][r];
+  __syncthreads();
+  // epilogue of column tile `wave`: C layout col = l & 15, row = (l >> 4) + 4 * reg
+  const int c = 16 * wave + jc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t i = 16 * b + kq + 4 * r;
+    if (i < nrows) {
+      const double tot = ((red[0][wave][r][lane] + red[1][wave][r][lane]) + red[2][wave][r][lane]) + red[3][wave][r][lane];
+      const int32_t srow = p[roff + i];
+      const double rhs = c < nrhs ? s[srow] * bin[(int64_t)srow * ldb + c] : 0.0;
+      out[(i << 6) + c] = rhs - tot;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // outer CRS SpMM: y = A x (RESID = false) or r = b - A x (RESID = true), tmp = 0; tmp += a*x
 // ---------------------------------------------------------------------------------------------
