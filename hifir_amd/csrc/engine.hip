@@ -408,10 +408,14 @@ class Engine : public EngineBase {
     band_opt.fuse_max_wgs = env_int("HIFIR_AMD_BAND_FUSE_WGS", 512);
     // component-dense bands (host.hpp plan_bands_cd): real data, fast mode; HIFIR_AMD_CD_ROWS=0 keeps the depth-cut bands
     band_opt.cd_rows = (sizeof(T) == sizeof(double) && band_opt.dense_block > 0) ? env_int("HIFIR_AMD_CD_ROWS", 128) : 0;
+    // complex handles: the same plan with 1 KB rows (k_band_cd_z keeps a component as two real planes: 96 rows = 96 KB);
+    // no sparse-own components, no combined top (both real-only)
+    if (sizeof(T) != sizeof(double) && band_opt.dense_block > 0) band_opt.cd_rows = std::min(144, env_int("HIFIR_AMD_CD_ROWS_Z", 96));
     band_opt.cd_max_nnz = env_int("HIFIR_AMD_CD_NNZ", 4000);  // (a band lasts as long as its heaviest component: 4.53 -> 4.44 ms)
     band_opt.cd_sparse_rows = std::min(192, env_int("HIFIR_AMD_CD_SPARSE_ROWS", 192));  // 0: thin triangles keep the flag bands
     band_opt.top_max = env_int("HIFIR_AMD_TOP_ROWS", 4096);      // combined top operator (host.hpp choose_top); 0 = off
     band_opt.top_few_wgs = env_int("HIFIR_AMD_TOP_WGS", 96);
+    if (sizeof(T) != sizeof(double)) band_opt.top_max = 0, band_opt.cd_sparse_rows = 0, band_opt.cd_max_nnz = env_int("HIFIR_AMD_CD_NNZ_Z", 0);
     if (band_opt.cd_rows > 240) band_opt.cd_rows = 240;  // (local row ids are bytes; 120 KB of the CU's 160 KB LDS)
   }
 
@@ -428,6 +432,10 @@ class Engine : public EngineBase {
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(false)));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(true)));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(true)));
+    }
+    if (sizeof(T) != sizeof(double) && band_opt.cd_rows > 0) {
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cd_z<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes_z()));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cd_z<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes_z()));
     }
   }
 
@@ -1074,6 +1082,10 @@ class Engine : public EngineBase {
     if (sparse) b += (size_t)kCdOwnCap * (sizeof(double) + 1) + 260 * sizeof(uint16_t) + 264;
     return b;
   }
+  size_t cd_lds_bytes_z() const {  // complex: two real planes of the component's right-hand sides + row ids
+    const size_t rows = (size_t)band_opt.cd_rows;
+    return rows * 128 * sizeof(double) + ((rows + 1) & ~(size_t)1) * sizeof(int32_t);
+  }
   template <bool LOWER>
   void launch_band_cd(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t g0, int32_t g1, int pre, int32_t ps0,
                       int32_t ps1, unsigned extra, const FL &fl, bool with_f = false) {
@@ -1095,8 +1107,12 @@ class Engine : public EngineBase {
                          lds_rows, cd_dbg, fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
                          M.own_lvl.as<uint8_t>());
     } else {
-      (void)st, (void)L, (void)M, (void)g0, (void)g1, (void)pre, (void)ps0, (void)ps1, (void)extra, (void)fl;
-      throw Error(HIFAMD_HIFIR_ERROR, "internal error: component-dense band on a complex handle");
+      (void)ps0, (void)ps1, (void)with_f;
+      if (extra || M.cd_sparse) throw Error(HIFAMD_HIFIR_ERROR, "internal error: carried prefix / sparse-own component band on a complex handle");
+      hipLaunchKernelGGL(k_band_cd_z<LOWER>, dim3((unsigned)(g1 - g0)), dim3(1024), cd_lds_bytes_z(), st, g0, M.wg_grp_ptr.as<int32_t>(),
+                         M.cd_desc.as<int32_t>(), M.rowid.as<int32_t>(), L.d.as<cplx>(), L.w.as<cplx>(), L.v.as<cplx>(),
+                         M.tinv.as<double>(), M.mid_col.as<int32_t>(), M.mid_val.as<cplx>(), M.mid_lrow.as<uint8_t>(), pre ? 0 : 1,
+                         (int32_t)band_opt.cd_rows, fl);
     }
   }
 

@@ -2315,6 +2315,184 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Component-dense band for COMPLEX data (gfx950 has no complex MFMA): the same scheme as k_band_cd<LOWER, false> --
+// a dependency component per workgroup, LDS-resident, x_c = Tinv_c (rhs_c - older-source sums) -- with the component's
+// right-hand sides kept as TWO real planes in LDS (re[rows][64], im[rows][64]) and the explicit inverse as two real
+// planes in HBM (host.hpp build_dense_block: P_re, then P_im), so that the product is four real MFMA streams per
+// output tile: x_re = P_re t_re - P_im t_im, x_im = P_re t_im + P_im t_re.  Rows are 1 KB (64 complex columns):
+// cd_rows is capped at 96 for complex handles (96 KB of LDS).  No carried prefixes (complex plans do not fuse bands),
+// no sparse-own variant, no staged top.  Units are (strip, 16-column tile): 4 per strip, heaviest strip first.
+// ---------------------------------------------------------------------------------------------
+template <bool LOWER>
+__global__ void __launch_bounds__(1024) k_band_cd_z(int32_t wg0, const int32_t *__restrict__ wg_grp_ptr,
+                                                    const int32_t *__restrict__ cd_desc, const int32_t *__restrict__ rowid,
+                                                    const cplx *__restrict__ d, cplx *w, cplx *v,
+                                                    const double *__restrict__ tinv, const int32_t *__restrict__ mid_col,
+                                                    const cplx *__restrict__ mid_val, const uint8_t *__restrict__ mid_lrow,
+                                                    int first_u, int32_t lds_rows, FirstL<cplx> fl) {
+  extern __shared__ double cd_tbuf[];  // re[lds_rows][64], im[lds_rows][64], then lds_rows row ids
+  double *t_re = cd_tbuf, *t_im = cd_tbuf + (size_t)lds_rows * 64;
+  int32_t *cd_rowid = reinterpret_cast<int32_t *>(cd_tbuf + (size_t)lds_rows * 128);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+  cplx *x = LOWER ? w : v;
+  const bool div_u = !LOWER && first_u;
+  const bool first_l = LOWER && first_u && fl.on();
+  const cplx *rhs = div_u ? (const cplx *)w : (first_l ? fl.bin.get() : (const cplx *)x);
+  const int64_t rstride = first_l ? fl.ldb : 64;
+  const int rlane = first_l ? min(lane, fl.nrhs - 1) : lane;
+  const int g = wg0 + (int)blockIdx.x;
+  const int32_t c_first = wg_grp_ptr[g], c_last = wg_grp_ptr[g + 1];
+  const int kq = lane >> 4;
+  for (int32_t c = c_first; c < c_last; ++c) {
+    const int32_t *dsc = cd_desc + (int64_t)c * 28;
+    const int32_t s0 = dsc[0], nb = dsc[1], mid0 = dsc[2];
+    const int64_t inv_off = ((int64_t)(uint32_t)dsc[5] << 32) | (uint32_t)dsc[4];
+    const uint8_t *wrow = reinterpret_cast<const uint8_t *>(dsc + 6);
+    const uint16_t *wmid = reinterpret_cast<const uint16_t *>(dsc + 11);
+    const int r0 = wrow[wave], nr = (int)wrow[wave + 1] - r0;
+    const int32_t e0 = mid0 + (int32_t)wmid[wave], e1 = mid0 + (int32_t)wmid[wave + 1];
+    // ---- phase 1a: right-hand sides of this wave's rows into the two LDS planes
+    int32_t h_i = 0, h_p = 0;
+    cplx h_d = cplx{1.0, 0.0};  // (U: the pivot; fused S1: the row's real scale in .x)
+    if (lane < nr) {
+      h_i = rowid[s0 + r0 + lane];
+      cd_rowid[r0 + lane] = h_i;
+      if (div_u) h_d = d[h_i];
+      if (first_l) {
+        h_p = fl.p[h_i];
+        h_d = cplx{fl.s[h_p], 0.0};
+      }
+    }
+    int32_t colv = 0, lrv = 0;
+    cplx valv = cplx{0.0, 0.0};
+    if (e0 + lane < e1) {  // first item of the wave's entry stream
+      colv = mid_col[e0 + lane];
+      valv = mid_val[e0 + lane];
+      lrv = mid_lrow[e0 + lane];
+    }
+    for (int j = 0; j < nr; j += 4) {
+      cplx t_[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int32_t i = rl32(first_l ? h_p : h_i, min(j + q, 63));
+        t_[q] = (j + q < nr) ? rhs[(int64_t)i * rstride + rlane] : cplx{0.0, 0.0};
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (j + q < nr) {
+          const cplx hd = cplx{rl64(h_d.x, min(j + q, 63)), rl64(h_d.y, min(j + q, 63))};
+          cplx val = t_[q];
+          if (div_u)
+            val = vdiv(val, hd);
+          else if (first_l)
+            val = lane < fl.nrhs ? vscale(hd.x, val) : cplx{0.0, 0.0};
+          t_re[((r0 + j + q) << 6) + lane] = val.x;
+          t_im[((r0 + j + q) << 6) + lane] = val.y;
+        }
+    }
+    // ---- phase 1b: the wave's entries (sources finished by earlier launches), items of 64, four gathers per batch
+    int cur_r = -1;
+    cplx acc = cplx{0.0, 0.0};
+    for (int32_t e = e0; e < e1; e += 64) {
+      const int cnt = min(64, e1 - e);
+      int32_t colv2 = 0, lrv2 = 0;
+      cplx valv2 = cplx{0.0, 0.0};
+      if (e + 64 + lane < e1) {
+        colv2 = mid_col[e + 64 + lane];
+        valv2 = mid_val[e + 64 + lane];
+        lrv2 = mid_lrow[e + 64 + lane];
+      }
+      for (int t = 0; t < cnt; t += 4) {
+        int32_t j_[4], r_[4];
+        cplx a_[4], xv_[4];
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2) {
+          const int idx = min(t + b2, 63);
+          j_[b2] = rl32(colv, idx);
+          a_[b2] = cplx{rl64(valv.x, idx), rl64(valv.y, idx)};
+          r_[b2] = rl32(lrv, idx);
+        }
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2)
+          if (t + b2 < cnt) xv_[b2] = x[((int64_t)j_[b2] << 6) + lane];
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2)
+          if (t + b2 < cnt) {
+            if (r_[b2] != cur_r) {  // (wave-uniform)
+              if (cur_r >= 0) {
+                t_re[(cur_r << 6) + lane] = acc.x;
+                t_im[(cur_r << 6) + lane] = acc.y;
+              }
+              cur_r = r_[b2];
+              acc = cplx{t_re[(cur_r << 6) + lane], t_im[(cur_r << 6) + lane]};
+            }
+            acc = vsub(acc, vmul(a_[b2], xv_[b2]));
+          }
+      }
+      colv = colv2;
+      valv = valv2;
+      lrv = lrv2;
+    }
+    if (cur_r >= 0) {
+      t_re[(cur_r << 6) + lane] = acc.x;
+      t_im[(cur_r << 6) + lane] = acc.y;
+    }
+    __syncthreads();
+    // ---- phase 2: x = Tinv * t on the real matrix cores, four products per output tile
+    const int lda = (nb + 31) & ~31;
+    const int S = (nb + 15) >> 4, nunits = S * 4;
+    const double *Are = tinv + inv_off, *Aim = Are + ((int64_t)((nb + 15) & ~15) * lda);  // plane_elems(nb, lda)
+    for (int q = wave; q < nunits; q += nw) {
+      const int strip = S - 1 - (q >> 2), ct = q & 3;
+      const int kend = min(nb, 16 * (strip + 1));
+      const int nk = (kend + 3) >> 2;  // k-steps of four columns
+      const double *Apr = Are + ((int64_t)strip * lda) * 16 + (lane & 15) + (int64_t)kq * 16;
+      const double *Api = Aim + ((int64_t)strip * lda) * 16 + (lane & 15) + (int64_t)kq * 16;
+      const double *Bre = t_re + ct * 16 + (lane & 15), *Bim = t_im + ct * 16 + (lane & 15);
+      v4f64 a_rr = v4f64{0.0, 0.0, 0.0, 0.0}, a_ii = a_rr, a_ri = a_rr, a_ir = a_rr;
+      constexpr int KU = 2;
+      double pr0[KU], pi0[KU], pr1[KU], pi1[KU];
+#define HIFAMD_CDZ_LOAD(pr, pi, t_)                                                       \
+  _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                        \
+    pr[u] = Apr[(int64_t)(KU * (t_) + u) * 64];                                           \
+    pi[u] = Api[(int64_t)(KU * (t_) + u) * 64];                                           \
+  }
+#define HIFAMD_CDZ_MFMA(pr, pi, t_)                                                       \
+  _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                        \
+    const int kb_ = 4 * (KU * (t_) + u) + kq;                                             \
+    const bool ok_ = kb_ < nb;                                                            \
+    const double br_ = ok_ ? Bre[kb_ << 6] : 0.0, bi_ = ok_ ? Bim[kb_ << 6] : 0.0;        \
+    a_rr = __builtin_amdgcn_mfma_f64_16x16x4f64(pr[u], br_, a_rr, 0, 0, 0);               \
+    a_ii = __builtin_amdgcn_mfma_f64_16x16x4f64(pi[u], bi_, a_ii, 0, 0, 0);               \
+    a_ri = __builtin_amdgcn_mfma_f64_16x16x4f64(pr[u], bi_, a_ri, 0, 0, 0);               \
+    a_ir = __builtin_amdgcn_mfma_f64_16x16x4f64(pi[u], br_, a_ir, 0, 0, 0);               \
+  }
+      // (the operand planes are zero padded in k up to lda, a multiple of 32: sets of KU k-steps never leave the strip)
+      const int nsets = (nk + KU - 1) / KU;
+      int t = 0;
+      HIFAMD_CDZ_LOAD(pr0, pi0, 0)
+      while (t < nsets) {
+        if (t + 1 < nsets) HIFAMD_CDZ_LOAD(pr1, pi1, t + 1)
+        HIFAMD_CDZ_MFMA(pr0, pi0, t)
+        if (t + 1 >= nsets) break;
+        if (t + 2 < nsets) HIFAMD_CDZ_LOAD(pr0, pi0, t + 2)
+        HIFAMD_CDZ_MFMA(pr1, pi1, t + 1)
+        t += 2;
+      }
+#undef HIFAMD_CDZ_LOAD
+#undef HIFAMD_CDZ_MFMA
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * strip + kq + 4 * r;
+        if (row < nb) x[((int64_t)cd_rowid[row] << 6) + ct * 16 + (lane & 15)] = cplx{a_rr[r] - a_ii[r], a_ri[r] + a_ir[r]};
+      }
+    }
+    __syncthreads();  // (the next component overwrites the LDS planes)
+  }
+}
+
 // Complex products on the real matrix cores: with X viewed as a real [rows][2R] block (re, im interleaved),
 // T1 = A_re * X and T2 = A_im * X are two real MFMA products (k_dense_gemm_d / k_tri_gemm_d at logR + 1);
 // this kernel recombines  out = (T1_re - T2_im) + i (T1_im + T2_re),  applies the output row permutation
