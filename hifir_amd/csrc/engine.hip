@@ -272,6 +272,10 @@ struct DevLevel {
   DevBuf w, v;  // arena: n * Rmax each, v right behind w in ONE allocation (row n + i of w is row i of v: the fused
                 // F streams address the child's solution through the L solve's vector)
   DevBuf arena;
+  // S7 fused into the last band of the final U solve (kernels LastU): q on the device, and the output rows the band
+  // does not write itself (the other bands' rows and the child's)
+  DevBuf q_s7, s7_list;
+  int64_t s7_n = -1;  // -1: not fused
   void alloc_arena(size_t bytes_each) {
     arena.alloc(2 * bytes_each);
     w.view(arena, 0, bytes_each);
@@ -358,6 +362,7 @@ class Engine : public EngineBase {
   bool spmm_tiles = true;       // E / F products on the matrix cores where rows share columns (HIFIR_AMD_SPMM_TILES=0: off)
   double spmm_tile_reuse = 2.0; // ... when a 16-row block has at least this many nonzeros per distinct column
   bool fuse_gather = true;  // S1 fused into the L solve (HIFIR_AMD_FUSE_S1=0: separate k_gather_scale launches)
+  bool fuse_out = true;    // S7 fused into the last band of the final U solve (HIFIR_AMD_FUSE_S7=0: k_scatter_scale over all rows)
   bool spmm_split = true;  // tiled Schur products: one 16-row block per workgroup (k_spmm_tile4); HIFIR_AMD_SPMM_SPLIT=0: per wave
   int carry_wgs = 256;   // workgroups a band's launch may add for the carried prefix of the next band (HIFIR_AMD_CARRY_WGS)
   bool fuse_f = true;    // S5 fused into the second L solve where the plan allows (HIFIR_AMD_FUSE_F=0: separate k_spmm_epi launch)
@@ -392,6 +397,7 @@ class Engine : public EngineBase {
     fuse_f = env_int("HIFIR_AMD_FUSE_F", 1) != 0;
     carry_wgs = std::max(1, env_int("HIFIR_AMD_CARRY_WGS", 256));
     spmm_split = env_int("HIFIR_AMD_SPMM_SPLIT", 1) != 0;
+    fuse_out = env_int("HIFIR_AMD_FUSE_S7", 1) != 0;
     fuse_gather = env_int("HIFIR_AMD_FUSE_S1", 1) != 0;
     spmm_tiles = env_int("HIFIR_AMD_SPMM_TILES", 1) != 0;
     use_twin = env_int("HIFIR_AMD_TWIN", 1);
@@ -512,6 +518,7 @@ class Engine : public EngineBase {
       E->fuse_f = fuse_f;
       E->carry_wgs = carry_wgs;
       E->spmm_split = spmm_split;
+      E->fuse_out = fuse_out;
       E->cd_dbg = cd_dbg;
       for (const auto &P : host.levels) E->add_level_adjoint(P);
       if (host.has_dense && host.dense.kind == 2) {  // LUP: ?getrs 'T' / ?gemv 'C' (LUP.hpp:150,187)
@@ -565,6 +572,7 @@ class Engine : public EngineBase {
       E->fuse_f = fuse_f;
       E->carry_wgs = carry_wgs;
       E->spmm_split = spmm_split;
+      E->fuse_out = fuse_out;
       E->cd_dbg = cd_dbg;
       E->max_nrhs = max_nrhs;
       E->Rmax = Rmax;
@@ -590,6 +598,9 @@ class Engine : public EngineBase {
         L.t.alias(Pl->t);
         L.p.alias(Pl->p);
         L.qinv.alias(Pl->qinv);
+        L.q_s7.alias(Pl->q_s7);
+        L.s7_list.alias(Pl->s7_list);
+        L.s7_n = Pl->s7_n;
         L.alloc_arena(Pl->w.bytes);
         if (L.w.bytes) zero_dev(L.w.p, L.w.bytes);
         if (L.v.bytes) zero_dev(L.v.p, L.v.bytes);
@@ -806,6 +817,25 @@ class Engine : public EngineBase {
           }
         }
       }
+      if constexpr (std::is_same<T, double>::value) {
+        // S7 fused into the last U band (LastU): that band must be a component band (its kernel knows how) and the level
+        // must have come with q (hifamd_add_level: optional)
+        const BandPlan &Up = H.Up;
+        const int64_t nbU = Up.nbands();
+        if (fuse_out && Rmax == 64 && H.m > 0 && nbU > 0 && !Up.band_cd.empty() && Up.band_cd[(size_t)nbU - 1] &&
+            !(L.top_n > 0 && L.top_bandU == nbU - 1) && (int64_t)H.q.size() == H.n) {
+          std::vector<uint8_t> covered((size_t)H.n, 0);
+          const int32_t s0 = Up.grp_slot_ptr[(size_t)Up.wg_grp_ptr[(size_t)Up.band_wg_ptr[(size_t)nbU - 1]]];
+          const int32_t s1 = Up.grp_slot_ptr[(size_t)Up.wg_grp_ptr[(size_t)Up.band_wg_ptr[(size_t)nbU]]];
+          for (int32_t sl = s0; sl < s1; ++sl) covered[(size_t)H.Ur.rowid[(size_t)sl]] = 1;
+          std::vector<int32_t> list;
+          for (int64_t i = 0; i < H.n; ++i)
+            if (!covered[(size_t)H.q_inv[(size_t)i]]) list.push_back((int32_t)i);
+          L.q_s7.upload(H.q);
+          L.s7_list.upload(list, 8);
+          L.s7_n = (int64_t)list.size();
+        }
+      }
       L.d.upload(H.d);
       L.s.upload(H.s);
       L.t.upload(H.t);
@@ -959,9 +989,12 @@ class Engine : public EngineBase {
   // chip, then ONE launch whose workgroups each own whole dependency components of the band.
   typedef FirstL<D> FL;
   static FL no_fl() { return FL{IoPtr<const D>{nullptr, nullptr, 0}, 0, 0, nullptr, nullptr}; }
+  typedef LastU<D> LU;
+  static LU no_lu() { return LU{IoPtr<D>{nullptr, nullptr, 0}, 0, 0, nullptr, nullptr}; }
   // flp != NULL: S1 is fused into this L solve -- whichever kernel touches a row first reads s[p] * b[p] (kernels FirstL)
   template <bool LOWER>
-  void launch_trsv(hipStream_t st, const DevLevel &L, int logR, int64_t &count, const FL *flp = nullptr, bool with_f = false) {
+  void launch_trsv(hipStream_t st, const DevLevel &L, int logR, int64_t &count, const FL *flp = nullptr, bool with_f = false,
+                   const LU *lup = nullptr) {
     const DevCsr &M = LOWER ? L.L : L.U;
     if (M.nrows == 0) return;
     const FL fl = (LOWER && flp) ? *flp : no_fl();
@@ -1013,7 +1046,9 @@ class Engine : public EngineBase {
           carried = true;
         }
         if (cdb) {
-          launch_band_cd<LOWER>(st, L, M, g0, g1, pre, ps0, ps1, extra, fl, LOWER && with_f);
+          // (the fused S7 -- LastU -- belongs to the LAST band of the final U solve only)
+          launch_band_cd<LOWER>(st, L, M, g0, g1, pre, ps0, ps1, extra, fl, LOWER && with_f,
+                                (!LOWER && lup && b + 1 == nb) ? *lup : no_lu());
           ++count;
           continue;
         }
@@ -1080,6 +1115,7 @@ class Engine : public EngineBase {
     const size_t rows = (size_t)(sparse ? band_opt.cd_sparse_rows : band_opt.cd_rows);
     size_t b = rows * 64 * sizeof(double) + ((rows + 1) & ~(size_t)1) * sizeof(int32_t);
     if (sparse) b += (size_t)kCdOwnCap * (sizeof(double) + 1) + 260 * sizeof(uint16_t) + 264;
+    b += rows * (sizeof(double) + sizeof(int32_t)) + 8;  // fused S7 (LastU): output row and scale of every row
     return b;
   }
   size_t cd_lds_bytes_z() const {  // complex: two real planes of the component's right-hand sides + row ids
@@ -1088,7 +1124,7 @@ class Engine : public EngineBase {
   }
   template <bool LOWER>
   void launch_band_cd(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t g0, int32_t g1, int pre, int32_t ps0,
-                      int32_t ps1, unsigned extra, const FL &fl, bool with_f = false) {
+                      int32_t ps1, unsigned extra, const FL &fl, bool with_f = false, const LU &lu = no_lu()) {
     if constexpr (std::is_same<T, double>::value) {
       // LDS: the component's right-hand sides + its row ids (the attribute for > 64 KB is set in bind_device)
       const size_t lds = cd_lds_bytes(M.cd_sparse);
@@ -1105,9 +1141,9 @@ class Engine : public EngineBase {
                          (with_f ? M.f_val : M.mid_val).template as<double>(), (with_f ? M.f_lrow : M.mid_lrow).template as<uint8_t>(),
                          pre ? 0 : 1, (int32_t)(g1 - g0), ps0, ps1, single_c0,
                          lds_rows, cd_dbg, fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
-                         M.own_lvl.as<uint8_t>());
+                         M.own_lvl.as<uint8_t>(), lu);
     } else {
-      (void)ps0, (void)ps1, (void)with_f;
+      (void)ps0, (void)ps1, (void)with_f, (void)lu;
       if (extra || M.cd_sparse) throw Error(HIFAMD_HIFIR_ERROR, "internal error: carried prefix / sparse-own component band on a complex handle");
       hipLaunchKernelGGL(k_band_cd_z<LOWER>, dim3((unsigned)(g1 - g0)), dim3(1024), cd_lds_bytes_z(), st, g0, M.wg_grp_ptr.as<int32_t>(),
                          M.cd_desc.as<int32_t>(), M.rowid.as<int32_t>(), L.d.as<cplx>(), L.w.as<cplx>(), L.v.as<cplx>(),
@@ -1116,10 +1152,11 @@ class Engine : public EngineBase {
     }
   }
 
-  void launch_ldu(hipStream_t st, DevLevel &L, int logR, int64_t &count, const FL *fl = nullptr, bool with_f = false) {
+  void launch_ldu(hipStream_t st, DevLevel &L, int logR, int64_t &count, const FL *fl = nullptr, bool with_f = false,
+                  const LU *lu = nullptr) {
     if (!L.m) return;
     launch_trsv<true>(st, L, logR, count, fl, with_f);
-    launch_trsv<false>(st, L, logR, count);
+    launch_trsv<false>(st, L, logR, count, nullptr, false, lu);
   }
 
   // complex products on the real matrix cores (operands: two real planes, see host.hpp mfma_operand)
@@ -1232,11 +1269,23 @@ class Engine : public EngineBase {
       }
     }
     // S6  :406  (its right-hand side is w = s b[p] - F y from S5, or -- no F, or no Schur complement at all -- S1 again)
-    launch_ldu(st, L, logR, count, (fuse_s1 && (!(nm && L.F_ncols) || fuse_f_lv)) ? &fl : nullptr, fuse_f_lv && nm && L.F_ncols);
-    // S7  :411
-    hipLaunchKernelGGL((k_scatter_scale<D>), dim3(grid_for(n, logR)), dim3(256), 0, st, v, L.qinv.as<int32_t>(),
-                       L.t.as<double>(), n, yout, ldy, nrhs, logR);
-    ++count;
+    // S7 (:411) fused into the last band of this U solve where the plan allows (kernels LastU; finalize built the list of
+    // output rows that band does not write)
+    const bool fuse_s7 = fuse_out && logR == 6 && m > 0 && L.s7_n >= 0;
+    const LU lu{yout, ldy, nrhs, L.q_s7.as<int32_t>(), L.t.as<double>()};
+    launch_ldu(st, L, logR, count, (fuse_s1 && (!(nm && L.F_ncols) || fuse_f_lv)) ? &fl : nullptr, fuse_f_lv && nm && L.F_ncols,
+               fuse_s7 ? &lu : nullptr);
+    if (fuse_s7) {
+      if (L.s7_n > 0) {
+        hipLaunchKernelGGL((k_scatter_scale_list<D>), dim3(grid_for(L.s7_n, logR)), dim3(256), 0, st, v, L.qinv.as<int32_t>(),
+                           L.t.as<double>(), L.s7_list.as<int32_t>(), L.s7_n, yout, ldy, nrhs);
+        ++count;
+      }
+    } else {
+      hipLaunchKernelGGL((k_scatter_scale<D>), dim3(grid_for(n, logR)), dim3(256), 0, st, v, L.qinv.as<int32_t>(),
+                         L.t.as<double>(), n, yout, ldy, nrhs, logR);
+      ++count;
+    }
   }
 
   // ---- y = M b: prec_prod (alg/prec_prod.hpp:55-147), the inverse direction of the apply ------------

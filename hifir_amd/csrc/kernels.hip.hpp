@@ -120,6 +120,19 @@ __device__ __forceinline__ T first_l_rhs(const T *__restrict__ bin, const FirstL
   return lane < f.nrhs ? vscale(f.s[src], b) : vzero(T());
 }
 
+// S7 fused into the LAST band of a level's final U solve: y[i] = t[i] * v[q_inv[i]] (prec_solve.hpp:411) is, for a row
+// r that this band finishes, y[q[r]] = t[q[r]] * v_r -- the band writes the level's output itself and v[r], which
+// nothing reads any more, not at all; k_scatter_scale_list serves the rows of the other bands and of the child.
+template <class T>
+struct LastU {
+  IoPtr<T> out;
+  int64_t ldy;
+  int nrhs;
+  const int32_t *q;
+  const double *t;
+  __device__ __forceinline__ bool on() const { return out.direct != nullptr || out.slot != nullptr; }
+};
+
 // ---------------------------------------------------------------------------------------------
 // S1: w[i] = s[p[i]] * b[p[i]],  rows [0, cnt)
 // ---------------------------------------------------------------------------------------------
@@ -172,6 +185,21 @@ __global__ void __launch_bounds__(256) k_scatter_scale(const T *__restrict__ v,
       const int64_t src = qinv[i];
       yout[i * ldy + lm.c] = vscale(t[i], v[(src << logR) + lm.c]);
     }
+  }
+}
+
+// the same for a LIST of output rows (the rows a fused last U band -- LastU -- does not write itself); R = 64
+template <class T>
+__global__ void __launch_bounds__(256) k_scatter_scale_list(const T *__restrict__ v, const int32_t *__restrict__ qinv,
+                                                            const double *__restrict__ t, const int32_t *__restrict__ list,
+                                                            int64_t cnt, IoPtr<T> yout_, int64_t ldy, int nrhs) {
+  T *__restrict__ yout = yout_.get();
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t k = wave; k < cnt; k += nwaves) {
+    const int64_t i = list[k];
+    if (lane < nrhs) yout[i * ldy + lane] = vscale(t[i], v[((int64_t)qinv[i] << 6) + lane]);
   }
 }
 
@@ -2103,7 +2131,8 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
                                                   int first_u, int32_t n_band, int32_t ps0, int32_t ps1, int32_t single_c0,
                                                   int32_t lds_rows, int dbg, FirstL<double> fl,
                                                   const double *__restrict__ own_val, const uint8_t *__restrict__ own_lsrc,
-                                                  const uint16_t *__restrict__ own_rptr, const uint8_t *__restrict__ own_lvl) {
+                                                  const uint16_t *__restrict__ own_rptr, const uint8_t *__restrict__ own_lvl,
+                                                  LastU<double> lu) {
   extern __shared__ double cd_tbuf[];  // [lds_rows][64] right-hand sides, then lds_rows row ids
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
@@ -2140,6 +2169,11 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
   uint8_t *ow_src = reinterpret_cast<uint8_t *>(ow_val + 4096);
   uint16_t *ow_rptr = reinterpret_cast<uint16_t *>(ow_src + 4096);
   uint8_t *ow_lvl = reinterpret_cast<uint8_t *>(ow_rptr + 260);
+  // fused S7 (LastU): output row and scale of every row of the component, behind everything else
+  const bool last_u = !LOWER && lu.on();
+  double *cd_ot = SPARSE ? reinterpret_cast<double *>(ow_lvl + 264) : reinterpret_cast<double *>(cd_rowid + ((lds_rows + 1) & ~1));
+  int32_t *cd_oi = reinterpret_cast<int32_t *>(cd_ot + lds_rows);
+  double *yout = last_u ? lu.out.get() : nullptr;
   for (int32_t c = c_first; c < c_last; ++c) {
     const int32_t *dsc = cd_desc + (int64_t)c * 28;
     const int32_t s0 = dsc[0], nb = dsc[1], mid0 = dsc[2];
@@ -2180,6 +2214,11 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
       if (first_l) {
         h_p = fl.p[h_i];
         h_d = fl.s[h_p];
+      }
+      if (last_u) {
+        const int32_t oi = lu.q[h_i];
+        cd_oi[r0 + lane] = oi;
+        cd_ot[r0 + lane] = lu.t[oi];
       }
     }
     // first item of the wave's entry stream: requested before the right-hand sides are waited for
@@ -2259,7 +2298,11 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
           const int eb = ow_rptr[r], ee = ow_rptr[r + 1];
           for (int e = eb; e < ee; ++e) a2 = a2 - ow_val[e] * cd_tbuf[((int)ow_src[e] << 6) + lane];
           if (ee > eb) cd_tbuf[(r << 6) + lane] = a2;
-          x[((int64_t)cd_rowid[r] << 6) + lane] = a2;
+          if (last_u) {
+            if (lane < lu.nrhs) yout[(int64_t)cd_oi[r] * lu.ldy + lane] = cd_ot[r] * a2;
+          } else {
+            x[((int64_t)cd_rowid[r] << 6) + lane] = a2;
+          }
         }
         __syncthreads();
       }
@@ -2305,9 +2348,17 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * strip + kq + 4 * r;
         if (row < nb) {
-          double *xo = x + ((int64_t)cd_rowid[row] << 6) + ch * 32 + (lane & 15);
-          xo[0] = acc0[r];
-          xo[16] = acc1[r];
+          if (last_u) {
+            const int cc = ch * 32 + (lane & 15);
+            double *yo = yout + (int64_t)cd_oi[row] * lu.ldy + cc;
+            const double tt = cd_ot[row];
+            if (cc < lu.nrhs) yo[0] = tt * acc0[r];
+            if (cc + 16 < lu.nrhs) yo[16] = tt * acc1[r];
+          } else {
+            double *xo = x + ((int64_t)cd_rowid[row] << 6) + ch * 32 + (lane & 15);
+            xo[0] = acc0[r];
+            xo[16] = acc1[r];
+          }
         }
       }
     }
