@@ -392,7 +392,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_note": traffic_note,
-                         "kernel": "one whole batched apply (hipGraph of k_band_cd/k_strip_gemm_d/k_trsv_wide/k_spmm_tile/k_spmm_epi/k_dense_gemm_d/k_scatter_scale; S1 fused into the first L kernel)",
+                         "kernel": "one whole batched apply (hipGraph of k_band_cd/k_strip_gemm4_d/k_trsv_wide/k_spmm_tile(4)/k_spmm_epi/k_dense_gemm_d/k_scatter_scale(_list); S1, S5 (level 0) and S7 fused into the component bands)",
                          "algorithmic_bytes": r["balg"], "apply_ms_hip_events": r["dev_ms"],
                          "algorithmic_bytes_by_stage": r["stage_bytes"], "stages_from_profile": stages},
             "cpu_baseline": cpu if world == 1 else None,  # timed on rank 0 at N = 1 only
