@@ -47,7 +47,8 @@ if os.path.exists(bj):
 
 def pmc(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if "hifamd" in r["Kernel_Name"] and r["Counter_Name"] == counter]
-    napply = max(1, sum(1 for r in rows if "k_scatter_scale" in r["Kernel_Name"]) // 6)  # 6 sparse levels -> 6 S7 per apply
+    # 6 sparse levels -> 6 S7 kernels per apply (k_scatter_scale, or k_scatter_scale_list behind a fused last U band)
+    napply = max(1, sum(1 for r in rows if "k_scatter_scale" in r["Kernel_Name"]) // 6)
     by = collections.OrderedDict()
     for r in rows:
         k = r["Kernel_Name"].split("(")[0].replace("void hifamd::", "").replace("hifamd::", "")
@@ -66,14 +67,36 @@ if kt and os.path.exists(bj):
     # primary workload's applies come first in the run (bench.py order).
     # (S1 is fused into the first L kernel since round 2: an apply starts with whatever follows the previous apply's
     #  level-0 scatter, and ends with a k_scatter_scale that is NOT followed by an S5 product.)
-    is_spmm = lambda nm: "k_spmm_epi" in nm or "k_spmm_tile" in nm
-    spans, cnts, bounds, start = [], [], [], 0
-    for i, r in enumerate(rows):
-        if "k_scatter_scale" in r["Kernel_Name"] and (i + 1 == len(rows) or not is_spmm(rows[i + 1]["Kernel_Name"])):
-            spans.append((int(r["End_Timestamp"]) - int(rows[start]["Start_Timestamp"])) / 1e6)
-            cnts.append(i - start + 1)
-            bounds.append((start, i))
-            start = i + 1
+    # (round 2, final: S1, S5 at level 0 and S7 are fused into the component bands, so no single kernel marks the end of
+    #  an apply any more.  bench.py reports the number of graph nodes of one apply; the primary workload's timed steps
+    #  replay the same node sequence back to back, so the applies are the maximal stretch in which the trace is
+    #  periodic with that period, cut into windows of that many kernels.)
+    line0 = json.loads(open(bj).read().strip().splitlines()[-1])
+    L_ = int(line0["config"]["launches_per_apply"])
+    sig = [(r["Kernel_Name"], r["Grid_Size_X"]) for r in rows]
+    best, cur_start = (0, 0), None
+    for i in range(len(sig) - L_):
+        if sig[i] == sig[i + L_]:
+            if cur_start is None:
+                cur_start = i
+            if i + 1 - cur_start > best[1] - best[0]:
+                best = (cur_start, i + 1)
+        else:
+            cur_start = None
+    p0, p1 = best[0], best[1] + L_  # the periodic stretch covers kernels [p0, p1)
+    # an apply starts where the first kernel of the graph stands: the stretch may begin mid-apply (warm-up applies of
+    # other shapes precede it), so align on the LAST complete window and walk backwards
+    spans, cnts, bounds = [], [], []
+    e = p1
+    while e - L_ >= p0:
+        a_ = e - L_
+        spans.append((int(rows[e - 1]["End_Timestamp"]) - int(rows[a_]["Start_Timestamp"])) / 1e6)
+        cnts.append(L_)
+        bounds.append((a_, e - 1))
+        e = a_
+    spans.reverse(), bounds.reverse()
+    # (align the windows with the end of the stretch only if the stretch ends with an apply: the kernel after it must
+    #  not continue the pattern -- true by construction of `best`)
     first = [s_ for s_, c_ in zip(spans, cnts) if c_ == cnts[0]]
     cnt = cnts
     line = json.loads(open(bj).read().strip().splitlines()[-1])
@@ -91,7 +114,7 @@ if kt and os.path.exists(bj):
         # (k_strip_gemm_d is the combined top operator of a level's triangular solves)
         group = {"k_gather_scale": "permute", "k_scatter_scale": "permute", "k_spmm_epi": "schur", "k_spmm_tile": "schur", "k_trsv_band": "ldu",
                  "k_band_cd": "ldu", "k_trsv_wide": "ldu", "k_thin_update": "ldu", "k_tri_gemm_d": "ldu",
-                 "k_strip_gemm_d": "ldu", "k_dense_gemm": "dense", "k_row_gather": "dense"}
+                 "k_strip_gemm": "ldu", "k_dense_gemm": "dense", "k_row_gather": "dense"}
         tms = {g: 0.0 for g in sb}
         per_kernel = {}
         napp = 0
@@ -115,8 +138,10 @@ if kt and os.path.exists(bj):
             tboth = (tms["permute"] + tms["ldu"]) / napp
             fused_note = {"algorithmic_bytes": both, "ms_per_apply": tboth, "achieved_GBs": both / (tboth * 1e-3) / 1e9,
                           "frac_of_8TBs": both / (tboth * 1e-3) / 8e12,
-                          "note": "S1 (half of the permute bytes) runs inside the first L kernel of each level: "
-                                  "'permute' alone overstates its rate, 'ldu' alone understates it"}
+                          "note": "S1 (half of the permute bytes) runs inside the first L kernel of each level and S7 inside "
+                                  "the last U band (only the rows of the other bands and of the child keep a scatter "
+                                  "kernel); level 0's S5 product runs inside the second L solve: 'permute' alone overstates "
+                                  "its rate, 'ldu' alone understates it"}
         else:
             fused_note = None
         stages = {g: {"algorithmic_bytes": sb[g], "ms_per_apply": tms[g] / napp,
