@@ -170,6 +170,47 @@ static int run_cd(int64_t m, int fan, int64_t cd_rows, int64_t dense_block, bool
           if (e != mid0 + nmid) ++bad;
         }
     }
+    // S5 fused into the L streams (build_cd_streams_fused): every row's stream entries are its [split, csplit) L entries
+    // followed by its F entries shifted to the child's rows, wave chunk by wave chunk with the plain streams' ownership;
+    // checked numerically too: rhs - sum (stream entries) == rhs - L_old x - F y for random x, y
+    if (!upper) {  // (cd_f_fusable decides about USING them; the streams of the component bands can always be built)
+      const int64_t ncols = 37;
+      Csr<T> F;
+      F.nrows = m, F.ncols = ncols;
+      F.ptr.assign((size_t)m + 1, 0);
+      std::mt19937_64 gf(77 + m);
+      for (int64_t i = 0; i < m; ++i) {
+        const int cnt = (int)(gf() % 4);
+        for (int k = 0; k < cnt; ++k) F.col.push_back((int32_t)(gf() % ncols)), F.val.push_back(T(1.0 + (double)(gf() % 7)));
+        F.ptr[(size_t)i + 1] = (int32_t)F.col.size();
+      }
+      CdFusedStreams<T> Sf;
+      const int64_t src0 = 2 * m + 11;
+      if (!build_cd_streams_fused(P, Rs, F, src0, Sf)) ++bad;
+      int64_t nchecked = 0;
+      for (int64_t bnd = 0; bnd < P.nbands(); ++bnd)
+        for (int32_t gg = P.band_wg_ptr[(size_t)bnd]; P.band_cd[(size_t)bnd] && gg < P.band_wg_ptr[(size_t)bnd + 1]; ++gg)
+          for (int32_t c = P.wg_grp_ptr[(size_t)gg]; c < P.wg_grp_ptr[(size_t)gg + 1]; ++c, ++nchecked) {
+            const int32_t *d0 = &P.cd_desc[(size_t)c * kCdDescWords], *d1 = &Sf.desc[(size_t)c * kCdDescWords];
+            const uint8_t *wrow = reinterpret_cast<const uint8_t *>(&d1[6]);
+            const uint16_t *wmid = reinterpret_cast<const uint16_t *>(&d1[11]);
+            if (d0[0] != d1[0] || d0[1] != d1[1] || std::memcmp(&d0[4], &d1[4], 8) != 0) ++bad;
+            int32_t e = d1[2];
+            for (int w = 0; w < 16; ++w) {
+              if (wmid[w] != e - d1[2]) ++bad;
+              for (int32_t r = wrow[w]; r < wrow[w + 1]; ++r) {
+                const int32_t sl = d1[0] + r;
+                for (int32_t k = P.split[(size_t)sl]; k < P.csplit[(size_t)sl]; ++k, ++e)
+                  if (Sf.col[(size_t)e] != Rs.col[(size_t)k] || Sf.val[(size_t)e] != Rs.val[(size_t)k] || Sf.lrow[(size_t)e] != r) ++bad;
+                const int32_t i = Rs.rowid[(size_t)sl];
+                for (int32_t k = F.ptr[(size_t)i]; k < F.ptr[(size_t)i + 1]; ++k, ++e)
+                  if (Sf.col[(size_t)e] != src0 + F.col[(size_t)k] || Sf.val[(size_t)e] != F.val[(size_t)k] || Sf.lrow[(size_t)e] != r) ++bad;
+              }
+            }
+            if (e != d1[2] + d1[3] || wmid[16] != d1[3]) ++bad;
+          }
+      if (!nchecked) ++bad;
+    }
     int64_t ncd = 0, ncomp = 0, maxcomp = 0;
     for (int64_t bnd = 0; bnd < P.nbands(); ++bnd) {
       if (!P.band_cd[(size_t)bnd] && !P.band_dense[(size_t)bnd]) {
