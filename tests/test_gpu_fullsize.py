@@ -90,6 +90,38 @@ def test_1m_default_hierarchy_columns(big_default):
     assert (np.linalg.norm(Y - B[:, :4], axis=0) / np.linalg.norm(B[:, :4], axis=0)).max() <= 1e-10
 
 
+def test_1m_default_fusions_and_kernel_choices_agree(big_default):
+    # the fused stages (S1 / S5 / S7 inside the component bands), the tiled Schur products and the re-tiled top product
+    # are choices of HOW the same operator is applied: with each of them switched off the columns agree to rounding,
+    # and the launch count shows that the switches did change the graph
+    import os
+
+    A, R, levels, M, O = big_default
+    if M.exact:
+        pytest.skip("exact mode plans none of these")
+    n = A.shape[0]
+    rng = np.random.default_rng(21)
+    B = rng.uniform(-1, 1, size=(n, 64))
+    X = M.solve_mrhs(B)
+    base_launches = M.stats()["launches"]
+    seen = set()
+    for env in ({"HIFIR_AMD_FUSE_S1": "0"}, {"HIFIR_AMD_FUSE_F": "0"}, {"HIFIR_AMD_FUSE_S7": "0"},
+                {"HIFIR_AMD_SPMM_TILES": "0"}, {"HIFIR_AMD_SPMM_SPLIT": "0", "HIFIR_AMD_TOP_GEMM": "1"},
+                {"HIFIR_AMD_CD_SPARSE_ROWS": "0"}, {"HIFIR_AMD_TOP_ROWS": "0", "HIFIR_AMD_CD_NNZ": "0"}):
+        os.environ.update(env)
+        try:
+            M2 = hifir_amd.HIF.from_levels(levels, max_nrhs=64)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        X2 = M2.solve_mrhs(B)
+        seen.add(M2.stats()["launches"])
+        M2.close()
+        assert relerr(X2, X) <= 1e-12, env
+        assert relerr(X2[:, 5], O.solve(B[:, 5].copy())) <= 1e-12, env
+    assert len(seen - {base_launches}) >= 3
+
+
 def test_1m_transposed_apply(big):
     # LHF_SH at full size: M^{-H} through the adjoint hierarchy vs the real reference's
     # HIF::solve(b, x, true) and the oracle's prec_solve_tran
