@@ -412,6 +412,7 @@ class Engine : public EngineBase {
     band_opt.fuse = env_int("HIFIR_AMD_BAND_FUSE", sizeof(T) == sizeof(double) ? 1 : 0) != 0;
     band_opt.fuse_reorder = band_opt.dense_block > 0;                  // exact mode keeps the reference's order
     band_opt.fuse_max_wgs = env_int("HIFIR_AMD_BAND_FUSE_WGS", 512);
+    band_opt.cd_fuse_max_wgs = env_int("HIFIR_AMD_CD_FUSE_WGS", 600);  // (4.26 -> 4.18 ms: the 1,216-workgroup last U band of level 1 gathers its own old sources)
     // component-dense bands (host.hpp plan_bands_cd): real data, fast mode; HIFIR_AMD_CD_ROWS=0 keeps the depth-cut bands
     band_opt.cd_rows = (sizeof(T) == sizeof(double) && band_opt.dense_block > 0) ? env_int("HIFIR_AMD_CD_ROWS", 128) : 0;
     // complex handles: the same plan with 1 KB rows (k_band_cd_z keeps a component as two real planes: 96 rows = 96 KB);

@@ -307,6 +307,7 @@ struct BandOptions {
   int64_t dense_min_rows = 96;   // thin bands shorter than this stay on the sequential workgroup
   int64_t cd_rows = 192;         // component-dense bands: rows per component (LDS-resident; 0 = scheme off)
   double cd_min_row_nnz = 4.0;   // ... only for triangles with at least this many nonzeros per row on average
+  int64_t cd_fuse_max_wgs = 0;   // a component band with more workgroups than this is not carried by its predecessor (0: always)
   int64_t cd_max_nnz = 0;        // ... and nonzeros per component (0 = no limit): spreads heavy rows over more units
   int64_t cd_sparse_max_depth = 64;  // ... only for triangles with at most this many wavefronts
   int64_t cd_sparse_rows = 192;  // sparse-own plans (BandPlan::cd_sparse) for the triangles below cd_min_row_nnz: rows per
@@ -1070,7 +1071,10 @@ void finish_band_plan(BandPlan &P, Csr<T> &A /* rows in slot order */, const Ban
     for (int64_t b = 1; b < nb_; ++b) {
       const int64_t wgs_prev = P.band_wg_ptr[(size_t)b] - P.band_wg_ptr[(size_t)b - 1];
       if (P.band_cd[(size_t)b]) {  // a component-dense band is carried by ANY preceding band kernel (its workgroups are
-        if (!P.band_dense[(size_t)b - 1]) P.band_fused[(size_t)b] = 1;  // handed out behind the band's own)
+        // handed out behind the band's own) -- unless the band fills the chip several times over by itself: then its
+        // own workgroups gather the old sources faster than the few carried ones of a narrow predecessor would
+        const int64_t wgs_b = P.band_wg_ptr[(size_t)b + 1] - P.band_wg_ptr[(size_t)b];
+        if (!P.band_dense[(size_t)b - 1] && (opt.cd_fuse_max_wgs <= 0 || wgs_b <= opt.cd_fuse_max_wgs)) P.band_fused[(size_t)b] = 1;
       } else if (!P.band_dense[(size_t)b] && !P.band_prefix[(size_t)b] && !P.band_dense[(size_t)b - 1] &&
                  !P.band_cd[(size_t)b - 1] && wgs_prev <= opt.fuse_max_wgs)
         P.band_fused[(size_t)b] = 1;
