@@ -70,7 +70,8 @@ HifAmdStatus hifamd_destroy(HifAmdHdl h); /* NULL-safe, frees HBM (cf. lhf?Destr
  *   L_B, U_B : m x m strict triangles, implicit unit diagonal, sorted row indices
  *   E        : (n-m) x m,   F : m x F_ncols (F_ncols == n-m, or 0 when absent; prec_solve.hpp:395)
  * d: m values; s,t: n REAL scalings (Prec.hpp:96-99); p, q_inv: n 0-based permutations.
- * p_inv and q are only needed by HIFAMD_SH / HIFAMD_M / HIFAMD_MH and may be NULL otherwise. */
+ * p_inv and q are only needed by HIFAMD_SH / HIFAMD_M / HIFAMD_MH and may be NULL otherwise (with q the plain solve
+ * also writes its output permutation from inside the last triangular kernel instead of a separate pass). */
 HifAmdStatus hifamd_add_level(HifAmdHdl h, int64_t m, int64_t n,
                               const int64_t *L_colptr, const int32_t *L_rowind, const void *L_vals,
                               const int64_t *U_colptr, const int32_t *U_rowind, const void *U_vals,
