@@ -25,9 +25,13 @@
 namespace hifamd {
 
 // Host-side parallel loop on plain std::thread (dynamic chunks off an atomic counter).  Deliberately NOT
-// OpenMP: the library lives in processes that already carry an OpenMP runtime of their own (PyTorch / MKL),
-// and a second runtime in the same address space corrupted host memory intermittently (seen as two
-// overwritten row pointers right after the dense factorization).  f(begin, end) handles [begin, end).
+// OpenMP: the library lives in processes that already carry an OpenMP runtime of their own (PyTorch / MKL).
+// Round 1 saw an intermittent host memory corruption with the OpenMP build inside such a process (two
+// overwritten row pointers right after the dense factorization); the sanitizer harness of round 2
+// (tests/cpp/import_san_test.cpp: ASan/UBSan/TSan, also with this loop on OpenMP and with a second OpenMP
+// runtime loaded) did NOT reproduce it, so a second runtime as the cause is a suspicion, not a finding --
+// what guards against a recurrence is check_level_invariants at finalize (import.hpp), not this choice.
+// f(begin, end) handles [begin, end).
 template <class F>
 inline void parallel_for(int64_t n, int64_t chunk, F f) {
   if (n <= 0) return;
