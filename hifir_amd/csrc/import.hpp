@@ -77,6 +77,11 @@ HostLevel<T> import_level(int64_t parent_nm, int64_t m, int64_t n, const int64_t
   if (!is_permutation(H.p, n) || !is_permutation(H.q_inv, n) || (p_inv && !is_permutation(H.p_inv, n)) ||
       (q && !is_permutation(H.q, n)))
     throw Error(kMismatchedSizes, "p, q_inv (and p_inv, q when given) must be permutations of [0, n)");
+  // ... and each other's inverses (Prec.hpp:317-321 builds them that way): the solve uses q to write its output from
+  // inside the last triangular kernel, the transposed solve and the products use both
+  for (int64_t i = 0; i < n; ++i)
+    if ((p_inv && H.p_inv[(size_t)H.p[(size_t)i]] != i) || (q && H.q[(size_t)H.q_inv[(size_t)i]] != i))
+      throw Error(kMismatchedSizes, "p_inv / q must be the inverse permutations of p / q_inv");
   H.Lr = ccs_to_csr(H.L, false);  // (row indices are range-checked there)
   H.Ur = ccs_to_csr(H.U, true);
   H.Er = ccs_to_csr(H.E, false);

@@ -245,6 +245,14 @@ def test_load_refuses_truncated_and_inconsistent_files(tmp_path):
             with pytest.raises(hifir_amd.HifAmdError) as e:
                 hifir_amd.HIF().add_level(lv)
             assert e.value.code == 2
+    # q / p_inv that are permutations but not the inverses of q_inv / p (the solve writes its output through q)
+    for key in ("q", "p_inv"):
+        lv = dict(levels[0])
+        lv[key] = lv[key].copy()
+        lv[key][[0, 1]] = lv[key][[1, 0]]
+        with pytest.raises(hifir_amd.HifAmdError) as e:
+            hifir_amd.HIF().add_level(lv)
+        assert e.value.code == 2
 
 
 def test_tensor_arguments_are_validated():
