@@ -351,3 +351,21 @@ def test_error_paths(cache):
     rc = hifir_amd.lib().hifamd_solve(M._h, b.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), 0)
     assert rc == 3  # aliasing b and x is refused (libhifir Ownership: b and x must not alias)
     assert b"alias" in hifir_amd.lib().hifamd_last_error()
+
+
+@pytest.mark.parametrize("name", ["p2d_100_tuned", "cd2d_48", "young1c"])
+def test_solve_without_the_optional_permutations(cache, name):
+    # q and p_inv are optional arguments of hifamd_add_level (only the transposed solve and the products need them);
+    # with q the plain solve writes its output from inside the last triangular kernel, without it through the separate
+    # scatter: the same columns either way, and the operators that need them are refused
+    levels, d, M, O = _get(cache, name)
+    ls = [dict(lv, q=None, p_inv=None) for lv in levels]
+    M2 = hifir_amd.HIF.from_levels(ls, max_nrhs=8)
+    rng = np.random.default_rng(8)
+    B = rng.uniform(-1, 1, size=(len(d["b"]), 5)).astype(M.dtype)
+    if np.iscomplexobj(B):
+        B = B + 1j * rng.uniform(-1, 1, size=B.shape)
+    assert relerr(M2.solve_mrhs(B), M.solve_mrhs(B)) <= 1e-13
+    with pytest.raises(hifir_amd.HifAmdError):
+        M2.solve_mrhs(B, trans=True)
+    M2.close()
