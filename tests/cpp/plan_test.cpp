@@ -286,8 +286,92 @@ static int run_cd(int64_t m, int fan, int64_t cd_rows, int64_t dense_block, bool
   return bad;
 }
 
+// The combined top operator (choose_top / build_top_operator): a triangle pair with the same pattern, both planned around
+// the top set T; G t_T must equal what plain substitution gives on T when t_T is the L right-hand side of the T rows
+// with everything below T already subtracted.
+static int run_top(int64_t m, int fan, int64_t top_max) {
+  typedef double T;
+  BandOptions opt;
+  opt.cd_rows = 64;
+  opt.dense_block = 2048;
+  opt.max_wg_rows = 16384;
+  opt.top_max = top_max;
+  int bad = 0;
+  Ccs<T> L = make_lower<T>(m, fan, 311 + m);
+  Csr<T> Lr = ccs_to_csr(L, false);
+  Ccs<T> U;
+  U.nrows = U.ncols = m;
+  U.colptr.assign((size_t)m + 1, 0);
+  for (int64_t j = 0; j < m; ++j) U.colptr[(size_t)j + 1] = U.colptr[(size_t)j] + (Lr.ptr[(size_t)j + 1] - Lr.ptr[(size_t)j]);
+  U.rowind.assign(Lr.col.begin(), Lr.col.end());
+  std::mt19937_64 g(5 + m);
+  std::uniform_real_distribution<double> u(-0.5, 0.5);
+  for (size_t k = 0; k < Lr.val.size(); ++k) U.vals.push_back(u(g));
+  Csr<T> Ur = ccs_to_csr(U, true);
+  const Csr<T> L0 = Lr, U0 = Ur;  // natural order, for the reference substitution
+  std::vector<T> d((size_t)m), b((size_t)m);
+  for (auto &v : d) v = 1.5 + u(g);
+  for (auto &v : b) v = u(g);
+  Schedule Ls = level_schedule(Lr, true), Us = level_schedule(Ur, false);
+  BandPlan Lp0 = plan_bands_cd(Lr, Ls, true, opt);
+  std::vector<uint8_t> top = choose_top(Lr, Ur, Lp0, opt.top_max, opt.top_few_wgs);
+  int64_t nt = 0;
+  for (uint8_t t : top) nt += t;
+  if (top.empty() || nt == 0) {
+    std::printf("top operator m=%ld fan=%d: no top set chosen\n", (long)m, fan);
+    return 1;  // (the cases below are built to have one)
+  }
+  BandPlan Lp = plan_bands_cd(Lr, Ls, true, opt, &top), Up = plan_bands_cd(Ur, Us, false, opt, &top);
+  Lr = permute_rows(Lr, Lp.order);
+  Ur = permute_rows(Ur, Up.order);
+  finish_band_plan(Lp, Lr, opt);
+  finish_band_plan(Up, Ur, opt);
+  const int32_t bL = (int32_t)Lp.nbands() - 1, bU = 0;
+  const int32_t r0L = Lp.grp_slot_ptr[(size_t)Lp.wg_grp_ptr[(size_t)Lp.band_wg_ptr[(size_t)bL]]];
+  const int32_t r0U = Up.grp_slot_ptr[(size_t)Up.wg_grp_ptr[(size_t)Up.band_wg_ptr[(size_t)bU]]];
+  std::vector<T> G;
+  const double growth = build_top_operator(Lr, Lp, r0L, Ur, Up, r0U, nt, d, G);
+  // reference: y = L^{-1} b, z = y / d, x = U^{-1} z in the natural order
+  std::vector<T> y = b;
+  for (int64_t i = 0; i < m; ++i)
+    for (int32_t k = L0.ptr[(size_t)i]; k < L0.ptr[(size_t)i + 1]; ++k) y[(size_t)i] -= L0.val[(size_t)k] * y[(size_t)L0.col[(size_t)k]];
+  std::vector<T> x((size_t)m);
+  for (int64_t i = 0; i < m; ++i) x[(size_t)i] = y[(size_t)i] / d[(size_t)i];
+  for (int64_t i = m - 1; i >= 0; --i)
+    for (int32_t k = U0.ptr[(size_t)i]; k < U0.ptr[(size_t)i + 1]; ++k) x[(size_t)i] -= U0.val[(size_t)k] * x[(size_t)U0.col[(size_t)k]];
+  // t_T: the L right-hand side of the T rows with the rows below T subtracted (what the prefix pass delivers), L slot order
+  std::vector<T> tT((size_t)nt);
+  for (int64_t r = 0; r < nt; ++r) {
+    const int32_t i = Lr.rowid[(size_t)(r0L + r)];
+    if (!top[(size_t)i]) ++bad;
+    T acc = b[(size_t)i];
+    for (int32_t k = L0.ptr[(size_t)i]; k < L0.ptr[(size_t)i + 1]; ++k)
+      if (!top[(size_t)L0.col[(size_t)k]]) acc -= L0.val[(size_t)k] * y[(size_t)L0.col[(size_t)k]];
+    tT[(size_t)r] = acc;
+  }
+  // every U source of a T row lies in T (the set is closed)
+  for (int64_t i = 0; i < m; ++i)
+    if (top[(size_t)i])
+      for (int32_t k = U0.ptr[(size_t)i]; k < U0.ptr[(size_t)i + 1]; ++k)
+        if (!top[(size_t)U0.col[(size_t)k]]) ++bad;
+  double err = 0.0, nrm = 0.0;
+  for (int64_t r = 0; r < nt; ++r) {
+    T acc = 0;
+    for (int64_t c = 0; c < nt; ++c) acc += G[(size_t)(r + c * nt)] * tT[(size_t)c];
+    const T want = x[(size_t)Lr.rowid[(size_t)(r0L + r)]];
+    err = std::max(err, std::abs(acc - want));
+    nrm = std::max(nrm, std::abs(want));
+  }
+  if (!(err <= 1e-11 * nrm)) ++bad;
+  std::printf("top operator m=%ld fan=%d: |T| = %ld of %ld rows, growth %.1f, relerr %.2e, bad=%d\n", (long)m, fan, (long)nt, (long)m,
+              growth, err / nrm, bad);
+  return bad;
+}
+
 int main() {
   int bad = 0;
+  bad += run_top(3000, 2, 4096);
+  bad += run_top(9000, 3, 8192);
   bad += run_cd<double>(3000, 2, 192, 2048);
   bad += run_cd<double>(9000, 3, 64, 512);
   bad += run_cd<double>(20000, 6, 192, 2048);
