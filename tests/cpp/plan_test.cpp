@@ -368,8 +368,57 @@ static int run_top(int64_t m, int fan, int64_t top_max) {
   return bad;
 }
 
+// Tiled form of a coupling block (build_spmm_tiles): the tiles reproduce A x -- every nonzero sits in exactly one
+// (block, group, column-in-group, row-in-block) cell, padding columns carry zero coefficients
+static int run_tiles(int64_t nrows, int64_t ncols, int per_row) {
+  Csr<double> A;
+  A.nrows = nrows, A.ncols = ncols;
+  A.ptr.assign(1, 0);
+  std::mt19937_64 g(17 + nrows);
+  std::uniform_real_distribution<double> u(-1.0, 1.0);
+  for (int64_t i = 0; i < nrows; ++i) {
+    std::vector<int32_t> cols;
+    const int64_t base = (i / 16) * 7 % std::max<int64_t>(1, ncols - 40);  // neighbouring rows share columns
+    for (int k = 0; k < per_row; ++k) cols.push_back((int32_t)(base + (int64_t)(g() % 40)));
+    std::sort(cols.begin(), cols.end());
+    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+    for (int32_t c : cols) A.col.push_back(c), A.val.push_back(u(g));
+    A.ptr.push_back((int32_t)A.col.size());
+  }
+  A.rowid.resize((size_t)nrows);
+  for (int64_t i = 0; i < nrows; ++i) A.rowid[(size_t)i] = (int32_t)i;
+  const SpmmTiles Tl = build_spmm_tiles(A);
+  std::vector<double> x((size_t)ncols), y((size_t)nrows, 0.0), yt((size_t)nrows, 0.0);
+  for (auto &v : x) v = u(g);
+  for (int64_t i = 0; i < nrows; ++i)
+    for (int32_t k = A.ptr[(size_t)i]; k < A.ptr[(size_t)i + 1]; ++k) y[(size_t)i] += A.val[(size_t)k] * x[(size_t)A.col[(size_t)k]];
+  int bad = 0;
+  if (Tl.nblk != (nrows + 15) / 16 || (int64_t)Tl.blk_gptr.size() != Tl.nblk + 1) ++bad;
+  for (int64_t b = 0; b < Tl.nblk; ++b)
+    for (int32_t gq = Tl.blk_gptr[(size_t)b]; gq < Tl.blk_gptr[(size_t)b + 1]; ++gq)
+      for (int k = 0; k < 4; ++k)
+        for (int r = 0; r < 16; ++r) {
+          const double a = Tl.coef[(size_t)(64 * (int64_t)gq + (k << 4) + r)];
+          const int64_t i = 16 * b + r;
+          if (i >= nrows) {
+            if (a != 0.0) ++bad;
+            continue;
+          }
+          const int32_t c = Tl.ucol[(size_t)(4 * (int64_t)gq + k)];
+          if (c < 0 || c >= ncols) ++bad; else yt[(size_t)i] += a * x[(size_t)c];
+        }
+  double err = 0.0, nrm = 0.0;
+  for (int64_t i = 0; i < nrows; ++i) err = std::max(err, std::abs(y[(size_t)i] - yt[(size_t)i])), nrm = std::max(nrm, std::abs(y[(size_t)i]));
+  if (!(err <= 1e-13 * nrm) || !(Tl.reuse >= 1.0)) ++bad;
+  std::printf("spmm tiles %ld x %ld, %d per row: %ld blocks, %d groups, reuse %.2f, relerr %.2e, bad=%d\n", (long)nrows, (long)ncols, per_row,
+              (long)Tl.nblk, Tl.blk_gptr.back(), Tl.reuse, err / nrm, bad);
+  return bad;
+}
+
 int main() {
   int bad = 0;
+  bad += run_tiles(1000, 5000, 12);
+  bad += run_tiles(77, 300, 30);
   bad += run_top(3000, 2, 4096);
   bad += run_top(9000, 3, 8192);
   bad += run_cd<double>(3000, 2, 192, 2048);
