@@ -362,6 +362,14 @@ class Engine : public EngineBase {
   bool spmm_tiles = true;       // E / F products on the matrix cores where rows share columns (HIFIR_AMD_SPMM_TILES=0: off)
   double spmm_tile_reuse = 2.0; // ... when a 16-row block has at least this many nonzeros per distinct column
   bool fuse_gather = true;  // S1 fused into the L solve (HIFIR_AMD_FUSE_S1=0: separate k_gather_scale launches)
+  // The hierarchy's tail as ONE dense operator: from the first level of at most tail_rows rows downwards (the small
+  // levels and the dense block behind them are a chain of ~15 dependent launches per solve for a few thousand rows),
+  // G = M_tail^{-1}, formed at finalize by running the device's own apply on the identity, one product per solve.
+  // Only where the effective rank of the dense block equals its numerical rank (the operator bakes that rank in; the graph
+  // cache keys on the effective rank too).  HIFIR_AMD_TAIL_ROWS=0: off.
+  int64_t tail_rows = 4096;
+  int64_t tail_level = -1, tail_n = 0;
+  DevBuf tailG;
   bool fuse_out = true;    // S7 fused into the last band of the final U solve (HIFIR_AMD_FUSE_S7=0: k_scatter_scale over all rows)
   bool spmm_split = true;  // tiled Schur products: one 16-row block per workgroup (k_spmm_tile4); HIFIR_AMD_SPMM_SPLIT=0: per wave
   int carry_wgs = 256;   // workgroups a band's launch may add for the carried prefix of the next band (HIFIR_AMD_CARRY_WGS)
@@ -398,6 +406,7 @@ class Engine : public EngineBase {
     carry_wgs = std::max(1, env_int("HIFIR_AMD_CARRY_WGS", 256));
     spmm_split = env_int("HIFIR_AMD_SPMM_SPLIT", 1) != 0;
     fuse_out = env_int("HIFIR_AMD_FUSE_S7", 1) != 0;
+    tail_rows = env_int("HIFIR_AMD_TAIL_ROWS", 4096);
     fuse_gather = env_int("HIFIR_AMD_FUSE_S1", 1) != 0;
     spmm_tiles = env_int("HIFIR_AMD_SPMM_TILES", 1) != 0;
     use_twin = env_int("HIFIR_AMD_TWIN", 1);
@@ -520,6 +529,7 @@ class Engine : public EngineBase {
       E->carry_wgs = carry_wgs;
       E->spmm_split = spmm_split;
       E->fuse_out = fuse_out;
+      E->tail_rows = tail_rows;
       E->cd_dbg = cd_dbg;
       for (const auto &P : host.levels) E->add_level_adjoint(P);
       if (host.has_dense && host.dense.kind == 2) {  // LUP: ?getrs 'T' / ?gemv 'C' (LUP.hpp:150,187)
@@ -574,6 +584,7 @@ class Engine : public EngineBase {
       E->carry_wgs = carry_wgs;
       E->spmm_split = spmm_split;
       E->fuse_out = fuse_out;
+      E->tail_rows = tail_rows;
       E->cd_dbg = cd_dbg;
       E->max_nrhs = max_nrhs;
       E->Rmax = Rmax;
@@ -607,6 +618,9 @@ class Engine : public EngineBase {
         if (L.v.bytes) zero_dev(L.v.p, L.v.bytes);
         E->lv.push_back(std::move(Lp));
       }
+      E->tailG.alias(tailG);
+      E->tail_level = tail_level;
+      E->tail_n = tail_n;
       E->dn.n = dn.n;
       E->dn.rank = dn.rank;
       E->dn.symm = dn.symm;
@@ -916,6 +930,43 @@ class Engine : public EngineBase {
     }
     pin_cap = 0;
     finalized = true;
+    build_tail_operator();
+  }
+
+  void build_tail_operator() {
+    if constexpr (std::is_same<T, double>::value) {
+      if (tail_rows <= 0 || band_opt.dense_block <= 0 || Rmax != 64 || lv.size() < 2) return;
+      size_t l0 = 0;
+      for (size_t l = 1; l < lv.size(); ++l)
+        if (lv[l]->n <= tail_rows) {
+          l0 = l;
+          break;
+        }
+      if (!l0) return;
+      const int64_t n = lv[l0]->n, ld = round_up32(n);
+      DevBuf I, O;
+      I.alloc((size_t)(n + 32) * 64 * sizeof(double));
+      O.alloc((size_t)(n + 32) * 64 * sizeof(double));
+      std::vector<double> hI((size_t)n * 64), hO((size_t)n * 64), G((size_t)(n * n), 0.0);
+      for (int64_t j0 = 0; j0 < n; j0 += 64) {
+        const int64_t jw = std::min<int64_t>(64, n - j0);
+        std::fill(hI.begin(), hI.end(), 0.0);
+        for (int64_t c = 0; c < jw; ++c) hI[(size_t)((j0 + c) * 64 + c)] = 1.0;
+        copy_h2d(I.p, hI.data(), hI.size() * sizeof(double));
+        int64_t cnt = 0;
+        enqueue_level(stream, l0, in_direct(I.as<D>()), 64, out_direct(O.as<D>()), 64, 64, 6, 0, cnt);
+        HIP_OK(hipStreamSynchronize(stream));
+        copy_d2h(hO.data(), O.p, hO.size() * sizeof(double));
+        for (int64_t c = 0; c < jw; ++c)
+          for (int64_t i = 0; i < n; ++i) G[(size_t)(i + (j0 + c) * n)] = hO[(size_t)(i * 64 + c)];
+      }
+      check_device_error();
+      for (double g : G)
+        if (!std::isfinite(g)) return;  // (a singular tail: keep the recursion, which reports what it finds)
+      tailG.upload(mfma_operand(G.data(), n, n, ld));
+      tail_level = (int64_t)l0;
+      tail_n = n;
+    }
   }
 
   // the sticky error word of the band kernels (a bounded spin expired); checked at sync points
@@ -1119,6 +1170,19 @@ class Engine : public EngineBase {
     b += rows * (sizeof(double) + sizeof(int32_t)) + 8;  // fused S7 (LastU): output row and scale of every row
     return b;
   }
+  // v_tail = G c_tail (build_tail_operator); the product reads up to 31 rows behind c_tail: they lie inside the level's
+  // arena (v follows w) and meet zero columns of the operand
+  bool launch_tail(hipStream_t st, const D *cin, D *zout) {
+    if constexpr (std::is_same<T, double>::value) {
+      const int nt = (int)tail_n, kt = (int)round_up32(tail_n);
+      hipLaunchKernelGGL(k_strip_gemm4_d<2>, dim3((unsigned)((nt + 15) / 16)), dim3(1024), 0, st, nt, kt, tailG.as<double>(), kt,
+                         (const double *)cin, (const int32_t *)nullptr, (double *)zout);
+      return true;
+    } else {
+      (void)st, (void)cin, (void)zout;
+      return false;
+    }
+  }
   size_t cd_lds_bytes_z() const {  // complex: two real planes of the component's right-hand sides + row ids
     const size_t rows = (size_t)band_opt.cd_rows;
     return rows * 128 * sizeof(double) + ((rows + 1) & ~(size_t)1) * sizeof(int32_t);
@@ -1253,6 +1317,9 @@ class Engine : public EngineBase {
       ++count;
       if (last)
         launch_dense(st, w + m * R, v + m * R, logR, rank, count);  // :371-381
+      else if ((int64_t)l + 1 == tail_level && logR == 6 && (!host.has_dense || eff_rank(rank) == dn.rank) &&  // (the rank it was built with)
+               launch_tail(st, w + m * R, v + m * R))
+        ++count;  // (levels l+1 ... and the dense block as one product)
       else
         enqueue_level(st, l + 1, in_direct(w + m * R), R, out_direct(v + m * R), R, (int)R, logR, rank, count);  // :383-388
       // S5  :392-403   (v[m:n] already is "work[m:n] = y[m:n]")

@@ -107,7 +107,8 @@ def test_1m_default_fusions_and_kernel_choices_agree(big_default):
     seen = set()
     for env in ({"HIFIR_AMD_FUSE_S1": "0"}, {"HIFIR_AMD_FUSE_F": "0"}, {"HIFIR_AMD_FUSE_S7": "0"},
                 {"HIFIR_AMD_SPMM_TILES": "0"}, {"HIFIR_AMD_SPMM_SPLIT": "0", "HIFIR_AMD_TOP_GEMM": "1"},
-                {"HIFIR_AMD_CD_SPARSE_ROWS": "0"}, {"HIFIR_AMD_TOP_ROWS": "0", "HIFIR_AMD_CD_NNZ": "0"}):
+                {"HIFIR_AMD_CD_SPARSE_ROWS": "0"}, {"HIFIR_AMD_TOP_ROWS": "0", "HIFIR_AMD_CD_NNZ": "0"},
+                {"HIFIR_AMD_TAIL_ROWS": "0"}, {"HIFIR_AMD_TAIL_ROWS": "12000"}):
         os.environ.update(env)
         try:
             M2 = hifir_amd.HIF.from_levels(levels, max_nrhs=64)
