@@ -45,14 +45,40 @@ if os.path.exists(bj):
     shutil.copy(bj, dst + "_bench_under_rocprof.json")
 
 
-def pmc(path, counter):
+def periodic_windows(sig, L_):
+    """[(first, last)] of the whole applies in a dispatch sequence: the longest stretch in which the sequence of
+    (kernel, grid) is periodic with the apply's launch count, cut into windows that end with the stretch."""
+    best, cur_start = (0, 0), None
+    for i in range(len(sig) - L_):
+        if sig[i] == sig[i + L_]:
+            if cur_start is None:
+                cur_start = i
+            if i + 1 - cur_start > best[1] - best[0]:
+                best = (cur_start, i + 1)
+        else:
+            cur_start = None
+    p0, p1 = best[0], best[1] + L_
+    out, e = [], p1
+    while e - L_ >= p0:
+        out.append((e - L_, e - 1))
+        e -= L_
+    out.reverse()
+    return out
+
+
+def pmc(path, counter, bench_json):
+    """per-apply counter sums of the primary workload's applies only (the hierarchy's set-up also launches kernels:
+    the tail operator is formed by applying the lower levels to the identity)"""
     rows = [r for r in csv.DictReader(open(path)) if "hifamd" in r["Kernel_Name"] and r["Counter_Name"] == counter]
-    # 6 sparse levels -> 6 S7 kernels per apply (k_scatter_scale, or k_scatter_scale_list behind a fused last U band)
-    napply = max(1, sum(1 for r in rows if "k_scatter_scale" in r["Kernel_Name"]) // 6)
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    L_ = int(json.loads(open(bench_json).read().strip().splitlines()[-1])["config"]["launches_per_apply"])
+    wins = periodic_windows([(r["Kernel_Name"], r["Grid_Size"]) for r in rows], L_)
+    napply = max(1, len(wins))
     by = collections.OrderedDict()
-    for r in rows:
-        k = r["Kernel_Name"].split("(")[0].replace("void hifamd::", "").replace("hifamd::", "")
-        by[k] = by.get(k, 0.0) + float(r["Counter_Value"])
+    for (a_, b_) in wins:
+        for r in rows[a_:b_ + 1]:
+            k = r["Kernel_Name"].split("(")[0].replace("void hifamd::", "").replace("hifamd::", "")
+            by[k] = by.get(k, 0.0) + float(r["Counter_Value"])
     return napply, {k: v / napply for k, v in by.items()}
 
 
@@ -73,30 +99,9 @@ if kt and os.path.exists(bj):
     #  periodic with that period, cut into windows of that many kernels.)
     line0 = json.loads(open(bj).read().strip().splitlines()[-1])
     L_ = int(line0["config"]["launches_per_apply"])
-    sig = [(r["Kernel_Name"], r["Grid_Size_X"]) for r in rows]
-    best, cur_start = (0, 0), None
-    for i in range(len(sig) - L_):
-        if sig[i] == sig[i + L_]:
-            if cur_start is None:
-                cur_start = i
-            if i + 1 - cur_start > best[1] - best[0]:
-                best = (cur_start, i + 1)
-        else:
-            cur_start = None
-    p0, p1 = best[0], best[1] + L_  # the periodic stretch covers kernels [p0, p1)
-    # an apply starts where the first kernel of the graph stands: the stretch may begin mid-apply (warm-up applies of
-    # other shapes precede it), so align on the LAST complete window and walk backwards
-    spans, cnts, bounds = [], [], []
-    e = p1
-    while e - L_ >= p0:
-        a_ = e - L_
-        spans.append((int(rows[e - 1]["End_Timestamp"]) - int(rows[a_]["Start_Timestamp"])) / 1e6)
-        cnts.append(L_)
-        bounds.append((a_, e - 1))
-        e = a_
-    spans.reverse(), bounds.reverse()
-    # (align the windows with the end of the stretch only if the stretch ends with an apply: the kernel after it must
-    #  not continue the pattern -- true by construction of `best`)
+    bounds = periodic_windows([(r["Kernel_Name"], r["Grid_Size_X"]) for r in rows], L_)
+    spans = [(int(rows[b_]["End_Timestamp"]) - int(rows[a_]["Start_Timestamp"])) / 1e6 for (a_, b_) in bounds]
+    cnts = [L_] * len(bounds)
     first = [s_ for s_, c_ in zip(spans, cnts) if c_ == cnts[0]]
     cnt = cnts
     line = json.loads(open(bj).read().strip().splitlines()[-1])
@@ -157,8 +162,8 @@ if kt and os.path.exists(bj):
 out = {}
 f, w = one("pmc_fetch/*/*counter_collection.csv"), one("pmc_write/*/*counter_collection.csv")
 if f and w:
-    nf, bf = pmc(f, "FETCH_SIZE")
-    nw, bw = pmc(w, "WRITE_SIZE")
+    nf, bf = pmc(f, "FETCH_SIZE", os.path.join(src, "bench_fetch.json"))
+    nw, bw = pmc(w, "WRITE_SIZE", os.path.join(src, "bench_write.json"))
     tf, tw = sum(bf.values()), sum(bw.values())
     out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --secondary 0 --extras 0",
            "applies_profiled": [nf, nw], "unit": "KiB per 64-RHS apply (default-parameter hierarchy)",
