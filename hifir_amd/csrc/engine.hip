@@ -376,11 +376,41 @@ class Engine : public EngineBase {
   bool fuse_f = true;    // S5 fused into the second L solve where the plan allows (HIFIR_AMD_FUSE_F=0: separate k_spmm_epi launch)
   int top_gemm = 2;      // top operator product: 1 k_strip_gemm_d<4>, 2 k_strip_gemm4_d<2>, 3 k_strip_gemm4_d<4> (HIFIR_AMD_TOP_GEMM)
   int cd_dbg = 0;        // development aid (HIFIR_AMD_CD_DBG): phases of k_band_cd switched off for timing experiments
+  // Column-sliced component bands (kernels.hip.hpp k_band_cs): a component band of at most cs_max_wgs workgroups is cut
+  // into 16-column slices (the heaviest component of a narrow band then runs on four compute units); a batch of fewer
+  // than 49 columns runs EVERY component band sliced and launches only the slices it has.  HIFIR_AMD_CS=0: off.
+  int cs_mode = 1;
+  int cs_max_wgs = 0;    // HIFIR_AMD_CS_MAX_WGS (full batches: measured equal to k_band_cd at every band width)
+  int act_cols = 64;     // columns of the 64-column arena that the tile being enqueued actually uses (enqueue_apply)
   int band_pipe = 1;     // 1: k_trsv_band_p (next row's head behind the last gathers), 0: k_trsv_band at R = 64 too
   BandOptions band_opt;  // how triangles are cut into bands (host.hpp)
   DevBuf errflag;        // sticky error word: a bounded spin of k_trsv_band expired
 #ifdef HIFAMD_PROBE
   DevBuf probe;          // development probe (make PROBE=1): wave timestamps of k_trsv_band, dumped at destruction
+#endif
+#ifdef HIFAMD_CSPROBE
+  DevBuf csprobe;        // development probe (make CSPROBE=1): phase stamps of the component band kernels
+  void csprobe_reset() {
+    if (!csprobe.p) return;
+    const unsigned z = 0;
+    HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_csprobe_cnt), &z, sizeof(z), 0, hipMemcpyHostToDevice, xfer_stream()));
+    HIP_OK(hipStreamSynchronize(xfer_stream()));
+  }
+  void csprobe_dump() {
+    if (!csprobe.p || !getenv("HIFIR_AMD_CSPROBE_OUT")) return;
+    (void)hipDeviceSynchronize();
+    unsigned cnt = 0;
+    (void)hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_csprobe_cnt), sizeof(cnt));
+    cnt = std::min(cnt, 400000u);
+    std::vector<unsigned long long> h((size_t)cnt * 12);
+    if (cnt) (void)hipMemcpy(h.data(), csprobe.p, h.size() * 8, hipMemcpyDeviceToHost);
+    if (FILE *f = fopen(getenv("HIFIR_AMD_CSPROBE_OUT"), "wb")) {
+      fwrite(h.data(), 8, h.size(), f);
+      fclose(f);
+    }
+    unsigned long long *np = nullptr;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_csprobe), &np, sizeof(np));
+  }
 #endif
   DevBuf blk_tmp;        // right-hand side of one diagonal block of a block-dense thin band
   DevBuf zt1, zt2;       // complex handles: the two real partial products A_re X, A_im X (k_zcombine)
@@ -401,6 +431,8 @@ class Engine : public EngineBase {
     gemm_waves = env_int("HIFIR_AMD_GEMM_WAVES", 16);
     band_pipe = env_int("HIFIR_AMD_BAND_PIPE", 1);
     cd_dbg = env_int("HIFIR_AMD_CD_DBG", 0);
+    cs_mode = env_int("HIFIR_AMD_CS", 1);
+    cs_max_wgs = env_int("HIFIR_AMD_CS_MAX_WGS", 0);
     top_gemm = env_int("HIFIR_AMD_TOP_GEMM", 2);
     fuse_f = env_int("HIFIR_AMD_FUSE_F", 1) != 0;
     carry_wgs = std::max(1, env_int("HIFIR_AMD_CARRY_WGS", 256));
@@ -448,6 +480,8 @@ class Engine : public EngineBase {
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(false)));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(true)));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(true)));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cs<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_lds_bytes(true)));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cs<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_lds_bytes(true)));
     }
     if (sizeof(T) != sizeof(double) && band_opt.cd_rows > 0) {
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd_z<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes_z()));
@@ -458,6 +492,9 @@ class Engine : public EngineBase {
   ~Engine() override {
     if (stream) (void)hipSetDevice(device);
     if (gm_ctl_host) (void)hipHostFree(gm_ctl_host);
+#ifdef HIFAMD_CSPROBE
+    csprobe_dump();
+#endif
 #ifdef HIFAMD_PROBE
     if (probe.p && getenv("HIFIR_AMD_PROBE_OUT")) {
       std::vector<unsigned long long> h(probe.bytes / 8);
@@ -531,6 +568,8 @@ class Engine : public EngineBase {
       E->fuse_out = fuse_out;
       E->tail_rows = tail_rows;
       E->cd_dbg = cd_dbg;
+      E->cs_mode = cs_mode;
+      E->cs_max_wgs = cs_max_wgs;
       for (const auto &P : host.levels) E->add_level_adjoint(P);
       if (host.has_dense && host.dense.kind == 2) {  // LUP: ?getrs 'T' / ?gemv 'C' (LUP.hpp:150,187)
         E->host.dense.kind = 2;
@@ -586,6 +625,8 @@ class Engine : public EngineBase {
       E->fuse_out = fuse_out;
       E->tail_rows = tail_rows;
       E->cd_dbg = cd_dbg;
+      E->cs_mode = cs_mode;
+      E->cs_max_wgs = cs_max_wgs;
       E->max_nrhs = max_nrhs;
       E->Rmax = Rmax;
       E->host.has_dense = host.has_dense;
@@ -901,6 +942,17 @@ class Engine : public EngineBase {
     }
     errflag.alloc(sizeof(unsigned));
     zero_dev(errflag.p, errflag.bytes);
+#ifdef HIFAMD_CSPROBE
+    if (getenv("HIFIR_AMD_CSPROBE_OUT") && !adjoint && !is_twin) {  // 12 words per workgroup
+      const unsigned cap = 400000;
+      csprobe.alloc((size_t)cap * 12 * 8);
+      zero_dev(csprobe.p, csprobe.bytes);
+      unsigned long long *pp = csprobe.as<unsigned long long>();
+      HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_csprobe), &pp, sizeof(pp), 0, hipMemcpyHostToDevice, xfer_stream()));
+      HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_csprobe_cap), &cap, sizeof(cap), 0, hipMemcpyHostToDevice, xfer_stream()));
+      HIP_OK(hipStreamSynchronize(xfer_stream()));
+    }
+#endif
 #ifdef HIFAMD_PROBE
     if (getenv("HIFIR_AMD_PROBE_OUT")) {  // 600 launches x 256 workgroups x 16 waves x 16 words
       probe.alloc((size_t)600 * 256 * 16 * 16 * 8);
@@ -1100,7 +1152,7 @@ class Engine : public EngineBase {
         if (cdb) {
           // (the fused S7 -- LastU -- belongs to the LAST band of the final U solve only)
           launch_band_cd<LOWER>(st, L, M, g0, g1, pre, ps0, ps1, extra, fl, LOWER && with_f,
-                                (!LOWER && lup && b + 1 == nb) ? *lup : no_lu());
+                                (!LOWER && lup && b + 1 == nb) ? *lup : no_lu(), b);
           ++count;
           continue;
         }
@@ -1163,12 +1215,24 @@ class Engine : public EngineBase {
   // one component-dense band (kernels.hip.hpp k_band_cd): real data, R = 64
   // LDS of k_band_cd: the component's right-hand sides + row ids; sparse-own plans add the own nonzeros (value + source
   // row, kCdOwnCap of them), the row offsets and the depth levels
+  // (dense-own plans: the rows are rounded up to a multiple of 32 -- the inverse product reads whole operand sets)
+  int32_t cd_lds_rows(bool sparse) const {
+    return (int32_t)(sparse ? band_opt.cd_sparse_rows : ((band_opt.cd_rows + 31) & ~(int64_t)31));
+  }
   size_t cd_lds_bytes(bool sparse) const {
-    const size_t rows = (size_t)(sparse ? band_opt.cd_sparse_rows : band_opt.cd_rows);
+    const size_t rows = (size_t)cd_lds_rows(sparse);
     size_t b = rows * 64 * sizeof(double) + ((rows + 1) & ~(size_t)1) * sizeof(int32_t);
     if (sparse) b += (size_t)kCdOwnCap * (sizeof(double) + 1) + 260 * sizeof(uint16_t) + 264;
     b += rows * (sizeof(double) + sizeof(int32_t)) + 8;  // fused S7 (LastU): output row and scale of every row
     return b;
+  }
+  // LDS of k_band_cs (one 16-column slice of a component): right-hand sides [rows][16], per row two doubles and three
+  // int32 (pivot / scale, output scale, row id, input row, output row); sparse-own plans add the own nonzeros
+  size_t cs_lds_bytes(bool sparse) const {
+    const size_t rows = (size_t)cd_lds_rows(sparse);
+    size_t b = rows * 18 * sizeof(double) + rows * 3 * sizeof(int32_t);
+    if (sparse) b += (size_t)kCdOwnCap * (sizeof(double) + 1) + 260 * sizeof(uint16_t) + 264;
+    return b + 16;
   }
   // v_tail = G c_tail (build_tail_operator); the product reads up to 31 rows behind c_tail: they lie inside the level's
   // arena (v follows w) and meet zero columns of the operand
@@ -1189,15 +1253,30 @@ class Engine : public EngineBase {
   }
   template <bool LOWER>
   void launch_band_cd(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t g0, int32_t g1, int pre, int32_t ps0,
-                      int32_t ps1, unsigned extra, const FL &fl, bool with_f = false, const LU &lu = no_lu()) {
+                      int32_t ps1, unsigned extra, const FL &fl, bool with_f = false, const LU &lu = no_lu(), size_t band = 0) {
     if constexpr (std::is_same<T, double>::value) {
       // LDS: the component's right-hand sides + its row ids (the attribute for > 64 KB is set in bind_device)
       const size_t lds = cd_lds_bytes(M.cd_sparse);
-      const int32_t lds_rows = (int32_t)(M.cd_sparse ? band_opt.cd_sparse_rows : band_opt.cd_rows);
+      const int32_t lds_rows = cd_lds_rows(M.cd_sparse);
       // one component per workgroup (the usual case): the kernel derives the component from blockIdx
       const int32_t c0 = M.host_wg_grp_ptr[(size_t)g0], c1 = M.host_wg_grp_ptr[(size_t)g1];
       const int32_t single_c0 = (c1 - c0 == g1 - g0) ? c0 : -1;
       (void)pre;  // (the packed streams already start at split[] for a carried band, at ptr[] otherwise)
+      // column slices (k_band_cs): narrow batches always, full batches where the band is narrow
+      const int nsl = std::min(4, (act_cols + 15) / 16);
+      const bool fits = (int64_t)(g1 - g0) * nsl + 4 * (int64_t)extra < (1LL << 30);
+      if (cs_mode && (nsl < 4 || g1 - g0 <= cs_max_wgs) && fits) {
+        auto kcs = M.cd_sparse ? k_band_cs<LOWER, true> : k_band_cs<LOWER, false>;
+        hipLaunchKernelGGL(kcs, dim3((unsigned)((g1 - g0) * nsl) + 4 * extra), dim3(256), cs_lds_bytes(M.cd_sparse), st, g0,
+                           M.wg_grp_ptr.as<int32_t>(), (with_f ? M.f_desc : M.cd_desc).template as<int32_t>(), M.ptr.as<int32_t>(),
+                           M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<double>(), M.rowid.as<int32_t>(), L.d.as<double>(),
+                           L.w.as<double>(), L.v.as<double>(), M.tinv.as<double>(), (with_f ? M.f_col : M.mid_col).template as<int32_t>(),
+                           (with_f ? M.f_val : M.mid_val).template as<double>(), (with_f ? M.f_lrow : M.mid_lrow).template as<uint8_t>(),
+                           pre ? 0 : 1, (int32_t)(g1 - g0), (int32_t)nsl, ps0, ps1, single_c0,
+                           lds_rows, cd_dbg, fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
+                           M.own_lvl.as<uint8_t>(), lu);
+        return;
+      }
       auto kern = M.cd_sparse ? k_band_cd<LOWER, true> : k_band_cd<LOWER, false>;
       hipLaunchKernelGGL(kern, dim3((unsigned)(g1 - g0) + extra), dim3(1024), lds, st, g0,
                          M.wg_grp_ptr.as<int32_t>(), (with_f ? M.f_desc : M.cd_desc).template as<int32_t>(), M.ptr.as<int32_t>(),
@@ -1496,6 +1575,7 @@ class Engine : public EngineBase {
     for (int64_t c0 = 64 * (int64_t)tfirst; c0 < nrhs; c0 += 64 * (int64_t)tstride) {
       const int64_t nc = std::min<int64_t>(64, nrhs - c0);
       const int logR = pick_logR(nc);
+      act_cols = (int)nc;
       const InP bin = slots ? InP{nullptr, (const D *const *)slots, c0} : in_direct(dB + c0);
       const OutP yout = slots ? OutP{nullptr, slots + 1, c0} : out_direct(dX + c0);
       if (kind == 0)
@@ -1522,6 +1602,12 @@ class Engine : public EngineBase {
                  int kind = 0) {
     check_batch(dB, ldb, dX, ldx, nrhs);
     HIP_OK(hipSetDevice(device));
+#ifdef HIFAMD_CSPROBE
+    if (csprobe.p) {  // (development build: the dump holds the LAST apply only)
+      HIP_OK(hipStreamSynchronize(user ? user : stream));
+      csprobe_reset();
+    }
+#endif
     if (kind == 1) ensure_prod_buffers();
     hipStream_t st = user ? user : stream;
     const int ntiles = (int)((nrhs + 63) / 64);

@@ -177,6 +177,17 @@ void analyze_level(HostLevel<T> &H, const BandOptions &band_opt, bool dump = fal
           distinct += std::unique(u.begin(), u.end()) - u.begin();
         }
       }
+      int32_t ck16 = 0, rowmax = 0, ne_max = 0;  // most entries of one wave chunk, of one row, of one component
+      if (P.band_cd[(size_t)b] && !P.cd_desc.empty()) {
+        for (int32_t c = P.wg_grp_ptr[(size_t)g0]; c < P.wg_grp_ptr[(size_t)g1]; ++c) {
+          const uint16_t *wm = reinterpret_cast<const uint16_t *>(&P.cd_desc[(size_t)c * kCdDescWords + 11]);
+          for (int q = 0; q < 16; ++q) ck16 = std::max<int32_t>(ck16, wm[q + 1] - wm[q]);
+          ne_max = std::max(ne_max, P.cd_desc[(size_t)c * kCdDescWords + 3]);
+        }
+        for (int32_t q = s0; q < s1; ++q) rowmax = std::max(rowmax, P.csplit[(size_t)q] - P.split[(size_t)q]);
+      }
+      std::fprintf(stderr, "PLAN2 level=%zu tri=%c band=%ld comp_entries_max=%d chunk_entries_max=%d row_entries_max=%d\n", level_no,
+                   tri ? 'U' : 'L', (long)b, ne_max, ck16, rowmax);
       int64_t own = 0, prevb = 0;  // nonzeros inside the rows' own component / gathered by the band kernel itself
       for (int32_t q = s0; q < s1; ++q) {
         own += A.ptr[(size_t)q + 1] - P.csplit[(size_t)q];

@@ -29,6 +29,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace hifamd {
 
@@ -2120,6 +2121,32 @@ __global__ void __launch_bounds__(NW * 64) k_tri_gemm_d(int nb, const double *__
 // carried prefix of the NEXT band, exactly as in k_trsv_band_p.  The summation order differs from the reference's
 // (tolerance-level, like every block-dense band); exact mode never plans such bands.
 // ---------------------------------------------------------------------------------------------
+// Development probe (make CSPROBE=1): every workgroup of k_band_cs / k_band_cd records wall-clock stamps (100 MHz) of its
+// phases into a global buffer (engine.hip dumps it to HIFIR_AMD_CSPROBE_OUT); compiled out by default.
+#ifdef HIFAMD_CSPROBE
+__device__ unsigned long long *g_csprobe = nullptr;
+__device__ unsigned g_csprobe_cap = 0, g_csprobe_cnt = 0;
+#define HIFAMD_CSP_DECL unsigned long long csp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define HIFAMD_CSP(k) \
+  if (threadIdx.x == 0) csp_[k] = wall_clock64();
+#define HIFAMD_CSP_FLUSH(kind, a, b)                                                   \
+  if (threadIdx.x == 0 && g_csprobe) {                                                 \
+    const unsigned slot_ = atomicAdd(&g_csprobe_cnt, 1u);                              \
+    if (slot_ < g_csprobe_cap) {                                                       \
+      unsigned long long *r_ = g_csprobe + (size_t)slot_ * 12;                         \
+      for (int k_ = 0; k_ < 8; ++k_) r_[k_] = csp_[k_];                                \
+      r_[8] = ((unsigned long long)(kind) << 32) | blockIdx.x;                         \
+      r_[9] = ((unsigned long long)gridDim.x << 32) | (unsigned)(a);                   \
+      r_[10] = (unsigned long long)(b);                                                \
+      r_[11] = __builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 20) /* HW_REG_XCC_ID */; \
+    }                                                                                  \
+  }
+#else
+#define HIFAMD_CSP_DECL
+#define HIFAMD_CSP(k)
+#define HIFAMD_CSP_FLUSH(kind, a, b)
+#endif
+
 template <bool LOWER, bool SPARSE>
 __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__restrict__ wg_grp_ptr,
                                                   const int32_t *__restrict__ cd_desc, const int32_t *__restrict__ ptr,
@@ -2134,6 +2161,8 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
                                                   const uint16_t *__restrict__ own_rptr, const uint8_t *__restrict__ own_lvl,
                                                   LastU<double> lu) {
   extern __shared__ double cd_tbuf[];  // [lds_rows][64] right-hand sides, then lds_rows row ids
+  HIFAMD_CSP_DECL
+  HIFAMD_CSP(0)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
   if ((int32_t)blockIdx.x >= n_band) {  // carried prefix of the next band over the sources older than this band
@@ -2142,6 +2171,8 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
     const double *pf_bin = (LOWER && fl.on()) ? fl.bin.get() : nullptr;
     trsv_stream_r64<double, 0, LOWER, true>(ps0 + pw, ps1, ((int32_t)gridDim.x - n_band) * nw, ptr, split, col, val, nullptr,
                                             rowid, d, LOWER ? w : v, w, lane, nullptr, 0, nullptr, true, nullptr, 0, 0, pf_bin, &fl);
+    HIFAMD_CSP(6)
+    HIFAMD_CSP_FLUSH(2 + (LOWER ? 0 : 4) + 16, n_band, 0)
     return;
   }
   double *x = LOWER ? w : v;
@@ -2244,6 +2275,7 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
               div_u ? t_[q] / hd : (first_l ? (lane < fl.nrhs ? hd * t_[q] : 0.0) : t_[q]);
         }
     }
+    HIFAMD_CSP(3)
     // ---- phase 1b: the wave's entries, items of 64, eight gathers per batch; the running row's sum stays in a register
     int cur_r = -1;
     double acc = 0.0;
@@ -2285,7 +2317,12 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
       lrv = lrv2;
     }
     if (cur_r >= 0) cd_tbuf[(cur_r << 6) + lane] = acc;
+    // (the inverse product reads whole operand sets of 32 rows: rows nb .. lda - 1 are zero; lds_rows is a multiple of 32)
+    if (!SPARSE)
+      for (int t = nb * 64 + (int)threadIdx.x; t < lda * 64; t += (int)blockDim.x) cd_tbuf[t] = 0.0;
+    HIFAMD_CSP(4)
     __syncthreads();
+    HIFAMD_CSP(5)
     if (SPARSE) {
       // ---- phase 2, sparse: substitution inside LDS, depth level by depth level.  The rows of a level are independent;
       // every own source sits in an earlier level (host.hpp build_cd_streams).  A wave takes a row at a time: the row's
@@ -2325,9 +2362,8 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
   {                                                                               \
     const int kb_ = 32 * (t_) + kq;                                               \
     _Pragma("unroll") for (int u = 0; u < KU; ++u) {                              \
-      const bool ok_ = kb_ + 4 * u < nb;                                          \
-      const double b0_ = ok_ ? Bp[(kb_ + 4 * u) << 6] : 0.0;                      \
-      const double b1_ = ok_ ? Bp[((kb_ + 4 * u) << 6) + 16] : 0.0;               \
+      const double b0_ = Bp[(kb_ + 4 * u) << 6];                                  \
+      const double b1_ = Bp[((kb_ + 4 * u) << 6) + 16];                           \
       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], b0_, acc0, 0, 0, 0);     \
       acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], b1_, acc1, 0, 0, 0);     \
     }                                                                             \
@@ -2364,6 +2400,323 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
     }
     __syncthreads();  // (the next component overwrites the LDS block)
   }
+  HIFAMD_CSP(6)
+  HIFAMD_CSP_FLUSH(1 + (LOWER ? 0 : 4) + (SPARSE ? 8 : 0) + 16, n_band, 0)
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column-sliced component band (round 3).  The same plan, descriptors and packed streams as k_band_cd, but a workgroup
+// solves ONE component for a SLICE of 16 right-hand-side columns: blockIdx.x = component-workgroup * nsl + slice, and
+// every step of the solve is column-separable, so the nsl slices of a component never talk to each other.  Why:
+//   * a narrow band (tens to a few hundred components: everything above the leaves of a triangle) lasts as long as ONE
+//     compute unit needs for its heaviest component -- sliced four ways, that component's gathers, its inverse product
+//     and its loads / stores run on four units at once (the critical path shrinks, the launch count does not change);
+//   * a batch of fewer than 49 columns launches only the slices it has: nrhs <= 16 moves a quarter of the vector bytes
+//     and issues a quarter of the gathers of the 64-column kernel (BASELINE configs[1] and [4]).
+// Mapping: 4 waves; a wave is four ROWS of 16 lanes (lane = 16 g + c: column cbase + c).  Lane group q = 4 wave + g
+// takes chunk q of the descriptor's sixteen row / entry chunks (k_band_cd gives chunk q to wave q): it loads its rows'
+// right-hand sides into LDS, then walks ITS entries -- (column, value, local row) fetched 16 at a time with one
+// coalesced load per lane group and broadcast inside the 16 lanes with DPP row_newbcast (a VALU move: no LDS, no
+// scalar round trip), eight 128-byte gathers per lane group in flight, the four lane groups of a wave in lock step.
+// Arithmetic per row and column is EXACTLY k_band_cd's (rhs, then the entries subtracted one by one in stream order;
+// the inverse product accumulated over k in steps of four from k = 0): both kernels give the same bits, whatever
+// the slicing -- a column's result does not depend on the width of the batch it travels in.
+// Workgroups beyond n_band * nsl run the carried prefix of the next band (full 64-column rows, as in k_band_cd).
+// ---------------------------------------------------------------------------------------------
+template <int IDX>
+__device__ __forceinline__ int32_t bc16(int32_t v) {  // lane IDX of every 16-lane row, to all lanes of that row
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + IDX, 0xf, 0xf, false);
+}
+template <int IDX>
+__device__ __forceinline__ double bc16(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)bc16<IDX>((int32_t)(b & 0xffffffffLL));
+  const unsigned hi = (unsigned)bc16<IDX>((int32_t)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>());
+    static_for<I + 1, N>(f);
+  }
+}
+__device__ __forceinline__ int wave_max4(int v) {  // max over the four 16-lane rows of a wave (v uniform inside a row)
+  return max(max(rl32(v, 0), rl32(v, 16)), max(rl32(v, 32), rl32(v, 48)));
+}
+
+// eight entries of every lane group (positions T0 .. T0+7 of the current item), see k_band_cs phase 1b
+template <int T0>
+__device__ __forceinline__ void cs_batch(int32_t colv, double valv, int32_t lrv, int32_t left, const double *__restrict__ x,
+                                         int cc, int l16, double *tb, int &cur, double &acc) {
+  int32_t j_[8], r_[8];
+  double a_[8], xv_[8], rv_[8];
+  bool nw_[8];
+  static_for<0, 8>([&](auto ic) {
+    constexpr int u = decltype(ic)::value;
+    j_[u] = bc16<T0 + u>(colv);
+    a_[u] = bc16<T0 + u>(valv);
+    r_[u] = bc16<T0 + u>(lrv);
+  });
+#pragma unroll
+  for (int u = 0; u < 8; ++u) xv_[u] = (T0 + u < left) ? x[((int64_t)j_[u] << 6) + cc] : 0.0;
+  // right-hand sides of the rows that START in this batch: requested beside the gathers (a lane group meets its rows
+  // once, in order, and nobody else touches them in this phase)
+  int prev = cur;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    nw_[u] = (T0 + u < left) && r_[u] != prev;
+    rv_[u] = nw_[u] ? tb[(r_[u] << 4) + l16] : 0.0;
+    if (T0 + u < left) prev = r_[u];
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (T0 + u < left) {
+      if (nw_[u]) {
+        if (cur >= 0) tb[(cur << 4) + l16] = acc;
+        cur = r_[u];
+        acc = rv_[u];
+      }
+      acc = acc - a_[u] * xv_[u];
+    }
+}
+
+template <bool LOWER, bool SPARSE>
+__global__ void __launch_bounds__(256) k_band_cs(int32_t wg0, const int32_t *__restrict__ wg_grp_ptr,
+                                                 const int32_t *__restrict__ cd_desc, const int32_t *__restrict__ ptr,
+                                                 const int32_t *__restrict__ split, const int32_t *__restrict__ col,
+                                                 const double *__restrict__ val, const int32_t *__restrict__ rowid,
+                                                 const double *__restrict__ d, double *w, double *v,
+                                                 const double *__restrict__ tinv, const int32_t *__restrict__ mid_col,
+                                                 const double *__restrict__ mid_val, const uint8_t *__restrict__ mid_lrow,
+                                                 int first_u, int32_t n_band, int32_t nsl, int32_t ps0, int32_t ps1,
+                                                 int32_t single_c0, int32_t lds_rows, int dbg, FirstL<double> fl,
+                                                 const double *__restrict__ own_val, const uint8_t *__restrict__ own_lsrc,
+                                                 const uint16_t *__restrict__ own_rptr, const uint8_t *__restrict__ own_lvl,
+                                                 LastU<double> lu) {
+  extern __shared__ double cs_buf[];
+  HIFAMD_CSP_DECL
+  HIFAMD_CSP(0)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int32_t nbw = n_band * nsl;
+  if (dbg & 8) return;  // (timing experiments: the bare launch)
+  if ((int32_t)blockIdx.x >= nbw) {  // carried prefix of the next band over the sources older than this band
+    const int32_t pw = __builtin_amdgcn_readfirstlane(((int32_t)blockIdx.x - nbw) * 4 + wave);
+    if (dbg & 4) return;
+    const double *pf_bin = (LOWER && fl.on()) ? fl.bin.get() : nullptr;
+    trsv_stream_r64<double, 0, LOWER, true>(ps0 + pw, ps1, ((int32_t)gridDim.x - nbw) * 4, ptr, split, col, val, nullptr,
+                                            rowid, d, LOWER ? w : v, w, lane, nullptr, 0, nullptr, true, nullptr, 0, 0, pf_bin, &fl);
+    HIFAMD_CSP(6)
+    HIFAMD_CSP_FLUSH(2 + (LOWER ? 0 : 4), n_band, nsl)
+    return;
+  }
+  const int32_t bw = (int32_t)blockIdx.x / nsl, slice = (int32_t)blockIdx.x - bw * nsl;
+  const int grp = lane >> 4, l16 = lane & 15, gq = wave * 4 + grp;  // lane group gq of 16 owns chunk gq
+  const int cc = slice * 16 + l16;                                   // this lane's column of the 64-column arena
+  double *x = LOWER ? w : v;
+  const bool div_u = !LOWER && first_u;
+  const bool first_l = LOWER && first_u && fl.on();
+  const double *rhs = div_u ? (const double *)w : (first_l ? fl.bin.get() : (const double *)x);
+  const int64_t rstride = first_l ? fl.ldb : 64;
+  const int rcol = first_l ? min(cc, fl.nrhs - 1) : cc;
+  int32_t c_first, c_last;
+  if (single_c0 >= 0) {
+    c_first = single_c0 + bw;
+    c_last = c_first + 1;
+  } else {
+    c_first = wg_grp_ptr[wg0 + bw];
+    c_last = wg_grp_ptr[wg0 + bw + 1];
+  }
+  // LDS: right-hand sides [lds_rows][16], then per row: pivot / scale, output scale, row id, input row, output row;
+  // sparse-own plans: the component's own nonzeros (value, local source), row offsets, depth levels
+  double *tb = cs_buf;
+  double *s_hd = tb + (size_t)lds_rows * 16;
+  double *s_ot = s_hd + lds_rows;
+  double *ow_val = s_ot + lds_rows;
+  int32_t *s_rowid = reinterpret_cast<int32_t *>(ow_val + (SPARSE ? 4096 : 0));
+  int32_t *s_hp = s_rowid + lds_rows;
+  int32_t *s_oi = s_hp + lds_rows;
+  uint16_t *ow_rptr = reinterpret_cast<uint16_t *>(s_oi + lds_rows);
+  uint8_t *ow_src = reinterpret_cast<uint8_t *>(ow_rptr + 260);
+  uint8_t *ow_lvl = ow_src + 4096;
+  const bool last_u = !LOWER && lu.on();
+  double *yout = last_u ? lu.out.get() : nullptr;
+  const int kq = grp;
+  for (int32_t c = c_first; c < c_last; ++c) {
+    const int32_t *dsc = cd_desc + (int64_t)c * 28;
+    const int32_t s0 = dsc[0], nb = dsc[1], mid0 = dsc[2];
+    const int64_t inv_off = ((int64_t)(uint32_t)dsc[5] << 32) | (uint32_t)dsc[4];
+    const uint8_t *wrow = reinterpret_cast<const uint8_t *>(dsc + 6);
+    const uint16_t *wmid = reinterpret_cast<const uint16_t *>(dsc + 11);
+    const int r0 = wrow[gq], nr = (int)wrow[gq + 1] - r0;
+    const int32_t e0 = mid0 + (int32_t)wmid[gq], ne = (int32_t)wmid[gq + 1] - (int32_t)wmid[gq];
+    const int lda = (nb + 31) & ~31;
+    const double *Ac = tinv + inv_off;
+    const int S = (nb + 15) >> 4;
+    constexpr int KU = 8;
+    double a0[KU], a1[KU];
+    // ---- phase 0: the component's row ids and per-row scalars (coalesced), sparse: its own nonzeros
+    for (int32_t t = (int32_t)threadIdx.x; t < nb; t += 256) {
+      const int32_t i = rowid[s0 + t];
+      s_rowid[t] = i;
+      if (div_u) s_hd[t] = d[i];
+      if (first_l) {
+        const int32_t pp = fl.p[i];
+        s_hp[t] = pp;
+        s_hd[t] = fl.s[pp];
+      }
+      if (last_u) {
+        const int32_t oi = lu.q[i];
+        s_oi[t] = oi;
+        s_ot[t] = lu.t[oi];
+      }
+    }
+    if (SPARSE) {
+      const int32_t own0 = dsc[20], nown = dsc[21], orp0 = dsc[22], lvl0 = dsc[23], nlvl = dsc[24];
+      for (int32_t t = (int32_t)threadIdx.x; t < nown; t += 256) {
+        ow_val[t] = own_val[own0 + t];
+        ow_src[t] = own_lsrc[own0 + t];
+      }
+      for (int32_t t = (int32_t)threadIdx.x; t <= nb; t += 256) ow_rptr[t] = own_rptr[orp0 + t];
+      for (int32_t t = (int32_t)threadIdx.x; t <= nlvl; t += 256) ow_lvl[t] = own_lvl[lvl0 + t];
+    }
+    // phase 2's first operand set and phase 1b's first item do not depend on anything computed here: requested now
+    if (!SPARSE && wave < S) {
+      const double *ap_ = Ac + ((int64_t)(S - 1 - wave) * lda) * 16 + l16 + (int64_t)kq * 16;
+#pragma unroll
+      for (int u = 0; u < KU; ++u) a0[u] = ap_[u * 64];
+    }
+    int32_t colv = 0, lrv = 0;
+    double valv = 0.0;
+    if (l16 < ne) {
+      colv = mid_col[e0 + l16];
+      valv = mid_val[e0 + l16];
+      lrv = mid_lrow[e0 + l16];
+    }
+    HIFAMD_CSP(1)
+    __syncthreads();
+    HIFAMD_CSP(2)
+    if (dbg & 16) return;  // (timing experiments: descriptor + row ids only)
+    // ---- phase 1a: right-hand sides of this lane group's rows into LDS, eight rows in flight
+    const int nrmax = wave_max4(nr);
+    for (int j = 0; j < nrmax; j += 8) {
+      double t_[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = r0 + min(j + q, max(nr - 1, 0));
+        const int32_t i = first_l ? s_hp[r] : s_rowid[r];
+        t_[q] = (j + q < nr) ? rhs[(int64_t)i * rstride + rcol] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (j + q < nr) {
+          const double hd = s_hd[r0 + j + q];
+          tb[((r0 + j + q) << 4) + l16] = div_u ? t_[q] / hd : (first_l ? (cc < fl.nrhs ? hd * t_[q] : 0.0) : t_[q]);
+        }
+    }
+    HIFAMD_CSP(3)
+    if (dbg & 32) return;  // (timing experiments: ... + right-hand sides)
+    // ---- phase 1b: this lane group's entries, items of 16, eight gathers per batch, the running row's value in a register
+    int cur = -1;
+    double acc = 0.0;
+    const int32_t nemax = (dbg & 1) ? 0 : wave_max4(ne);
+    for (int32_t base = 0; base < nemax; base += 16) {
+      int32_t colv2 = 0, lrv2 = 0;
+      double valv2 = 0.0;
+      if (base + 16 + l16 < ne) {
+        colv2 = mid_col[e0 + base + 16 + l16];
+        valv2 = mid_val[e0 + base + 16 + l16];
+        lrv2 = mid_lrow[e0 + base + 16 + l16];
+      }
+      const int32_t left = ne - base;  // entries of this lane group from `base` on (may be <= 0)
+      cs_batch<0>(colv, valv, lrv, left, x, cc, l16, tb, cur, acc);
+      if (base + 8 < nemax) cs_batch<8>(colv, valv, lrv, left, x, cc, l16, tb, cur, acc);
+      colv = colv2;
+      valv = valv2;
+      lrv = lrv2;
+    }
+    if (cur >= 0) tb[(cur << 4) + l16] = acc;
+    if (!SPARSE)  // (rows nb .. lda - 1 are zero for the inverse product; lds_rows is a multiple of 32)
+      for (int t = nb * 16 + (int)threadIdx.x; t < lda * 16; t += 256) tb[t] = 0.0;
+    HIFAMD_CSP(4)
+    __syncthreads();
+    HIFAMD_CSP(5)
+    if (SPARSE) {
+      // ---- phase 2, sparse: substitution inside LDS, depth level by depth level; a lane group takes a row at a time
+      const int nlvl = dsc[24];
+      for (int lv = 0; lv < nlvl; ++lv) {
+        const int r_lo = ow_lvl[lv], r_hi = ow_lvl[lv + 1];
+        for (int r = r_lo + gq; r < r_hi; r += 16) {
+          double a2 = tb[(r << 4) + l16];
+          const int eb = ow_rptr[r], ee = ow_rptr[r + 1];
+          for (int e = eb; e < ee; ++e) a2 = a2 - ow_val[e] * tb[((int)ow_src[e] << 4) + l16];
+          if (ee > eb) tb[(r << 4) + l16] = a2;
+          if (last_u) {
+            if (cc < lu.nrhs) yout[(int64_t)s_oi[r] * lu.ldy + cc] = s_ot[r] * a2;
+          } else {
+            x[((int64_t)s_rowid[r] << 6) + cc] = a2;
+          }
+        }
+        __syncthreads();
+      }
+      continue;
+    }
+    // ---- phase 2: x = Tinv * t on the matrix cores, one 16-row strip x this slice's 16 columns per step; strips are
+    // dealt heaviest first in snake order over the four waves
+    for (int rnd = 0;; ++rnd) {
+      const int q = 4 * rnd + ((rnd & 1) ? 3 - wave : wave);
+      if (q >= ((dbg & 2) ? 0 : S)) {
+        if (4 * rnd >= S) break;
+        continue;
+      }
+      const int strip = S - 1 - q;
+      const int kend = min(nb, 16 * (strip + 1));
+      const int nsets = (kend + 31) >> 5;
+      const double *Ap = Ac + ((int64_t)strip * lda) * 16 + l16;
+      const double *Bp = tb + l16;
+      v4f64 acc0 = v4f64{0.0, 0.0, 0.0, 0.0};
+#define HIFAMD_CS_LOAD(aa, t_)                                          \
+  {                                                                     \
+    const double *ap_ = Ap + (int64_t)(32 * (t_) + kq) * 16;            \
+    _Pragma("unroll") for (int u = 0; u < KU; ++u) aa[u] = ap_[u * 64]; \
+  }
+#define HIFAMD_CS_MFMA(aa, t_)                                                \
+  {                                                                           \
+    const int kb_ = 32 * (t_) + kq;                                           \
+    _Pragma("unroll") for (int u = 0; u < KU; ++u) {                          \
+      const double b0_ = Bp[(kb_ + 4 * u) << 4];                              \
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], b0_, acc0, 0, 0, 0); \
+    }                                                                         \
+  }
+      int t = 0;
+      if (rnd != 0) HIFAMD_CS_LOAD(a0, 0)  // (the first strip's first set was requested before phase 1)
+      while (t < nsets) {
+        if (t + 1 < nsets) HIFAMD_CS_LOAD(a1, t + 1)
+        HIFAMD_CS_MFMA(a0, t)
+        if (t + 1 >= nsets) break;
+        if (t + 2 < nsets) HIFAMD_CS_LOAD(a0, t + 2)
+        HIFAMD_CS_MFMA(a1, t + 1)
+        t += 2;
+      }
+#undef HIFAMD_CS_LOAD
+#undef HIFAMD_CS_MFMA
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * strip + kq + 4 * r;
+        if (row < nb) {
+          if (last_u) {
+            if (cc < lu.nrhs) yout[(int64_t)s_oi[row] * lu.ldy + cc] = s_ot[row] * acc0[r];
+          } else {
+            x[((int64_t)s_rowid[row] << 6) + cc] = acc0[r];
+          }
+        }
+      }
+    }
+    __syncthreads();  // (the next component overwrites the LDS block)
+  }
+  HIFAMD_CSP(6)
+  HIFAMD_CSP_FLUSH(1 + (LOWER ? 0 : 4) + (SPARSE ? 8 : 0), n_band, nsl)
 }
 
 // ---------------------------------------------------------------------------------------------
