@@ -374,7 +374,9 @@ class Engine : public EngineBase {
   bool spmm_split = true;  // tiled Schur products: one 16-row block per workgroup (k_spmm_tile4); HIFIR_AMD_SPMM_SPLIT=0: per wave
   int carry_wgs = 256;   // workgroups a band's launch may add for the carried prefix of the next band (HIFIR_AMD_CARRY_WGS)
   bool fuse_f = true;    // S5 fused into the second L solve where the plan allows (HIFIR_AMD_FUSE_F=0: separate k_spmm_epi launch)
-  int top_gemm = 2;      // top operator product: 1 k_strip_gemm_d<4>, 2 k_strip_gemm4_d<2>, 3 k_strip_gemm4_d<4> (HIFIR_AMD_TOP_GEMM)
+  int top_gemm = 4;      // top / tail operator product: 4 k_top_gemm (64-row tiles, panel through LDS, K splits); 1 k_strip_gemm_d<4>,
+                         // 2 k_strip_gemm4_d<2>, 3 k_strip_gemm4_d<4> (HIFIR_AMD_TOP_GEMM)
+  DevBuf gemm_part;      // partial tiles of the K splits of k_top_gemm
   int cd_dbg = 0;        // development aid (HIFIR_AMD_CD_DBG): phases of k_band_cd switched off for timing experiments
   // Column-sliced component bands (kernels.hip.hpp k_band_cs): a component band of at most cs_max_wgs workgroups is cut
   // into 16-column slices (the heaviest component of a narrow band then runs on four compute units); a batch of fewer
@@ -433,7 +435,7 @@ class Engine : public EngineBase {
     cd_dbg = env_int("HIFIR_AMD_CD_DBG", 0);
     cs_mode = env_int("HIFIR_AMD_CS", 1);
     cs_max_wgs = env_int("HIFIR_AMD_CS_MAX_WGS", 0);
-    top_gemm = env_int("HIFIR_AMD_TOP_GEMM", 2);
+    top_gemm = env_int("HIFIR_AMD_TOP_GEMM", 4);
     fuse_f = env_int("HIFIR_AMD_FUSE_F", 1) != 0;
     carry_wgs = std::max(1, env_int("HIFIR_AMD_CARRY_WGS", 256));
     spmm_split = env_int("HIFIR_AMD_SPMM_SPLIT", 1) != 0;
@@ -483,6 +485,10 @@ class Engine : public EngineBase {
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cs<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_lds_bytes(true)));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cs<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_lds_bytes(true)));
     }
+    HIP_OK(hipFuncSetAttribute((const void *)k_top_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTopGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void *)k_top_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTopGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void *)k_top_gemm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTopGemmLds));
+    HIP_OK(hipFuncSetAttribute((const void *)k_top_gemm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTopGemmLds));
     if (sizeof(T) != sizeof(double) && band_opt.cd_rows > 0) {
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd_z<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes_z()));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd_z<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes_z()));
@@ -679,6 +685,7 @@ class Engine : public EngineBase {
         E->blk_tmp.alloc(blk_tmp.bytes);
         zero_dev(E->blk_tmp.p, E->blk_tmp.bytes);
       }
+      if (gemm_part.bytes) E->gemm_part.alloc(gemm_part.bytes);
       if (zt1.bytes) {
         E->zt1.alloc(zt1.bytes);
         E->zt2.alloc(zt2.bytes);
@@ -837,7 +844,7 @@ class Engine : public EngineBase {
         std::vector<T> G;
         const double growth = build_top_operator(H.Lr, H.Lp, r0L, H.Ur, H.Up, r0U, H.top_n, H.d, G);
         if (growth <= band_opt.dense_max_growth) {
-          L.topG.upload(mfma_operand(G.data(), H.top_n, H.top_n, round_up32(H.top_n)));  // (k zero-padded to 32)
+          L.topG.upload(mfma_operand(G.data(), H.top_n, H.top_n, round_up32(H.top_n)), 4096);  // (k zero-padded to 32; k_top_gemm reads past the end)
           L.top_n = H.top_n;
           L.top_bandL = H.top_bandL;
           L.top_bandU = H.top_bandU;
@@ -969,6 +976,7 @@ class Engine : public EngineBase {
       HIP_OK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_xcd_remap), &remap, sizeof(int), 0, hipMemcpyHostToDevice, xfer_stream()));
       HIP_OK(hipStreamSynchronize(xfer_stream()));
     }
+    if (top_rows_max > 0) gemm_part.alloc((size_t)kTopGemmSplits * (size_t)((top_rows_max + 63) / 64 * 64) * 64 * sizeof(double));
     if (band_opt.dense_block > 0) {  // +32 rows: the MFMA kernel reads whole 32-k operand sets (masked)
       blk_tmp.alloc((size_t)(std::max<int64_t>(band_opt.dense_block, top_rows_max) + 32) * Rmax * sizeof(T));
       zero_dev(blk_tmp.p, blk_tmp.bytes);
@@ -1015,7 +1023,11 @@ class Engine : public EngineBase {
       check_device_error();
       for (double g : G)
         if (!std::isfinite(g)) return;  // (a singular tail: keep the recursion, which reports what it finds)
-      tailG.upload(mfma_operand(G.data(), n, n, ld));
+      tailG.upload(mfma_operand(G.data(), n, n, ld), 4096);
+      if (gemm_part.bytes < (size_t)kTopGemmSplits * (size_t)((n + 63) / 64 * 64) * 64 * sizeof(double)) {
+        HIP_OK(hipStreamSynchronize(stream));
+        gemm_part.alloc((size_t)kTopGemmSplits * (size_t)((n + 63) / 64 * 64) * 64 * sizeof(double));
+      }
       tail_level = (int64_t)l0;
       tail_n = n;
     }
@@ -1184,6 +1196,33 @@ class Engine : public EngineBase {
   template <bool LOWER>
   void launch_dense_block(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t q, int logR, int64_t &count,
                           bool rhs_ready = false);
+  // Out[rowmap] = G X on the matrix cores (kernels.hip.hpp k_top_gemm): 64-row tiles x K splits chosen so that one wave
+  // of workgroups fills the chip; the splits' partial tiles are added in order by k_top_reduce
+  static constexpr size_t kTopGemmLds = 2 * 64 * 80 * sizeof(double);
+  static constexpr int kTopGemmSplits = 8;
+  void launch_top_gemm(hipStream_t st, int nt, const double *G, const double *X, const int32_t *rowmap, double *Out,
+                       int64_t &count) {
+    const int lda = (int)round_up32(nt);
+    const int tiles = (nt + 63) / 64;
+    int nks = std::max(1, std::min(kTopGemmSplits, 256 / std::max(1, tiles)));
+    int kper = (int)(((int64_t)(lda + nks - 1) / nks + 63) / 64 * 64);
+    nks = (lda + kper - 1) / kper;
+    const int nct = std::min(4, (act_cols + 15) / 16);
+    const int pad = (nt + 63) / 64 * 64;
+    if (nks > 1 && gemm_part.bytes < (size_t)nks * pad * 64 * sizeof(double)) {  // (sized at finalize; cannot happen)
+      nks = 1;
+      kper = (int)((lda + 63) / 64 * 64);
+    }
+    auto kern = nct == 1 ? k_top_gemm<1> : (nct == 2 ? k_top_gemm<2> : (nct == 3 ? k_top_gemm<3> : k_top_gemm<4>));
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)nks), dim3(1024), kTopGemmLds, st, nt, nt, kper, G, lda, X, rowmap,
+                       Out, gemm_part.as<double>(), pad);
+    ++count;
+    if (nks > 1) {
+      hipLaunchKernelGGL(k_top_reduce, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, st, nt, nks,
+                         (const double *)gemm_part.as<double>(), pad, rowmap, Out, nct);
+      ++count;
+    }
+  }
   // the level's top rows: t_T = w_T - (sources outside T) by the chip-wide prefix pass, straight into the product's
   // right-hand side; then v_T = G t_T on the matrix cores (G = U_TT^{-1} D_T^{-1} L_TT^{-1}, rows scattered by L's row ids)
   void launch_top(hipStream_t st, const DevLevel &L, int logR, int64_t &count, const FL &fl) {
@@ -1197,6 +1236,13 @@ class Engine : public EngineBase {
                          M.rowid.as<int32_t>(), L.d.as<double>(), L.w.as<double>(), L.v.as<double>(), logR, 1,
                          blk_tmp.as<double>(), (int32_t)s1, fl);
       const int ktop = (int)round_up32(nt);
+      ++count;  // (the prefix pass)
+      if (top_gemm >= 4) {
+        launch_top_gemm(st, nt, L.topG.as<double>(), (const double *)blk_tmp.as<double>(), M.rowid.as<int32_t>() + s0,
+                        L.v.as<double>(), count);
+        return;
+      }
+      ++count;
       if (top_gemm == 1)
         hipLaunchKernelGGL(k_strip_gemm_d<4>, dim3((unsigned)((nt + 15) / 16)), dim3(1024), 0, st, nt, ktop, L.topG.as<double>(), ktop,
                            (const double *)blk_tmp.as<double>(), M.rowid.as<int32_t>() + s0, L.v.as<double>());
@@ -1206,7 +1252,6 @@ class Engine : public EngineBase {
       else
         hipLaunchKernelGGL(k_strip_gemm4_d<4>, dim3((unsigned)((nt + 15) / 16)), dim3(1024), 0, st, nt, ktop, L.topG.as<double>(), ktop,
                            (const double *)blk_tmp.as<double>(), M.rowid.as<int32_t>() + s0, L.v.as<double>());
-      count += 2;
     } else {
       (void)st, (void)L, (void)logR, (void)count, (void)fl;
       throw Error(HIFAMD_HIFIR_ERROR, "internal error: combined top operator on a complex handle");
@@ -1236,14 +1281,19 @@ class Engine : public EngineBase {
   }
   // v_tail = G c_tail (build_tail_operator); the product reads up to 31 rows behind c_tail: they lie inside the level's
   // arena (v follows w) and meet zero columns of the operand
-  bool launch_tail(hipStream_t st, const D *cin, D *zout) {
+  bool launch_tail(hipStream_t st, const D *cin, D *zout, int64_t &count) {
     if constexpr (std::is_same<T, double>::value) {
       const int nt = (int)tail_n, kt = (int)round_up32(tail_n);
+      if (top_gemm >= 4) {  // (reads exactly the tail_n rows of c_tail: nothing behind them)
+        launch_top_gemm(st, nt, tailG.as<double>(), (const double *)cin, nullptr, (double *)zout, count);
+        return true;
+      }
+      ++count;
       hipLaunchKernelGGL(k_strip_gemm4_d<2>, dim3((unsigned)((nt + 15) / 16)), dim3(1024), 0, st, nt, kt, tailG.as<double>(), kt,
                          (const double *)cin, (const int32_t *)nullptr, (double *)zout);
       return true;
     } else {
-      (void)st, (void)cin, (void)zout;
+      (void)st, (void)cin, (void)zout, (void)count;
       return false;
     }
   }
@@ -1397,8 +1447,9 @@ class Engine : public EngineBase {
       if (last)
         launch_dense(st, w + m * R, v + m * R, logR, rank, count);  // :371-381
       else if ((int64_t)l + 1 == tail_level && logR == 6 && (!host.has_dense || eff_rank(rank) == dn.rank) &&  // (the rank it was built with)
-               launch_tail(st, w + m * R, v + m * R))
-        ++count;  // (levels l+1 ... and the dense block as one product)
+               launch_tail(st, w + m * R, v + m * R, count)) {
+        // (levels l+1 ... and the dense block as one product)
+      }
       else
         enqueue_level(st, l + 1, in_direct(w + m * R), R, out_direct(v + m * R), R, (int)R, logR, rank, count);  // :383-388
       // S5  :392-403   (v[m:n] already is "work[m:n] = y[m:n]")

@@ -1999,6 +1999,135 @@ __global__ void __launch_bounds__(1024) k_strip_gemm4_d(int nrows, int kend, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// Out[rowmap[r]] = sum_k G(r, k) X[k]: the combined top operator of a level and the tail operator of the hierarchy
+// (round 3).  k_strip_gemm4_d gives a 16-row strip to a workgroup whose sixteen waves split K: every workgroup then pulls
+// the WHOLE right-hand-side panel (nt x 512 B) through its compute unit's L1 beside its 16 x nt strip of G -- four times
+// the bytes of the operator itself, served by the L2s: 48 us for 3,351 rows, 30 TFLOP/s (profiles/r02).  Here a
+// workgroup owns 64 rows (four strips) x ONE K range of the grid's nks: its waves are (strip s, K quarter j); the
+// panel's rows of the K range stream through LDS in chunks of 64 (double buffered, rows padded to 80 doubles: the two
+// 16-lane halves of a ds_read_b64 then hit disjoint banks), so a panel row is fetched once per 64 output rows, and G
+// streams from HBM once, each wave's fragments two chunks ahead in registers.  Partial tiles of the four K quarters are
+// summed through LDS in a fixed order; nks > 1: the workgroup's 64 x 64 partial goes to part[ksplit][row][64] and
+// k_top_reduce adds the splits in order (deterministic).  nct = 16-column tiles in use (a batch of <= 16 columns: one).
+// Panel rows >= kvalid are read as zeros (the buffer behind them may hold anything, also non-finite values).
+// G: strip-major MFMA operand (host.hpp mfma_operand), lda = K rounded up to 32.
+// ---------------------------------------------------------------------------------------------
+template <int NCT>
+__global__ void __launch_bounds__(1024) k_top_gemm(int nrows, int kvalid, int kper /* K range per split, multiple of 64 */,
+                                                   const double *__restrict__ A, int lda, const double *__restrict__ X,
+                                                   const int32_t *__restrict__ rowmap, double *__restrict__ Out,
+                                                   double *__restrict__ part, int nrows_pad) {
+  constexpr int nct = NCT;
+  constexpr int XS = 80;               // LDS row stride of the panel (doubles)
+  extern __shared__ double tg_lds[];   // two chunks of 64 panel rows: 2 x 64 x 80 doubles = 80 KB; reused for the reduction
+  double (*xb)[64 * XS] = reinterpret_cast<double (*)[64 * XS]>(tg_lds);
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;     // 0..15
+  const int sw = wv & 3, jq = wv >> 2; // strip within the tile, K quarter within a chunk
+  const int cl = lane & 15, kq = lane >> 4;
+  const int tile = blockIdx.x, ksp = blockIdx.y;
+  const int strip = tile * 4 + sw;
+  const int nstrips = (nrows + 15) >> 4;
+  const int k0 = ksp * kper, k1 = min(k0 + kper, lda);
+  const int nchunks = (k1 - k0 + 63) >> 6;
+  v4f64 acc[NCT];
+#pragma unroll
+  for (int t = 0; t < NCT; ++t) acc[t] = v4f64{0.0, 0.0, 0.0, 0.0};
+  const bool live = strip < nstrips;
+  // this wave's A fragments of chunk c: k = k0 + 64 c + 16 jq + 4 u + kq, u = 0..3 (512 contiguous bytes each).  Loads
+  // are unconditional: a chunk index past the end re-reads the last chunk (never multiplied), a dead wave reads the
+  // last strip, and k >= lda (the last chunk of the last split, at most 32 columns: the next strip's first ones, or the
+  // padding behind the operand) meets panel rows >= kvalid, which are zero in LDS
+  const double *Ap = A + ((int64_t)min(strip, nstrips - 1) * lda) * 16 + cl + (int64_t)(k0 + 16 * jq + kq) * 16;
+  double a0[4], a1[4], a2[4];
+#define HIFAMD_TG_A(aa, c_)                                                                   \
+  {                                                                                           \
+    const double *ap_ = Ap + (int64_t)min((c_), nchunks - 1) * (64 * 16);                     \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) aa[u] = ap_[u * 64];                        \
+  }
+  // panel chunk c into buffer b: 64 rows x 64 columns, 16 bytes per thread and pass (rows >= kvalid: zeros)
+  typedef double v2f64 __attribute__((ext_vector_type(2)));
+  const int xr = threadIdx.x >> 5, xc = (threadIdx.x & 31) * 2;  // row 0..31 (+32), columns xc, xc+1
+  v2f64 xs0, xs1;
+#define HIFAMD_TG_XLOAD(c_)                                                                   \
+  {                                                                                           \
+    const int r0_ = k0 + 64 * (c_) + xr, r1_ = r0_ + 32;                                      \
+    xs0 = (r0_ < kvalid && xc < 16 * nct) ? *reinterpret_cast<const v2f64 *>(X + ((int64_t)r0_ << 6) + xc) : v2f64{0.0, 0.0}; \
+    xs1 = (r1_ < kvalid && xc < 16 * nct) ? *reinterpret_cast<const v2f64 *>(X + ((int64_t)r1_ << 6) + xc) : v2f64{0.0, 0.0}; \
+  }
+#define HIFAMD_TG_XSTORE(b_)                                                   \
+  {                                                                            \
+    *reinterpret_cast<v2f64 *>(&xb[b_][xr * XS + xc]) = xs0;                   \
+    *reinterpret_cast<v2f64 *>(&xb[b_][(xr + 32) * XS + xc]) = xs1;            \
+  }
+#define HIFAMD_TG_MFMA(aa, b_)                                                                     \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                  \
+    const double *bp_ = &xb[b_][(16 * jq + 4 * u + kq) * XS + cl];                                 \
+    _Pragma("unroll") for (int t = 0; t < NCT; ++t)                                                \
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], bp_[16 * t], acc[t], 0, 0, 0);        \
+  }
+  HIFAMD_TG_A(a0, 0)
+  HIFAMD_TG_A(a1, 1)
+  HIFAMD_TG_XLOAD(0)
+  HIFAMD_TG_XSTORE(0)
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {  // (A fragments two chunks ahead in registers, the panel one chunk ahead in LDS)
+    HIFAMD_TG_A(a2, c + 2)
+    if (c + 1 < nchunks) HIFAMD_TG_XLOAD(c + 1)
+    HIFAMD_TG_MFMA(a0, (c & 1))
+    if (c + 1 < nchunks) HIFAMD_TG_XSTORE(((c + 1) & 1))
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a0[u] = a1[u], a1[u] = a2[u];
+  }
+#undef HIFAMD_TG_A
+#undef HIFAMD_TG_XLOAD
+#undef HIFAMD_TG_XSTORE
+#undef HIFAMD_TG_MFMA
+  // (the panel buffers become the reduction scratch: every wave is past the loop's last barrier)
+  // K quarters 1..3 hand their tiles to quarter 0 of the same strip, summed in the order 0, 1, 2, 3
+  double *red = &xb[0][0];  // [jq - 1][sw][t][r][lane]: 3 x 4 x 4 x 4 x 64 doubles = 96 KB > 80 KB: two rounds
+  // round 1: quarters 2, 3 -> scratch; quarters 0, 1 add (0 += 2 is NOT the order wanted) -- keep it simple and exact:
+  // quarter 1 first, then 2, then 3, one quarter per round (3 rounds x 32 KB)
+  for (int q = 1; q < 4; ++q) {
+    if (jq == q) {
+#pragma unroll
+      for (int t = 0; t < NCT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(((sw * 4 + t) * 4 + r) << 6) + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (jq == 0) {
+#pragma unroll
+      for (int t = 0; t < NCT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += red[(((sw * 4 + t) * 4 + r) << 6) + lane];
+    }
+    __syncthreads();
+  }
+  if (jq != 0 || !live) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * strip + kq + 4 * r;
+    if (row >= nrows) continue;
+    double *dst = (gridDim.y > 1) ? part + (((int64_t)ksp * nrows_pad + row) << 6) : Out + ((int64_t)(rowmap ? rowmap[row] : row) << 6);
+#pragma unroll
+    for (int t = 0; t < NCT; ++t) dst[16 * t + cl] = acc[t][r];
+  }
+}
+
+// the K splits of k_top_gemm, added in order
+__global__ void __launch_bounds__(256) k_top_reduce(int nrows, int nks, const double *__restrict__ part, int nrows_pad,
+                                                    const int32_t *__restrict__ rowmap, double *__restrict__ Out, int nct) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows || lane >= 16 * nct) return;
+  double sacc = part[((int64_t)row << 6) + lane];
+  for (int q = 1; q < nks; ++q) sacc += part[(((int64_t)q * nrows_pad + row) << 6) + lane];
+  Out[((int64_t)(rowmap ? rowmap[row] : row) << 6) + lane] = sacc;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Block-dense thin bands, step (2): Out[rowmap[r]] = sum_{k<=r} Tinv(r,k) X[k] for one diagonal block
 // (nb rows), Tinv = explicit inverse of the block's unit lower triangle, strip-major with
 // lda = nb rounded up to 32 (zero padded; everything right of the diagonal is zero too).
