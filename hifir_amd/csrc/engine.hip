@@ -153,6 +153,7 @@ struct DevCsr {
   DevBuf f_desc, f_col, f_val, f_lrow;  // L only: the streams with the level's F entries appended (host.hpp build_cd_streams_fused)
   bool f_fused = false;
   bool cd_sparse = false;
+  int32_t own_cap = kCdOwnCap;  // sparse-own plans: most own nonzeros of one component, rounded up to 64 (sizes the kernels' LDS)
   std::vector<int32_t> band_wg_ptr, band_slot_ptr, host_wg_grp_ptr;
   std::vector<uint8_t> band_prefix, band_dense, band_fused, band_cd, band_old;
   std::vector<int32_t> band_blk_ptr, blk_slot0, blk_slot1;
@@ -176,6 +177,7 @@ struct DevCsr {
     grp_slot_ptr.alias(o.grp_slot_ptr);
     wg_slot.alias(o.wg_slot);
     csplit.alias(o.csplit);
+    own_cap = o.own_cap;
     grp_inv_off.alias(o.grp_inv_off);
     cd_desc.alias(o.cd_desc);
     mid_col.alias(o.mid_col);
@@ -239,6 +241,11 @@ struct DevCsr {
         mid_val.upload(mv, 80);
         mid_lrow.upload(P->mid_lrow, 80);
         cd_sparse = P->cd_sparse;
+        if (cd_sparse) {
+          int32_t mx = 0;
+          for (size_t c = 0; c * kCdDescWords < P->cd_desc.size(); ++c) mx = std::max(mx, P->cd_desc[c * kCdDescWords + 21]);
+          own_cap = std::min<int32_t>(kCdOwnCap, std::max<int32_t>(64, (mx + 63) & ~63));
+        }
         std::vector<T> ov(P->own_k.size());
         for (size_t e = 0; e < ov.size(); ++e) ov[e] = A.val[(size_t)P->own_k[e]];
         own_val.upload(ov, 8);
@@ -382,6 +389,7 @@ class Engine : public EngineBase {
   // into 16-column slices (the heaviest component of a narrow band then runs on four compute units); a batch of fewer
   // than 49 columns runs EVERY component band sliced and launches only the slices it has.  HIFIR_AMD_CS=0: off.
   int cs_mode = 1;
+  int cs_sparse = 0;     // HIFIR_AMD_CS_SPARSE=1: sparse-own bands (level 0) in column slices at full width too
   int cs_max_wgs = 0;    // HIFIR_AMD_CS_MAX_WGS (full batches: measured equal to k_band_cd at every band width)
   int act_cols = 64;     // columns of the 64-column arena that the tile being enqueued actually uses (enqueue_apply)
   int band_pipe = 1;     // 1: k_trsv_band_p (next row's head behind the last gathers), 0: k_trsv_band at R = 64 too
@@ -435,6 +443,7 @@ class Engine : public EngineBase {
     cd_dbg = env_int("HIFIR_AMD_CD_DBG", 0);
     cs_mode = env_int("HIFIR_AMD_CS", 1);
     cs_max_wgs = env_int("HIFIR_AMD_CS_MAX_WGS", 0);
+    cs_sparse = env_int("HIFIR_AMD_CS_SPARSE", 0);
     top_gemm = env_int("HIFIR_AMD_TOP_GEMM", 4);
     fuse_f = env_int("HIFIR_AMD_FUSE_F", 1) != 0;
     carry_wgs = std::max(1, env_int("HIFIR_AMD_CARRY_WGS", 256));
@@ -576,6 +585,7 @@ class Engine : public EngineBase {
       E->cd_dbg = cd_dbg;
       E->cs_mode = cs_mode;
       E->cs_max_wgs = cs_max_wgs;
+      E->cs_sparse = cs_sparse;
       for (const auto &P : host.levels) E->add_level_adjoint(P);
       if (host.has_dense && host.dense.kind == 2) {  // LUP: ?getrs 'T' / ?gemv 'C' (LUP.hpp:150,187)
         E->host.dense.kind = 2;
@@ -633,6 +643,7 @@ class Engine : public EngineBase {
       E->cd_dbg = cd_dbg;
       E->cs_mode = cs_mode;
       E->cs_max_wgs = cs_max_wgs;
+      E->cs_sparse = cs_sparse;
       E->max_nrhs = max_nrhs;
       E->Rmax = Rmax;
       E->host.has_dense = host.has_dense;
@@ -1264,19 +1275,19 @@ class Engine : public EngineBase {
   int32_t cd_lds_rows(bool sparse) const {
     return (int32_t)(sparse ? band_opt.cd_sparse_rows : ((band_opt.cd_rows + 31) & ~(int64_t)31));
   }
-  size_t cd_lds_bytes(bool sparse) const {
+  size_t cd_lds_bytes(bool sparse, int32_t own_cap = kCdOwnCap) const {
     const size_t rows = (size_t)cd_lds_rows(sparse);
     size_t b = rows * 64 * sizeof(double) + ((rows + 1) & ~(size_t)1) * sizeof(int32_t);
-    if (sparse) b += (size_t)kCdOwnCap * (sizeof(double) + 1) + 260 * sizeof(uint16_t) + 264;
+    if (sparse) b += (size_t)own_cap * (sizeof(double) + 1) + 260 * sizeof(uint16_t) + 264;
     b += rows * (sizeof(double) + sizeof(int32_t)) + 8;  // fused S7 (LastU): output row and scale of every row
     return b;
   }
   // LDS of k_band_cs (one 16-column slice of a component): right-hand sides [rows][16], per row two doubles and three
   // int32 (pivot / scale, output scale, row id, input row, output row); sparse-own plans add the own nonzeros
-  size_t cs_lds_bytes(bool sparse) const {
+  size_t cs_lds_bytes(bool sparse, int32_t own_cap = kCdOwnCap) const {
     const size_t rows = (size_t)cd_lds_rows(sparse);
     size_t b = rows * 18 * sizeof(double) + rows * 3 * sizeof(int32_t);
-    if (sparse) b += (size_t)kCdOwnCap * (sizeof(double) + 1) + 260 * sizeof(uint16_t) + 264;
+    if (sparse) b += (size_t)own_cap * (sizeof(double) + 1) + 260 * sizeof(uint16_t) + 264;
     return b + 16;
   }
   // v_tail = G c_tail (build_tail_operator); the product reads up to 31 rows behind c_tail: they lie inside the level's
@@ -1306,7 +1317,7 @@ class Engine : public EngineBase {
                       int32_t ps1, unsigned extra, const FL &fl, bool with_f = false, const LU &lu = no_lu(), size_t band = 0) {
     if constexpr (std::is_same<T, double>::value) {
       // LDS: the component's right-hand sides + its row ids (the attribute for > 64 KB is set in bind_device)
-      const size_t lds = cd_lds_bytes(M.cd_sparse);
+      const size_t lds = cd_lds_bytes(M.cd_sparse, M.own_cap);
       const int32_t lds_rows = cd_lds_rows(M.cd_sparse);
       // one component per workgroup (the usual case): the kernel derives the component from blockIdx
       const int32_t c0 = M.host_wg_grp_ptr[(size_t)g0], c1 = M.host_wg_grp_ptr[(size_t)g1];
@@ -1315,15 +1326,15 @@ class Engine : public EngineBase {
       // column slices (k_band_cs): narrow batches always, full batches where the band is narrow
       const int nsl = std::min(4, (act_cols + 15) / 16);
       const bool fits = (int64_t)(g1 - g0) * nsl + 4 * (int64_t)extra < (1LL << 30);
-      if (cs_mode && (nsl < 4 || g1 - g0 <= cs_max_wgs) && fits) {
+      if (cs_mode && (nsl < 4 || g1 - g0 <= cs_max_wgs || (cs_sparse && M.cd_sparse)) && fits) {
         auto kcs = M.cd_sparse ? k_band_cs<LOWER, true> : k_band_cs<LOWER, false>;
-        hipLaunchKernelGGL(kcs, dim3((unsigned)((g1 - g0) * nsl) + 4 * extra), dim3(256), cs_lds_bytes(M.cd_sparse), st, g0,
+        hipLaunchKernelGGL(kcs, dim3((unsigned)((g1 - g0) * nsl) + 4 * extra), dim3(256), cs_lds_bytes(M.cd_sparse, M.own_cap), st, g0,
                            M.wg_grp_ptr.as<int32_t>(), (with_f ? M.f_desc : M.cd_desc).template as<int32_t>(), M.ptr.as<int32_t>(),
                            M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<double>(), M.rowid.as<int32_t>(), L.d.as<double>(),
                            L.w.as<double>(), L.v.as<double>(), M.tinv.as<double>(), (with_f ? M.f_col : M.mid_col).template as<int32_t>(),
                            (with_f ? M.f_val : M.mid_val).template as<double>(), (with_f ? M.f_lrow : M.mid_lrow).template as<uint8_t>(),
                            pre ? 0 : 1, (int32_t)(g1 - g0), (int32_t)nsl, ps0, ps1, single_c0,
-                           lds_rows, cd_dbg, fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
+                           lds_rows, M.own_cap, cd_dbg, fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
                            M.own_lvl.as<uint8_t>(), lu);
         return;
       }
@@ -1334,7 +1345,7 @@ class Engine : public EngineBase {
                          L.w.as<double>(), L.v.as<double>(), M.tinv.as<double>(), (with_f ? M.f_col : M.mid_col).template as<int32_t>(),
                          (with_f ? M.f_val : M.mid_val).template as<double>(), (with_f ? M.f_lrow : M.mid_lrow).template as<uint8_t>(),
                          pre ? 0 : 1, (int32_t)(g1 - g0), ps0, ps1, single_c0,
-                         lds_rows, cd_dbg, fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
+                         lds_rows, M.own_cap, cd_dbg, fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
                          M.own_lvl.as<uint8_t>(), lu);
     } else {
       (void)ps0, (void)ps1, (void)with_f, (void)lu;

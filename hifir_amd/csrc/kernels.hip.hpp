@@ -2285,7 +2285,7 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
                                                   const double *__restrict__ tinv, const int32_t *__restrict__ mid_col,
                                                   const double *__restrict__ mid_val, const uint8_t *__restrict__ mid_lrow,
                                                   int first_u, int32_t n_band, int32_t ps0, int32_t ps1, int32_t single_c0,
-                                                  int32_t lds_rows, int dbg, FirstL<double> fl,
+                                                  int32_t lds_rows, int32_t own_cap, int dbg, FirstL<double> fl,
                                                   const double *__restrict__ own_val, const uint8_t *__restrict__ own_lsrc,
                                                   const uint16_t *__restrict__ own_rptr, const uint8_t *__restrict__ own_lvl,
                                                   LastU<double> lu) {
@@ -2326,8 +2326,8 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
   int32_t *cd_rowid = reinterpret_cast<int32_t *>(cd_tbuf + (size_t)lds_rows * 64);  // the component's row ids, for phase 2
   // SPARSE: the component's own nonzeros (value, local source row), their row offsets and the depth levels
   double *ow_val = reinterpret_cast<double *>(cd_rowid + ((lds_rows + 1) & ~1));
-  uint8_t *ow_src = reinterpret_cast<uint8_t *>(ow_val + 4096);
-  uint16_t *ow_rptr = reinterpret_cast<uint16_t *>(ow_src + 4096);
+  uint8_t *ow_src = reinterpret_cast<uint8_t *>(ow_val + own_cap);  // (own_cap: multiple of 64, host: the plan's maximum)
+  uint16_t *ow_rptr = reinterpret_cast<uint16_t *>(ow_src + own_cap);
   uint8_t *ow_lvl = reinterpret_cast<uint8_t *>(ow_rptr + 260);
   // fused S7 (LastU): output row and scale of every row of the component, behind everything else
   const bool last_u = !LOWER && lu.on();
@@ -2619,7 +2619,7 @@ __global__ void __launch_bounds__(256) k_band_cs(int32_t wg0, const int32_t *__r
                                                  const double *__restrict__ tinv, const int32_t *__restrict__ mid_col,
                                                  const double *__restrict__ mid_val, const uint8_t *__restrict__ mid_lrow,
                                                  int first_u, int32_t n_band, int32_t nsl, int32_t ps0, int32_t ps1,
-                                                 int32_t single_c0, int32_t lds_rows, int dbg, FirstL<double> fl,
+                                                 int32_t single_c0, int32_t lds_rows, int32_t own_cap, int dbg, FirstL<double> fl,
                                                  const double *__restrict__ own_val, const uint8_t *__restrict__ own_lsrc,
                                                  const uint16_t *__restrict__ own_rptr, const uint8_t *__restrict__ own_lvl,
                                                  LastU<double> lu) {
@@ -2663,12 +2663,12 @@ __global__ void __launch_bounds__(256) k_band_cs(int32_t wg0, const int32_t *__r
   double *s_hd = tb + (size_t)lds_rows * 16;
   double *s_ot = s_hd + lds_rows;
   double *ow_val = s_ot + lds_rows;
-  int32_t *s_rowid = reinterpret_cast<int32_t *>(ow_val + (SPARSE ? 4096 : 0));
+  int32_t *s_rowid = reinterpret_cast<int32_t *>(ow_val + (SPARSE ? own_cap : 0));
   int32_t *s_hp = s_rowid + lds_rows;
   int32_t *s_oi = s_hp + lds_rows;
   uint16_t *ow_rptr = reinterpret_cast<uint16_t *>(s_oi + lds_rows);
   uint8_t *ow_src = reinterpret_cast<uint8_t *>(ow_rptr + 260);
-  uint8_t *ow_lvl = ow_src + 4096;
+  uint8_t *ow_lvl = ow_src + own_cap;
   const bool last_u = !LOWER && lu.on();
   double *yout = last_u ? lu.out.get() : nullptr;
   const int kq = grp;
