@@ -377,6 +377,11 @@ class Engine : public EngineBase {
   int64_t tail_rows = 4096;
   int64_t tail_level = -1, tail_n = 0;
   DevBuf tailG;
+  double tail_probe_err = 0.0, tail_max_abs = 0.0;  // build_tail_operator: G c against the recursion on a probe, max |G|
+  int tail_rejected = 0;                            // 1: not finite, 2: growth, 3: probe, 4: an error while building
+  double tail_probe_tol = 1e-11, tail_max_growth = 1e8;  // HIFIR_AMD_TAIL_PROBE_TOL / HIFIR_AMD_TAIL_GROWTH
+  double finalize_seconds = 0.0, capture_ms = 0.0;  // set-up cost: hifamd_finalize, the last hipGraph capture + instantiate
+  double bytes_inverses = 0.0, bytes_top = 0.0, bytes_tail = 0.0;  // resident explicit operators (HBM)
   bool fuse_out = true;    // S7 fused into the last band of the final U solve (HIFIR_AMD_FUSE_S7=0: k_scatter_scale over all rows)
   bool spmm_split = true;  // tiled Schur products: one 16-row block per workgroup (k_spmm_tile4); HIFIR_AMD_SPMM_SPLIT=0: per wave
   int carry_wgs = 256;   // workgroups a band's launch may add for the carried prefix of the next band (HIFIR_AMD_CARRY_WGS)
@@ -450,6 +455,8 @@ class Engine : public EngineBase {
     spmm_split = env_int("HIFIR_AMD_SPMM_SPLIT", 1) != 0;
     fuse_out = env_int("HIFIR_AMD_FUSE_S7", 1) != 0;
     tail_rows = env_int("HIFIR_AMD_TAIL_ROWS", 4096);
+    if (const char *e = getenv("HIFIR_AMD_TAIL_PROBE_TOL")) tail_probe_tol = atof(e);
+    if (const char *e = getenv("HIFIR_AMD_TAIL_GROWTH")) tail_max_growth = atof(e);
     fuse_gather = env_int("HIFIR_AMD_FUSE_S1", 1) != 0;
     spmm_tiles = env_int("HIFIR_AMD_SPMM_TILES", 1) != 0;
     use_twin = env_int("HIFIR_AMD_TWIN", 1);
@@ -830,6 +837,7 @@ class Engine : public EngineBase {
     const auto &last = host.levels.back();
     if (last.n != last.m && !host.has_dense)
       throw Error(HIFAMD_BAD_PREC, "last level has a Schur complement but no dense block was set");
+    const auto t_fin0 = std::chrono::steady_clock::now();
     if (max_nrhs_ < 1) max_nrhs_ = 1;
     max_nrhs = max_nrhs_;
     Rmax = 1;
@@ -1000,8 +1008,24 @@ class Engine : public EngineBase {
       pin_done[k] = nullptr;
     }
     pin_cap = 0;
+    for (const auto &Lp : lv) {
+      bytes_inverses += (double)Lp->L.tinv.bytes + (double)Lp->U.tinv.bytes;
+      bytes_top += (double)Lp->topG.bytes;
+    }
+    // The tail operator is an optimisation: whatever goes wrong while it is formed (allocation, a device error of
+    // its own applies) leaves the handle with the recursion -- and the handle is marked finalized only afterwards.
+    try {
+      build_tail_operator();
+    } catch (const std::exception &) {
+      (void)hipGetLastError();
+      tailG.release();
+      tail_level = -1;
+      tail_n = 0;
+      tail_rejected = 4;
+    }
+    bytes_tail = (double)tailG.bytes;
     finalized = true;
-    build_tail_operator();
+    finalize_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_fin0).count();
   }
 
   void build_tail_operator() {
@@ -1032,12 +1056,61 @@ class Engine : public EngineBase {
           for (int64_t i = 0; i < n; ++i) G[(size_t)(i + (j0 + c) * n)] = hO[(size_t)(i * 64 + c)];
       }
       check_device_error();
-      for (double g : G)
-        if (!std::isfinite(g)) return;  // (a singular tail: keep the recursion, which reports what it finds)
+      // Guards (every other explicit operator has one: block inverses and top operators fall back to substitution when
+      // their entries grow beyond dense_max_growth).  G = M_tail^{-1} bakes the sparse levels below l0 AND the (possibly
+      // rank-truncated) dense block into one matrix:
+      //  (1) every entry finite (a singular tail: keep the recursion, which reports what it finds);
+      //  (2) max |G| <= tail_max_growth: the product G c then loses at most that factor against the data;
+      //  (3) a probe: G c against the recursion on a fixed pseudo-random block c, relative difference (max norm, all 64
+      //      columns) <= tail_probe_tol -- an ill-conditioned tail, where the two roads differ by kappa eps, keeps the
+      //      recursion, i.e. the road the oracle comparison is stated for.
+      double gmax = 0.0;
+      for (double g : G) {
+        if (!std::isfinite(g)) {
+          tail_rejected = 1;
+          return;
+        }
+        gmax = std::max(gmax, std::fabs(g));
+      }
+      tail_max_abs = gmax;
+      if (gmax > tail_max_growth) {
+        tail_rejected = 2;
+        return;
+      }
       tailG.upload(mfma_operand(G.data(), n, n, ld), 4096);
       if (gemm_part.bytes < (size_t)kTopGemmSplits * (size_t)((n + 63) / 64 * 64) * 64 * sizeof(double)) {
         HIP_OK(hipStreamSynchronize(stream));
         gemm_part.alloc((size_t)kTopGemmSplits * (size_t)((n + 63) / 64 * 64) * 64 * sizeof(double));
+      }
+      {
+        uint64_t rs = 0x9E3779B97F4A7C15ull;
+        for (double &x : hI) {
+          rs = rs * 6364136223846793005ull + 1442695040888963407ull;
+          x = (double)(int64_t)(rs >> 11) / 9007199254740992.0 * 2.0 - 1.0;
+        }
+        copy_h2d(I.p, hI.data(), hI.size() * sizeof(double));
+        int64_t cnt = 0;
+        enqueue_level(stream, l0, in_direct(I.as<D>()), 64, out_direct(O.as<D>()), 64, 64, 6, 0, cnt);  // the recursion
+        HIP_OK(hipStreamSynchronize(stream));
+        copy_d2h(hO.data(), O.p, hO.size() * sizeof(double));
+        std::vector<double> hP((size_t)n * 64);
+        tail_n = n;  // (launch_tail reads it)
+        launch_tail(stream, I.as<D>(), O.as<D>(), cnt);  // the product
+        HIP_OK(hipStreamSynchronize(stream));
+        copy_d2h(hP.data(), O.p, hP.size() * sizeof(double));
+        tail_n = 0;
+        check_device_error();
+        double num = 0.0, den = 0.0;
+        for (size_t i = 0; i < hP.size(); ++i) {
+          num = std::max(num, std::fabs(hP[i] - hO[i]));
+          den = std::max(den, std::fabs(hO[i]));
+        }
+        tail_probe_err = den > 0.0 ? num / den : num;
+        if (!(tail_probe_err <= tail_probe_tol)) {
+          tailG.release();
+          tail_rejected = 3;
+          return;
+        }
       }
       tail_level = (int64_t)l0;
       tail_n = n;
@@ -1734,6 +1807,7 @@ class Engine : public EngineBase {
         graphs.erase(old);
       }
       GraphEntry ge;
+      const auto t_cap0 = std::chrono::steady_clock::now();
       HIP_OK(hipMalloc((void **)&ge.slots, 2 * sizeof(void *)));
       HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
       try {
@@ -1747,6 +1821,7 @@ class Engine : public EngineBase {
       }
       HIP_OK(hipStreamEndCapture(stream, &ge.graph));
       HIP_OK(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+      capture_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cap0).count();
       it = graphs.emplace(key, ge).first;
     }
     it->second.stamp = ++clock;
@@ -2149,8 +2224,9 @@ class Engine : public EngineBase {
       for (const DevCsr *M : {&L.L, &L.U, &L.E, &L.F})
         for (const DevBuf *b : {&M->ptr, &M->col, &M->val, &M->rowid, &M->srcslot, &M->split, &M->wg_grp_ptr, &M->grp_slot_ptr, &M->tinv})
           v.push_back(cksum(*b));
-      for (const DevBuf *b : {&L.d, &L.s, &L.t, &L.p, &L.qinv}) v.push_back(cksum(*b));
+      for (const DevBuf *b : {&L.d, &L.s, &L.t, &L.p, &L.qinv, &L.topG}) v.push_back(cksum(*b));
     }
+    v.push_back(cksum(tailG));
     for (const DevBuf *b : {&dn.QH, &dn.Rinv, &dn.jpvt0}) v.push_back(cksum(*b));
     v.push_back((uint64_t)dn.rank);
     for (int i = 0; i < cap && i < (int)v.size(); ++i) out[i] = v[(size_t)i];
@@ -2214,6 +2290,17 @@ class Engine : public EngineBase {
     o[8] = (double)wfU;
     o[9] = (double)last_launches;
     o[10] = (double)host.levels.size();
+    o[13] = finalize_seconds;
+    o[14] = bytes_inverses + bytes_top + bytes_tail;
+    o[15] = capture_ms;
+  }
+  // set-up / operator accounting beyond the 16 slots of hifamd_stats (hifir_amd.h hifamd_stats_ext)
+  int stats_ext(double *o, int cap) const {
+    const double v[] = {finalize_seconds, capture_ms,     bytes_inverses,  bytes_top,     bytes_tail,           (double)tail_n,
+                        (double)tail_level, tail_probe_err, tail_max_abs, (double)tail_rejected, tail_probe_tol, tail_max_growth};
+    const int nv = (int)(sizeof(v) / sizeof(v[0]));
+    for (int i = 0; i < cap && i < nv; ++i) o[i] = v[i];
+    return nv;
   }
 
   int64_t nnz_total() const {
@@ -2713,6 +2800,11 @@ int64_t hifamd_levels(HifAmdHdl h) { QUERY(q_levels(ENG_D), q_levels(ENG_Z)) }
 int64_t hifamd_nnz(HifAmdHdl h) { QUERY(ENG_D->nnz_total(), ENG_Z->nnz_total()) }
 int64_t hifamd_schur_size(HifAmdHdl h) { QUERY(q_schur_size(ENG_D), q_schur_size(ENG_Z)) }
 int64_t hifamd_schur_rank(HifAmdHdl h) { QUERY(q_schur_rank(ENG_D), q_schur_rank(ENG_Z)) }
+
+int hifamd_stats_ext(HifAmdHdl h, double *out, int cap) {
+  if (!h || !h->eng || (cap > 0 && !out)) return -1;
+  return h->vt == HIFAMD_D ? ENG_D->stats_ext(out, cap) : ENG_Z->stats_ext(out, cap);
+}
 
 HifAmdStatus hifamd_stats(HifAmdHdl h, double *stats16) {
   API_BEGIN

@@ -191,8 +191,16 @@ class HIF:
         s = np.zeros(16)
         _check(lib().hifamd_stats(self._h, _p(s)))
         keys = ["sum_n", "sum_m", "nnz_LU", "nnz_EF", "dense_n", "B_mat", "B_vec", "wavefronts_L", "wavefronts_U",
-                "launches", "sparse_levels", "bands", "band_workgroups"]
+                "launches", "sparse_levels", "bands", "band_workgroups", "finalize_s", "operator_bytes", "graph_capture_ms"]
         return {k: float(s[i]) for i, k in enumerate(keys)}
+
+    def stats_ext(self):
+        """Set-up cost and resident explicit operators (hifamd_stats_ext)."""
+        s = np.zeros(16)
+        k = lib().hifamd_stats_ext(self._h, _p(s), 16)
+        keys = ["finalize_s", "graph_capture_ms", "bytes_inverses", "bytes_top", "bytes_tail", "tail_rows", "tail_level",
+                "tail_probe_relerr", "tail_max_abs", "tail_rejected", "tail_probe_tol", "tail_max_growth"]
+        return {key: float(s[i]) for i, key in enumerate(keys[:max(0, k)])}
 
     def algorithmic_bytes(self, nrhs):
         """B_alg(nrhs) = B_mat + nrhs * B_vec of SURVEY 8(d), for the hierarchy actually resident."""

@@ -127,8 +127,16 @@ int64_t hifamd_schur_rank(HifAmdHdl h);
 /* stats[0..15]: 0 sum n_l, 1 sum m_l, 2 nnz(L)+nnz(U), 3 nnz(E)+nnz(F), 4 dense n, 5 B_mat bytes,
  * 6 B_vec bytes per RHS (SURVEY 8d formula), 7 #wavefronts L (all levels), 8 #wavefronts U,
  * 9 kernel launches per apply at the last captured batch width, 10 sparse levels, 11 bands (L+U, all
- * levels), 12 band workgroups, 13..15 reserved */
+ * levels), 12 band workgroups, 13 seconds spent in hifamd_finalize, 14 bytes of explicit operators resident in HBM
+ * (block inverses + combined top operators + the tail operator), 15 milliseconds of the last hipGraph capture */
 HifAmdStatus hifamd_stats(HifAmdHdl h, double *stats16);
+/* Set-up and operator accounting (additive, no reference counterpart); returns the number of values it knows, writes
+ * min(cap, that) of them: 0 finalize seconds, 1 last graph capture ms, 2 bytes of block inverses, 3 bytes of combined top
+ * operators, 4 bytes of the tail operator, 5 rows of the tail operator (0: the recursion runs), 6 its first level,
+ * 7 relative difference product vs recursion on the finalize-time probe, 8 max |entry| of the tail operator, 9 why it
+ * was rejected (0 not, 1 not finite, 2 growth, 3 probe, 4 an error while it was formed), 10 / 11 the probe and growth
+ * limits in force (HIFIR_AMD_TAIL_PROBE_TOL, HIFIR_AMD_TAIL_GROWTH).  -1 for a NULL handle. */
+int hifamd_stats_ext(HifAmdHdl h, double *out, int cap);
 /* level schedule of one triangular factor (host-side analysis; usable without a GPU):
  * which = 0 (L_B) / 1 (U_B).  *nwf = number of wavefronts; if order != NULL it receives the m row
  * ids in processing order and wf_ptr (nwf+1 entries) the wavefront boundaries into it. */

@@ -41,6 +41,7 @@ def child(path, nrhs_list, check):
             err = " relerr=%.2e" % (np.abs(x - xo).max() / np.abs(xo).max())
         out.append("nrhs=%d %.3f ms launches=%d%s" % (nrhs, ms, M.stats()["launches"], err))
     print("  finalize %.2fs | " % fin + " | ".join(out), flush=True)
+    print("  stats_ext", {k: (round(v, 3) if abs(v) > 1e-3 else v) for k, v in M.stats_ext().items()}, flush=True)
     M.close()
 
 

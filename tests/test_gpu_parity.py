@@ -231,6 +231,10 @@ def test_saved_hierarchy_applies_identically(cache, name, tmp_path):
     ck = lambda H: (lambda o: o[:hifir_amd.lib().hifamd_debug_checksums(H._h, o.ctypes.data, 256)])(np.zeros(256, np.uint64))
     M3 = hifir_amd.HIF.load(path, max_nrhs=64)
     assert np.array_equal(ck(M2), ck(M3))
+    # ... including the operators that finalize FORMS (combined tops on the host, the tail operator by the device's own
+    # applies on the identity): built twice from one file, and once from the caller's arrays, they are the same bytes
+    assert np.array_equal(ck(M), ck(M2))
+    assert M.stats_ext()["tail_rows"] == M2.stats_ext()["tail_rows"]
     for tr in (False, True):
         X2, X1 = M2.solve_mrhs(d["B4"], trans=tr), M.solve_mrhs(d["B4"], trans=tr)
         assert np.array_equal(X2, X1), (tr, relerr(X2, d["XT4"] if tr else d["X4"]))

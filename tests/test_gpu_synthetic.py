@@ -146,6 +146,112 @@ def test_rank_deficient_dense_block_all_operators():
         assert relerr(M.mmultiply(b, rank=0, trans=True), O.mmultiply(b, rank=0, trans=True)) <= 1e-9
 
 
+def _two_level_with_dense(seed, D, n0=3000, m0=2300, m1=520):
+    rng = np.random.default_rng(seed)
+    n1 = n0 - m0
+    nd = n1 - m1
+    assert D.shape == (nd, nd)
+    lv0 = _level(m0, n0, _rand_tri(m0, 0.004, True, rng), _rand_tri(m0, 0.004, False, rng),
+                 sp.random(n0 - m0, m0, density=0.01, random_state=np.random.RandomState(seed), format="csr"),
+                 sp.random(m0, n0 - m0, density=0.01, random_state=np.random.RandomState(seed + 7), format="csr"), rng)
+    lv1 = _level(m1, n1, _rand_tri(m1, 0.02, True, rng), _rand_tri(m1, 0.02, False, rng),
+                 sp.random(nd, m1, density=0.05, random_state=np.random.RandomState(seed + 1), format="csr"),
+                 sp.random(m1, nd, density=0.05, random_state=np.random.RandomState(seed + 2), format="csr"), rng)
+    lv1["dense_n"], lv1["dense"] = nd, D.ravel(order="F")
+    return [lv0, lv1]
+
+
+def test_tail_operator_with_rank_deficient_block(monkeypatch):
+    # The tail of the hierarchy (level 1 and the dense block behind it) is applied as ONE operator formed at finalize
+    # (engine.hip build_tail_operator) -- here with a rank-deficient QRCP block inside it (9 exactly dependent columns,
+    # QRCP.hpp:371-411 truncates): the numerical rank goes through the operator, any other rank through the recursion;
+    # both must agree with the oracle as well as the recursion alone does.
+    rng = np.random.default_rng(21)
+    nd = 180
+    D = rng.normal(size=(nd, nd)) + 3 * np.eye(nd)
+    D[:, nd - 9:] = D[:, :9] @ rng.normal(size=(9, 9))
+    levels = _two_level_with_dense(21, D)
+    O = orc.Oracle(levels)
+    B = rng.uniform(-1, 1, size=(3000, 64))
+    monkeypatch.setenv("HIFIR_AMD_TAIL_ROWS", "0")
+    M0 = hifir_amd.HIF.from_levels(levels, max_nrhs=64)  # the recursion alone
+    monkeypatch.delenv("HIFIR_AMD_TAIL_ROWS")
+    M = hifir_amd.HIF.from_levels(levels, max_nrhs=64)
+    se = M.stats_ext()
+    assert M0.stats_ext()["tail_rows"] == 0
+    assert se["tail_rows"] == 700 or se["tail_rejected"] in (2.0, 3.0), se  # formed, or refused by a guard (never silently)
+    assert M.schur_rank() == O.dense_rank == nd - 9
+    # (rank = -1, "full", divides by the block's rounding-level pivots: no two implementations agree on that noise)
+    for rank in (0, 50, nd - 9, 120):
+        X, X0 = M.solve_mrhs(B, rank=rank), M0.solve_mrhs(B, rank=rank)
+        for c in (0, 17, 63):
+            xo = O.solve(B[:, c].copy(), rank=rank)
+            e0 = relerr(X0[:, c], xo)
+            assert e0 <= 1e-8, (rank, c, e0)
+            assert relerr(X[:, c], xo) <= max(10 * e0, 1e-12), (rank, c, relerr(X[:, c], xo), e0, se)
+
+
+def test_tail_operator_with_ill_conditioned_coarse_level(monkeypatch):
+    # kappa(dense block) ~ 1e10: product and recursion differ by kappa * eps -- the finalize-time probe must notice and
+    # keep the recursion (or the operator must be as good as the recursion against the oracle)
+    rng = np.random.default_rng(22)
+    nd = 180
+    Q1, _ = np.linalg.qr(rng.normal(size=(nd, nd)))
+    Q2, _ = np.linalg.qr(rng.normal(size=(nd, nd)))
+    D = (Q1 * np.logspace(0, -10, nd)) @ Q2.T
+    levels = _two_level_with_dense(22, D)
+    O = orc.Oracle(levels)
+    B = rng.uniform(-1, 1, size=(3000, 64))
+    monkeypatch.setenv("HIFIR_AMD_TAIL_ROWS", "0")
+    M0 = hifir_amd.HIF.from_levels(levels, max_nrhs=64, rrqr_cond=1e14)
+    monkeypatch.delenv("HIFIR_AMD_TAIL_ROWS")
+    M = hifir_amd.HIF.from_levels(levels, max_nrhs=64, rrqr_cond=1e14)
+    se = M.stats_ext()
+    X, X0 = M.solve_mrhs(B, rank=-1), M0.solve_mrhs(B, rank=-1)
+    for c in (0, 31, 63):
+        xo = O.solve(B[:, c].copy(), rank=-1)
+        e0 = relerr(X0[:, c], xo)
+        assert relerr(X[:, c], xo) <= max(10 * e0, 1e-12), (c, relerr(X[:, c], xo), e0, se)
+    # the guard's verdict is visible: either the probe passed at its limit, or the operator was refused
+    assert (se["tail_rows"] > 0 and se["tail_probe_relerr"] <= se["tail_probe_tol"]) or se["tail_rejected"] in (1.0, 2.0, 3.0), se
+
+
+def test_non_finite_column_does_not_poison_later_solves():
+    # level 0 with fewer than 32 leading rows (the tail product's right-hand side then sits right in front of rows that
+    # the same solve writes) -- a solve with a NaN column, then a finite solve on the same handle: exact same result as
+    # on a fresh handle (round 2's product read up to 31 rows behind its panel through zero columns: 0 x NaN)
+    rng = np.random.default_rng(23)
+    n0, m0 = 620, 20
+    n1 = n0 - m0
+    m1 = 420
+    nd = n1 - m1
+    lv0 = _level(m0, n0, _rand_tri(m0, 0.2, True, rng), _rand_tri(m0, 0.2, False, rng),
+                 sp.random(n1, m0, density=0.05, random_state=np.random.RandomState(1), format="csr"),
+                 sp.random(m0, n1, density=0.05, random_state=np.random.RandomState(2), format="csr"), rng)
+    lv1 = _level(m1, n1, _rand_tri(m1, 0.02, True, rng), _rand_tri(m1, 0.02, False, rng),
+                 sp.random(nd, m1, density=0.05, random_state=np.random.RandomState(3), format="csr"),
+                 sp.random(m1, nd, density=0.05, random_state=np.random.RandomState(4), format="csr"), rng)
+    lv1["dense_n"], lv1["dense"] = nd, (rng.normal(size=(nd, nd)) + 4 * np.eye(nd)).ravel(order="F")
+    levels = [lv0, lv1]
+    O = orc.Oracle(levels)
+    B = rng.uniform(-1, 1, size=(n0, 64))
+    Mf = hifir_amd.HIF.from_levels(levels, max_nrhs=64)
+    Xf = Mf.solve_mrhs(B)
+    M = hifir_amd.HIF.from_levels(levels, max_nrhs=64)
+    Bn = B.copy()
+    Bn[:, 5] = np.nan
+    Bn[3, 9] = np.inf
+    Xn = M.solve_mrhs(Bn)
+    assert not np.isfinite(Xn[:, 5]).any() or np.isnan(Xn[:, 5]).any()
+    good = [c for c in range(64) if c not in (5, 9)]
+    assert np.array_equal(Xn[:, good], Xf[:, good])  # columns are independent of each other
+    X2 = M.solve_mrhs(B)
+    assert np.isfinite(X2).all()
+    assert np.array_equal(X2, Xf)
+    for c in (0, 5, 9, 63):
+        assert relerr(X2[:, c], O.solve(B[:, c].copy())) <= 1e-12
+
+
 def test_one_based_matrix_input():
     # the outer matrix may come 1-based like the reference accepts it (builder.hpp:311-329)
     torch = pytest.importorskip("torch")
