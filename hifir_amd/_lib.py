@@ -50,6 +50,7 @@ SIGNATURES = {
     "hifamd_fgmres_batch": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _int, _dbl, _int, _i64, _vp, _vp, _vp]),
     "hifamd_time_apply": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _int, _int, _vp]),
     "hifamd_sync": (_int, [_vp]),
+    "hifamd_copy_columns_dev": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64]),
     "hifamd_debug_checksums": (_int, [_vp, _vp, _int]),
 }
 

@@ -2608,6 +2608,16 @@ static void do_time(E *e, const D *dB, int64_t ldb, D *dX, int64_t ldx, int64_t 
 }
 
 template <class E>
+static void do_copy_columns(E *e, size_t elem, const void *src, int64_t lds, int64_t ncols, void *dst, int64_t ldd, int64_t col0) {
+  if (!e->finalized) throw Error(HIFAMD_BAD_PREC, "hierarchy not finalized (hifamd_finalize)");
+  if (!src || !dst) throw Error(HIFAMD_NULL_OBJ, "NULL vector");
+  if (ncols < 1 || lds < ncols || col0 < 0 || ldd < col0 + ncols) throw Error(HIFAMD_MISMATCHED_SIZES, "column block does not fit");
+  HIP_OK(hipSetDevice(e->device));
+  const int64_t n = e->lv[0]->n;
+  HIP_OK(hipMemcpy2DAsync((char *)dst + (size_t)col0 * elem, (size_t)ldd * elem, src, (size_t)lds * elem, (size_t)ncols * elem,
+                          (size_t)n, hipMemcpyDefault, e->stream));
+}
+template <class E>
 static void do_sync(E *e) {
   if (!e->finalized) throw Error(HIFAMD_BAD_PREC, "hierarchy not finalized (hifamd_finalize)");
   HIP_OK(hipSetDevice(e->device));
@@ -2937,6 +2947,14 @@ HifAmdStatus hifamd_time_apply(HifAmdHdl h, const void *dB, int64_t ldb, void *d
 HifAmdStatus hifamd_sync(HifAmdHdl h) {
   API_BEGIN
   DISPATCH(do_sync(ENG_D), do_sync(ENG_Z))
+  API_END
+}
+
+HifAmdStatus hifamd_copy_columns_dev(HifAmdHdl h, const void *src, int64_t lds, int64_t ncols, void *dst, int64_t ldd,
+                                     int64_t col0) {
+  API_BEGIN
+  DISPATCH(do_copy_columns(ENG_D, sizeof(double), src, lds, ncols, dst, ldd, col0),
+           do_copy_columns(ENG_Z, 2 * sizeof(double), src, lds, ncols, dst, ldd, col0))
   API_END
 }
 

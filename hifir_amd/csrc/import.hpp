@@ -369,6 +369,16 @@ void get_vec(std::FILE *f, std::vector<V> &v, int64_t limit) {
   int64_t cnt = 0;
   if (std::fread(&cnt, sizeof(cnt), 1, f) != 1) throw Error(kBadPrec, "truncated hierarchy file");
   if (cnt < 0 || cnt > limit) throw Error(kBadPrec, "corrupt hierarchy file (array length)");
+  // ... and by what the file still holds: the record header itself comes from the file (n up to INT32_MAX), so a
+  // few-byte hostile or truncated file must not make this allocate gigabytes before the short read is noticed
+  if (cnt > 0) {
+    const long here = std::ftell(f);
+    if (here >= 0 && std::fseek(f, 0, SEEK_END) == 0) {
+      const long end = std::ftell(f);
+      if (std::fseek(f, here, SEEK_SET) != 0) throw Error(kHifirError, "hierarchy file: seek failed");
+      if (end >= here && (uint64_t)cnt > (uint64_t)(end - here) / sizeof(V)) throw Error(kBadPrec, "truncated hierarchy file");
+    }
+  }
   v.resize((size_t)cnt);
   if (cnt && std::fread(v.data(), sizeof(V), (size_t)cnt, f) != (size_t)cnt) throw Error(kBadPrec, "truncated hierarchy file");
   const size_t padb = (8 - (cnt * sizeof(V)) % 8) % 8;
@@ -478,8 +488,13 @@ void load_hierarchy(std::FILE *f, Sink &sink) {
     if ((int64_t)mat.size() != nd * nd) throw Error(kBadPrec, "inconsistent hierarchy file (dense block)");
     if (hd == 3)
       sink.set_dense_lup(nd, mat.data());
-    else if (hd == 2)
+    else if (hd == 2) {
+      // (the record's double carries the caller's integer spd flag -- its sign matters: a NaN or a value out of int's
+      //  range, whose conversion is undefined behaviour, is a corrupt file)
+      if (!(std::isfinite(cond) && std::fabs(cond) <= 1e9 && cond == std::floor(cond)))
+        throw Error(kBadPrec, "corrupt hierarchy file (spd flag of the symmetric block)");
       sink.set_dense_symm(nd, mat.data(), (int)cond);
+    }
     else
       sink.set_dense(nd, mat.data(), cond);
   }

@@ -228,6 +228,12 @@ HifAmdStatus hifamd_fgmres_batch(HifAmdHdl h, const void *B, int64_t ldb, void *
 HifAmdStatus hifamd_time_apply(HifAmdHdl h, const void *dB, int64_t ldb, void *dX, int64_t ldx,
                                int64_t nrhs, int64_t rank, int warmup, int reps, double *ms_avg);
 HifAmdStatus hifamd_sync(HifAmdHdl h);
+/* Stream-ordered copy of an [n][ncols] block (device memory of the handle's device, row stride lds) into the columns
+ * [col0, col0 + ncols) of dst (row stride ldd; device memory of ANY device of the process: a peer copy), enqueued on
+ * the handle's own stream behind whatever was enqueued there with stream = NULL -- the gather of an RHS-sharded batch
+ *  without a host round trip.  Not synchronized (hifamd_sync). */
+HifAmdStatus hifamd_copy_columns_dev(HifAmdHdl h, const void *src, int64_t lds, int64_t ncols, void *dst, int64_t ldd,
+                                     int64_t col0);
 /* development aid: checksums of the device-resident arrays of a finalized handle (per level: the nine
  * arrays of L, U, E, F, then d, s, t, p, q_inv; finally Q^H, R^{-1}, jpvt and the rank); returns how many */
 int hifamd_debug_checksums(HifAmdHdl h, uint64_t *out, int cap);

@@ -34,6 +34,27 @@ LhfStatus lhfzApplyBatch(const LhfzHifHdl hif, const LhfOperationType op, const 
                          const size_t ldb, const int nirs, const double *betas, const int rank, double _Complex *X,
                          const size_t ldx, int *ir_status);
 
+/* The same for a batch that is ALREADY sharded over the devices of lhfSetDevices and stays there (a Krylov solver on
+ * several GPUs): block d -- B_dev[d], X_dev[d]: device pointers into the HBM of device ids[d], row-interleaved
+ * [n][ncols[d]] with row strides ldb[d], ldx[d] -- is applied by the handle's replica d.  Direct operators only
+ * (LHF_S / LHF_SH with the numerical rank, LHF_M / LHF_MH; no refinement); every block is ENQUEUED on its replica's own
+ * stream and the call returns: no PCIe traffic, no host threads.  nblocks <= the number of devices given to
+ * lhfSetDevices before the handle was set up; a block of 0 columns is skipped.
+ * lhf?GatherBatchDev enqueues, behind those applies, peer copies of the blocks into the consecutive column ranges of
+ * ONE [n][ldd] block dst_dev (device memory of any device; SURVEY 8(e): the gather at the end of a batch);
+ * lhf?SyncDevices waits for everything enqueued on the handle's replicas. */
+LhfStatus lhfdApplyBatchDev(const LhfdHifHdl hif, const LhfOperationType op, const int nblocks, const double *const *B_dev,
+                            const size_t *ncols, const size_t *ldb, double *const *X_dev, const size_t *ldx);
+LhfStatus lhfzApplyBatchDev(const LhfzHifHdl hif, const LhfOperationType op, const int nblocks,
+                            const double _Complex *const *B_dev, const size_t *ncols, const size_t *ldb,
+                            double _Complex *const *X_dev, const size_t *ldx);
+LhfStatus lhfdGatherBatchDev(const LhfdHifHdl hif, const int nblocks, const double *const *X_dev, const size_t *ncols,
+                             const size_t *ldx, double *dst_dev, const size_t ldd);
+LhfStatus lhfzGatherBatchDev(const LhfzHifHdl hif, const int nblocks, const double _Complex *const *X_dev,
+                             const size_t *ncols, const size_t *ldx, double _Complex *dst_dev, const size_t ldd);
+LhfStatus lhfdSyncDevices(const LhfdHifHdl hif);
+LhfStatus lhfzSyncDevices(const LhfzHifHdl hif);
+
 /* Export / import of the factored hierarchy in the on-disk format of hifamd_save / hifamd_load (include/hifir_amd.h):
  * factorize once where the host factorization is affordable, apply on GPU nodes without refactorizing.  A loaded
  * handle serves Apply / Solve / the size queries; lhf?Refactorize gives it a host factorization again. */

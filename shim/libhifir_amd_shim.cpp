@@ -366,6 +366,54 @@ LhfStatus hif_apply(HifRec<V> *h, LhfOperationType op, const V *B, std::size_t n
   return LHF_SUCCESS;
 }
 
+// lhf?ApplyBatchDev: the blocks of an RHS-sharded batch stay in the HBM of their devices (block d on replica d, i.e. on
+// device ids[d] of lhfSetDevices); direct operators only; enqueue-and-return on the replicas' own streams
+template <class V>
+LhfStatus hif_apply_dev(HifRec<V> *h, LhfOperationType op, int nblocks, const V *const *B, const std::size_t *ncols,
+                        const std::size_t *ldb, V *const *X, const std::size_t *ldx) {
+  if (!h) return LHF_NULL_OBJ;
+  if (h->gpu.empty()) return fail("MILU-Prec is empty!");
+  if (op != LHF_S && op != LHF_SH && op != LHF_M && op != LHF_MH) return fail("unknown operation tag");
+  if (nblocks < 1 || !B || !X || !ncols || !ldb || !ldx) return LHF_NULL_OBJ;
+  if ((std::size_t)nblocks > h->gpu.size()) return LHF_MISMATCHED_SIZES;  // one replica (lhfSetDevices) per block
+  for (int d = 0; d < nblocks; ++d) {
+    if (!ncols[d]) continue;  // (an empty block: nothing to do on that device)
+    if (!B[d] || !X[d]) return LHF_NULL_OBJ;
+    if (ldb[d] < ncols[d] || ldx[d] < ncols[d]) return LHF_MISMATCHED_SIZES;
+    const LhfStatus st = from_amd(hifamd_apply_batch_dev(h->gpu[(std::size_t)d], (HifAmdOp)op, B[d], (int64_t)ldb[d], X[d],
+                                                         (int64_t)ldx[d], (int64_t)ncols[d], 0, nullptr));
+    if (st != LHF_SUCCESS) return st;
+  }
+  return LHF_SUCCESS;
+}
+template <class V>
+LhfStatus hif_gather_dev(HifRec<V> *h, int nblocks, const V *const *X, const std::size_t *ncols, const std::size_t *ldx,
+                         V *dst, std::size_t ldd) {
+  if (!h) return LHF_NULL_OBJ;
+  if (h->gpu.empty()) return fail("MILU-Prec is empty!");
+  if (nblocks < 1 || !X || !ncols || !ldx || !dst) return LHF_NULL_OBJ;
+  if ((std::size_t)nblocks > h->gpu.size()) return LHF_MISMATCHED_SIZES;
+  std::size_t col0 = 0;
+  for (int d = 0; d < nblocks; ++d) {
+    if (ncols[d]) {
+      const LhfStatus st = from_amd(hifamd_copy_columns_dev(h->gpu[(std::size_t)d], X[d], (int64_t)ldx[d], (int64_t)ncols[d], dst,
+                                                            (int64_t)ldd, (int64_t)col0));
+      if (st != LHF_SUCCESS) return st;
+    }
+    col0 += ncols[d];
+  }
+  return LHF_SUCCESS;
+}
+template <class V>
+LhfStatus hif_sync_devices(HifRec<V> *h) {
+  if (!h) return LHF_NULL_OBJ;
+  for (HifAmdHdl g : h->gpu) {
+    const LhfStatus st = from_amd(hifamd_sync(g));
+    if (st != LHF_SUCCESS) return st;
+  }
+  return LHF_SUCCESS;
+}
+
 template <class V>
 void hif_stats(const HifRec<V> *h, std::size_t stats[]) {  // the nine slots of lhf?GetStats (libhifir.h:700-716)
   for (int i = 0; i < 9; ++i) stats[i] = 0;
@@ -560,6 +608,16 @@ LHF_MATRIX_API(c, cflt, float _Complex)
     if (!nrhs || ldb < nrhs || ldx < nrhs) return hif ? LHF_MISMATCHED_SIZES : LHF_NULL_OBJ;                          \
     return hif_apply<V>(hif, op, (const V *)B, nrhs, ldb, nirs, betas, rank, (V *)X, ldx, ir_status);                 \
   }                                                                                                                   \
+  LhfStatus lhf##T##ApplyBatchDev(const Lhf##T##HifHdl hif, const LhfOperationType op, const int nblocks,             \
+                                  const CV *const *B_dev, const size_t *ncols, const size_t *ldb, CV *const *X_dev,   \
+                                  const size_t *ldx) {                                                                \
+    return hif_apply_dev<V>(hif, op, nblocks, (const V *const *)B_dev, ncols, ldb, (V *const *)X_dev, ldx);           \
+  }                                                                                                                   \
+  LhfStatus lhf##T##GatherBatchDev(const Lhf##T##HifHdl hif, const int nblocks, const CV *const *X_dev,               \
+                                   const size_t *ncols, const size_t *ldx, CV *dst_dev, const size_t ldd) {           \
+    return hif_gather_dev<V>(hif, nblocks, (const V *const *)X_dev, ncols, ldx, (V *)dst_dev, ldd);                   \
+  }                                                                                                                   \
+  LhfStatus lhf##T##SyncDevices(const Lhf##T##HifHdl hif) { return hif_sync_devices<V>(hif); }                        \
   LhfStatus lhf##T##GetStats(const Lhf##T##HifHdl hif, size_t stats[]) {                                              \
     hif_stats<V>(hif, stats);                                                                                         \
     return LHF_SUCCESS;                                                                                               \

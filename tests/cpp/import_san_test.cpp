@@ -205,6 +205,16 @@ static int run_file(const char *path, const std::vector<unsigned char> &bytes, i
     }
     std::memcpy(&mut[off], &keep, 8);
   }
+  {  // a few dozen bytes that CLAIM a 2^31-row level: every count is bounded by what the file still holds, so this is
+     // refused before anything of that size is allocated (under ASan a 16 GB request would abort the run)
+    std::vector<unsigned char> tiny(bytes.begin(), bytes.begin() + 16);
+    const int64_t big = 2147483647;
+    const int64_t words[] = {1, 0, big, big, 0, big, big, big + 1, 0, 0, 0, 0};
+    tiny.insert(tiny.end(), (const unsigned char *)words, (const unsigned char *)words + sizeof(words));
+    const int before = refused;
+    attempt(tiny);
+    if (refused != before + 1) ++bad;
+  }
   std::fprintf(stderr, "%s: levels=%zu dense=%d blocks(L0)=%zu  hostile files: %d refused, %d loaded  -> %s\n", path,
                A.host.levels.size(), (int)A.host.has_dense, A.host.levels[0].Lp.blk_slot0.size(), refused, accepted,
                bad ? "FAILED" : "ok");

@@ -62,6 +62,9 @@ def lib():
         for t in "dz":
             g = lambda name: getattr(L, f"lhf{t}{name}")
             g("ApplyBatch").argtypes = [_vp, _int, _vp, _sz, _sz, _int, _dp, _int, _vp, _sz, C.POINTER(_int)]
+            g("ApplyBatchDev").argtypes = [_vp, _int, _int, _vp, C.POINTER(_sz), C.POINTER(_sz), _vp, C.POINTER(_sz)]
+            g("GatherBatchDev").argtypes = [_vp, _int, _vp, C.POINTER(_sz), C.POINTER(_sz), _vp, _sz]
+            g("SyncDevices").argtypes = [_vp]
             g("SaveHierarchy").argtypes = [_vp, C.c_char_p]
             g("LoadHierarchy").restype = _vp
             g("LoadHierarchy").argtypes = [C.c_char_p]

@@ -190,6 +190,54 @@ def test_apply_batch_devices_and_hierarchy_files(case, request, tmp_path):
     assert L.lhfSetDevices(bad, 1) == su.LHF_MISMATCHED_SIZES
 
 
+@pytest.mark.parametrize("case", ["real_case", "complex_case"])
+def test_apply_batch_dev_blocks_stay_in_hbm(case, request):
+    # lhf?ApplyBatchDev / GatherBatchDev / SyncDevices (include/libhifir_amd_ext.h): a batch that is already sharded over
+    # the devices of lhfSetDevices -- here two replicas on device 0 -- is applied where it lies, block d by replica d,
+    # enqueue-and-return; the gather writes the blocks side by side into one device array.  Same bits as lhf?ApplyBatch.
+    torch = pytest.importorskip("torch")
+    levels, d, A, M = request.getfixturevalue(case)
+    L = su.lib()
+    t = M.t
+    st, X, _ = M.apply_batch(su.LHF_S, d["B4"])
+    assert st == 0
+    st, XM, _ = M.apply_batch(su.LHF_M, d["B4"])
+    assert st == 0
+    ids = (C.c_int * 2)(0, 0)
+    assert L.lhfSetDevices(ids, 2) == su.LHF_SUCCESS
+    try:
+        M3 = su.Hif(t, A, None, su.default_params())
+        assert M3.h, su.errmsg()
+        B = np.ascontiguousarray(d["B4"])
+        n = B.shape[0]
+        blocks = [np.ascontiguousarray(B[:, :3]), np.ascontiguousarray(B[:, 3:])]  # 3 + 1 columns
+        Bd = [torch.from_numpy(b).cuda() for b in blocks]
+        Xd = [torch.empty_like(b) for b in Bd]
+        ncols = (C.c_size_t * 2)(3, 1)
+        Bp = (C.c_void_p * 2)(*[b.data_ptr() for b in Bd])
+        Xp = (C.c_void_p * 2)(*[x.data_ptr() for x in Xd])
+        for op, want in ((su.LHF_S, X), (su.LHF_M, XM)):
+            assert getattr(L, f"lhf{t}ApplyBatchDev")(M3.h, op, 2, Bp, ncols, ncols, Xp, ncols) == su.LHF_SUCCESS, su.errmsg()
+            G = torch.zeros((n, 6), dtype=Bd[0].dtype, device="cuda")  # gathered with a padded row stride
+            torch.cuda.synchronize()  # (torch fills G on ITS stream; the replicas' streams know nothing of it)
+            assert getattr(L, f"lhf{t}GatherBatchDev")(M3.h, 2, Xp, ncols, ncols, C.c_void_p(G.data_ptr()), 6) == su.LHF_SUCCESS
+            assert getattr(L, f"lhf{t}SyncDevices")(M3.h) == su.LHF_SUCCESS
+            got = G.cpu().numpy()
+            assert np.array_equal(got[:, :4], want) and not got[:, 4:].any()
+            assert np.array_equal(Xd[0].cpu().numpy(), want[:, :3]) and np.array_equal(Xd[1].cpu().numpy(), want[:, 3:])
+        # errors: more blocks than replicas, a stride smaller than the block, NULL arrays
+        three = (C.c_size_t * 3)(1, 1, 1)
+        Bp3 = (C.c_void_p * 3)(Bd[0].data_ptr(), Bd[0].data_ptr(), Bd[0].data_ptr())
+        assert getattr(L, f"lhf{t}ApplyBatchDev")(M3.h, su.LHF_S, 3, Bp3, three, three, Bp3, three) == su.LHF_MISMATCHED_SIZES
+        small = (C.c_size_t * 2)(2, 1)
+        assert getattr(L, f"lhf{t}ApplyBatchDev")(M3.h, su.LHF_S, 2, Bp, ncols, small, Xp, ncols) == su.LHF_MISMATCHED_SIZES
+        assert getattr(L, f"lhf{t}ApplyBatchDev")(M3.h, su.LHF_S, 2, None, ncols, ncols, Xp, ncols) == su.LHF_NULL_OBJ
+        assert getattr(L, f"lhf{t}ApplyBatchDev")(None, su.LHF_S, 2, Bp, ncols, ncols, Xp, ncols) == su.LHF_NULL_OBJ
+        M3.close()
+    finally:
+        assert L.lhfSetDevices(None, 0) == su.LHF_SUCCESS
+
+
 def test_single_precision_families_refuse(real_case):
     levels, d, A, M = real_case
     L = su.lib()
