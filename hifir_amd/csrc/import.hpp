@@ -89,13 +89,33 @@ HostLevel<T> import_level(int64_t parent_nm, int64_t m, int64_t n, const int64_t
   return H;
 }
 
+// two independent pieces of host work side by side (an exception of either is rethrown after both have finished)
+template <class FA, class FB>
+void par2(FA &&fa, FB &&fb) {
+  std::exception_ptr ea, eb;
+  std::thread ta([&] {
+    try {
+      fa();
+    } catch (...) {
+      ea = std::current_exception();
+    }
+  });
+  try {
+    fb();
+  } catch (...) {
+    eb = std::current_exception();
+  }
+  ta.join();
+  if (ea) std::rethrow_exception(ea);
+  if (eb) std::rethrow_exception(eb);
+}
+
 // schedules, band plans, slot-ordered matrices and the block cutting of one level (H.Lr .. H.Fr given)
 template <class T>
 void analyze_level(HostLevel<T> &H, const BandOptions &band_opt, bool dump = false, size_t level_no = 0) {
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t0 = now();
-  H.Ls = level_schedule(H.Lr, true);
-  H.Us = level_schedule(H.Ur, false);
+  par2([&] { H.Ls = level_schedule(H.Lr, true); }, [&] { H.Us = level_schedule(H.Ur, false); });
   double t1 = now();
   // component-dense plan (host.hpp plan_bands_cd) for triangles with real rows to gather; the depth-cut bands for the
   // nearly diagonal ones (level 0 of a PDE hierarchy: ~2 nonzeros per row, shallow, bandwidth-bound) and in exact mode
@@ -111,8 +131,8 @@ void analyze_level(HostLevel<T> &H, const BandOptions &band_opt, bool dump = fal
     // the narrow top of the level as ONE dense operator (host.hpp choose_top): replan both triangles around it
     if (band_opt.top_max > 0) H.top = choose_top(H.Lr, H.Ur, H.Lp, band_opt.top_max, band_opt.top_few_wgs);
     if (!H.top.empty()) {
-      H.Lp = plan_bands_cd(H.Lr, H.Ls, true, band_opt, &H.top);
-      H.Up = plan_bands_cd(H.Ur, H.Us, false, band_opt, &H.top);
+      par2([&] { H.Lp = plan_bands_cd(H.Lr, H.Ls, true, band_opt, &H.top); },
+           [&] { H.Up = plan_bands_cd(H.Ur, H.Us, false, band_opt, &H.top); });
       for (uint8_t t : H.top) H.top_n += t;
       H.top_bandL = (int32_t)H.Lp.nbands() - 1;  // lower: the rest band comes last; upper: first
       H.top_bandU = 0;
@@ -120,8 +140,7 @@ void analyze_level(HostLevel<T> &H, const BandOptions &band_opt, bool dump = fal
         H.top.clear();
         H.top_n = 0;
         H.top_bandL = H.top_bandU = -1;
-        H.Lp = plan_bands_cd(H.Lr, H.Ls, true, band_opt);
-        H.Up = plan_bands_cd(H.Ur, H.Us, false, band_opt);
+        par2([&] { H.Lp = plan_bands_cd(H.Lr, H.Ls, true, band_opt); }, [&] { H.Up = plan_bands_cd(H.Ur, H.Us, false, band_opt); });
       }
     } else {
       H.Up = plan_bands_cd(H.Ur, H.Us, false, band_opt);
@@ -137,19 +156,29 @@ void analyze_level(HostLevel<T> &H, const BandOptions &band_opt, bool dump = fal
         return plan_bands_cd(A, S, lower, band_opt, nullptr, true);
       return plan_bands(A, S, lower, band_opt);
     };
-    H.Lp = plan_one(H.Lr, H.Ls, true);
-    H.Up = plan_one(H.Ur, H.Us, false);
+    par2([&] { H.Lp = plan_one(H.Lr, H.Ls, true); }, [&] { H.Up = plan_one(H.Ur, H.Us, false); });
   }
   double t2 = now();
-  H.Lr = permute_rows(H.Lr, H.Lp.order);
-  H.Ur = permute_rows(H.Ur, H.Up.order);
-  finish_band_plan(H.Lp, H.Lr, band_opt);
-  finish_band_plan(H.Up, H.Ur, band_opt);
+  // (the two triangles of a level are planned, permuted and cut independently: one host thread each)
+  par2(
+      [&] {
+        H.Lr = permute_rows(H.Lr, H.Lp.order);
+        finish_band_plan(H.Lp, H.Lr, band_opt);
+      },
+      [&] {
+        H.Ur = permute_rows(H.Ur, H.Up.order);
+        finish_band_plan(H.Up, H.Ur, band_opt);
+      });
   double t3 = now();
-  H.Ltinv_elems = plan_dense_blocks<T>(H.Lp, band_opt);
-  H.Utinv_elems = plan_dense_blocks<T>(H.Up, band_opt);
-  build_cd_streams(H.Lp, H.Lr.ptr);
-  build_cd_streams(H.Up, H.Ur.ptr);
+  par2(
+      [&] {
+        H.Ltinv_elems = plan_dense_blocks<T>(H.Lp, band_opt);
+        build_cd_streams(H.Lp, H.Lr.ptr);
+      },
+      [&] {
+        H.Utinv_elems = plan_dense_blocks<T>(H.Up, band_opt);
+        build_cd_streams(H.Up, H.Ur.ptr);
+      });
   if (!dump) return;
   std::fprintf(stderr, "ANALYZE m=%ld: schedule %.2f s, band plan %.2f s, permute+finish %.2f s, block cutting %.2f s\n",
                (long)H.m, t1 - t0, t2 - t1, t3 - t2, now() - t3);
