@@ -259,10 +259,25 @@ def main():
         dev_ms = M.time_apply(B, X, warmup=1, reps=max(5, steps // 2))
         balg = M.algorithmic_bytes(args.nrhs)
         stage_bytes = M.stage_bytes(args.nrhs)
+        # which level / stage each launch of the apply belongs to, and B_alg level by level (tests/prof_summarize.py
+        # attributes the kernel trace with them); set-up cost and resident explicit operators
+        launch_map = [16 * l + s_ for (l, s_) in M.launch_map()]
+        level_bytes = {str(l): {str(k): v for k, v in d_.items()} for l, d_ in M.level_bytes(args.nrhs).items()}
+        setup = M.stats_ext()
         # BASELINE configs[1]: the same hierarchy with ONE right-hand side (latency-bound; reported, not the metric)
         b1 = B[:, :1].contiguous()
         x1 = torch.empty_like(b1)
         nrhs1_ms = M.time_apply(b1, x1, warmup=1, reps=5) if (world == 1 and args.extras) else None
+        # narrow batches run the component bands in 16-column slices (k_band_cs) and the operator products on the column
+        # tiles they have: 8 columns = what each of 8 RHS-sharded GPUs gets of one 64-column batch; 16 = BASELINE configs[4]
+        narrow = None
+        if world == 1 and args.extras:
+            narrow = {}
+            for k in (8, 16, 32):
+                bk = B[:, :k].contiguous()
+                xk = torch.empty_like(bk)
+                narrow[str(k)] = M.time_apply(bk, xk, warmup=1, reps=5)
+                del bk, xk
         st = M.stats()
         # one end-of-batch gather of the solution blocks (not in the per-step data path)
         gather_ms = None
@@ -335,6 +350,7 @@ def main():
                          "first_tile_equals_64_column_result": bool(torch.equal(X2[:, :args.nrhs], X))}
             del B2, X2
         res = dict(ms_per_step=1e3 * el / steps, value=world * args.nrhs * steps / el, dev_ms=dev_ms, balg=balg, stage_bytes=stage_bytes, nrhs1_ms=nrhs1_ms, pipelined=pipelined,
+                   launch_map=launch_map, level_bytes=level_bytes, setup=setup, narrow=narrow,
                    stats=st, cpu=cpu, gather_ms=gather_ms, parity=parity, levels=levels, strong=strong, exact=exact)
         M.close()
         del B, X
@@ -388,13 +404,21 @@ def main():
                        "nnz_LU": int(st["nnz_LU"]), "nnz_EF": int(st["nnz_EF"]),
                        "wavefronts_L": int(st["wavefronts_L"]), "wavefronts_U": int(st["wavefronts_U"]),
                        "launches_per_apply": int(st["launches"]) if st["launches"] else None,
-                       "parallelism": f"rhs-sharded x{world} (hierarchy replicated)"},
+                       "parallelism": f"rhs-sharded x{world} (hierarchy replicated)",
+                       # set-up cost (once per hierarchy) and what stays resident beside the factors
+                       "finalize_s": r["setup"].get("finalize_s"), "graph_capture_ms": r["setup"].get("graph_capture_ms"),
+                       "operator_bytes": {"block_inverses": r["setup"].get("bytes_inverses"), "top_operators": r["setup"].get("bytes_top"),
+                                          "tail_operator": r["setup"].get("bytes_tail")},
+                       "tail_operator": {"rows": r["setup"].get("tail_rows"), "level": r["setup"].get("tail_level"),
+                                         "probe_relerr": r["setup"].get("tail_probe_relerr"),
+                                         "max_abs": r["setup"].get("tail_max_abs"), "rejected": r["setup"].get("tail_rejected")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_note": traffic_note,
-                         "kernel": "one whole batched apply (hipGraph of k_band_cd/k_strip_gemm4_d/k_trsv_wide/k_spmm_tile(4)/k_spmm_epi/k_dense_gemm_d/k_scatter_scale(_list); S1, S5 (level 0) and S7 fused into the component bands)",
+                         "kernel": "one whole batched apply (hipGraph of k_band_cd/k_top_gemm/k_top_reduce/k_trsv_wide/k_spmm_tile(4)/k_spmm_epi/k_scatter_scale_list; S1, S5 (level 0) and S7 fused into the component bands)",
                          "algorithmic_bytes": r["balg"], "apply_ms_hip_events": r["dev_ms"],
-                         "algorithmic_bytes_by_stage": r["stage_bytes"], "stages_from_profile": stages},
+                         "algorithmic_bytes_by_stage": r["stage_bytes"], "algorithmic_bytes_by_level": r["level_bytes"],
+                         "launch_map": r["launch_map"], "levels_from_profile": stages},
             "cpu_baseline": cpu if world == 1 else None,  # timed on rank 0 at N = 1 only
             "parity_relerr_col0_vs_oracle": r["parity"],
         }
@@ -409,6 +433,8 @@ def main():
         if r["nrhs1_ms"] is not None:
             line["nrhs1"] = {"config": "same hierarchy, nrhs=1 (BASELINE configs[1])", "ms_per_apply": r["nrhs1_ms"],
                              "applies_per_s": 1e3 / r["nrhs1_ms"]}
+        if r["narrow"] is not None:
+            line["narrow_batches_ms"] = r["narrow"]
         if world == 1 and args.secondary:
             other = "tuned" if args.params == "default" else "default"
             r2 = run(other, True, max(5, args.steps // 2), 2)

@@ -35,6 +35,8 @@ SIGNATURES = {
     "hifamd_schur_rank": (_i64, [_vp]),
     "hifamd_stats": (_int, [_vp, _vp]),
     "hifamd_stats_ext": (_int, [_vp, _vp, _int]),
+    "hifamd_level_stats": (_int, [_vp, _int, _vp, _int]),
+    "hifamd_launch_map": (_int, [_vp, _vp, _int]),
     "hifamd_level_schedule": (_int, [_vp, _int, _int, _vp, _vp, _vp]),
     "hifamd_solve": (_int, [_vp, _vp, _vp, _i64]),
     "hifamd_solve_batch": (_int, [_vp, _vp, _i64, _vp, _i64, _i64, _i64]),

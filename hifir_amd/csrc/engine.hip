@@ -321,6 +321,7 @@ struct GraphEntry {
   void **slots = nullptr;  // device: {B base, X base}, rewritten (stream-ordered) before every replay
   int64_t launches = 0;
   uint64_t stamp = 0;
+  std::vector<int32_t> map;  // per launch: 16 * level + stage (Engine::launch_map)
 };
 
 class EngineBase {
@@ -363,6 +364,13 @@ class Engine : public EngineBase {
   uint64_t io_next = 0;
   uint64_t clock = 0;
   int64_t last_launches = 0;
+  // which level and stage every launch of the apply being enqueued belongs to (16 * level + stage; stages: 1 S1 gather,
+  // 2 first LDU solve incl. the fused S1, 3 S3 product with E, 4 dense block / tail operator, 5 S5 product with F,
+  // 6 second LDU solve incl. the fused S5 / S7, 7 S7 scatter); last_map: of the apply launched last (hifamd_launch_map)
+  std::vector<int32_t> cur_map, last_map;
+  void mark(size_t level, int stage, int64_t c0, int64_t c1) {
+    for (int64_t c = c0; c < c1; ++c) cur_map.push_back((int32_t)(16 * level + stage));
+  }
   bool use_graph = true;
   int min_logR = 6;
   int gemm_waves = 16;   // split-K width of the block-inverse GEMM
@@ -1518,25 +1526,33 @@ class Engine : public EngineBase {
     const bool fuse_s1 = fuse_gather && logR == 6 && band_pipe && m > 0;
     const FL fl{bin, ldb, nrhs, L.p.as<int32_t>(), L.s.as<double>()};
     const bool fuse_f_lv = fuse_s1 && L.L.f_fused;  // S5 fused as well (level with thin F rows, all-component L plan)
+    int64_t c0 = count;
     if (m && !fuse_s1) {  // S1  :359
       hipLaunchKernelGGL((k_gather_scale<D>), dim3(grid_for(m, logR)), dim3(256), 0, st, bin, ldb, nrhs,
                          L.p.as<int32_t>(), L.s.as<double>(), m, w, logR);
       ++count;
     }
+    mark(l, 1, c0, count);
     if (nm) {
+      c0 = count;
       launch_ldu(st, L, logR, count, fuse_s1 ? &fl : nullptr);  // S2  :364
+      mark(l, 2, c0, count);
       // S3  :366-368  -> w[m:n] (becomes the child's rhs, :386)
+      c0 = count;
       launch_spmm(st, L.E, nm, v, bin, ldb, nrhs, L, m, w + m * R, logR);
       ++count;
-      if (last)
+      mark(l, 3, c0, count);
+      c0 = count;
+      if (last) {
         launch_dense(st, w + m * R, v + m * R, logR, rank, count);  // :371-381
-      else if ((int64_t)l + 1 == tail_level && logR == 6 && (!host.has_dense || eff_rank(rank) == dn.rank) &&  // (the rank it was built with)
-               launch_tail(st, w + m * R, v + m * R, count)) {
-        // (levels l+1 ... and the dense block as one product)
-      }
-      else
+        mark(l, 4, c0, count);
+      } else if ((int64_t)l + 1 == tail_level && logR == 6 && (!host.has_dense || eff_rank(rank) == dn.rank) &&  // (the rank it was built with)
+                 launch_tail(st, w + m * R, v + m * R, count)) {
+        mark(l + 1, 4, c0, count);  // (levels l+1 ... and the dense block as one product)
+      } else
         enqueue_level(st, l + 1, in_direct(w + m * R), R, out_direct(v + m * R), R, (int)R, logR, rank, count);  // :383-388
       // S5  :392-403   (v[m:n] already is "work[m:n] = y[m:n]")
+      c0 = count;
       if (m) {
         if (L.F_ncols && fuse_f_lv) {
           // fused into the first touch of the L solve below: rhs = s b[p] - sum F v[m + k] (FirstL + the F streams)
@@ -1549,14 +1565,18 @@ class Engine : public EngineBase {
           ++count;
         }
       }
+      mark(l, 5, c0, count);
     }
     // S6  :406  (its right-hand side is w = s b[p] - F y from S5, or -- no F, or no Schur complement at all -- S1 again)
     // S7 (:411) fused into the last band of this U solve where the plan allows (kernels LastU; finalize built the list of
     // output rows that band does not write)
     const bool fuse_s7 = fuse_out && logR == 6 && m > 0 && L.s7_n >= 0;
     const LU lu{yout, ldy, nrhs, L.q_s7.as<int32_t>(), L.t.as<double>()};
+    c0 = count;
     launch_ldu(st, L, logR, count, (fuse_s1 && (!(nm && L.F_ncols) || fuse_f_lv)) ? &fl : nullptr, fuse_f_lv && nm && L.F_ncols,
                fuse_s7 ? &lu : nullptr);
+    mark(l, 6, c0, count);
+    c0 = count;
     if (fuse_s7) {
       if (L.s7_n > 0) {
         hipLaunchKernelGGL((k_scatter_scale_list<D>), dim3(grid_for(L.s7_n, logR)), dim3(256), 0, st, v, L.qinv.as<int32_t>(),
@@ -1568,6 +1588,7 @@ class Engine : public EngineBase {
                          L.t.as<double>(), n, yout, ldy, nrhs, logR);
       ++count;
     }
+    mark(l, 7, c0, count);
   }
 
   // ---- y = M b: prec_prod (alg/prec_prod.hpp:55-147), the inverse direction of the apply ------------
@@ -1707,6 +1728,7 @@ class Engine : public EngineBase {
   int64_t enqueue_apply(hipStream_t st, const D *dB, int64_t ldb, D *dX, int64_t ldx, int64_t nrhs, int64_t rank,
                         int kind = 0, D *const *slots = nullptr, int tfirst = 0, int tstride = 1) {
     int64_t count = 0;
+    cur_map.clear();
     for (int64_t c0 = 64 * (int64_t)tfirst; c0 < nrhs; c0 += 64 * (int64_t)tstride) {
       const int64_t nc = std::min<int64_t>(64, nrhs - c0);
       const int logR = pick_logR(nc);
@@ -1791,6 +1813,7 @@ class Engine : public EngineBase {
                    int tfirst, int tstride) {
     if (!use_graph) {
       last_launches = enqueue_apply(st, dB, ldb, dX, ldx, nrhs, rank, kind, nullptr, tfirst, tstride);
+      last_map = cur_map;
       return;
     }
     GraphKey key{ldb, ldx, nrhs, host.has_dense ? eff_rank(rank) : 0, kind, tfirst, tstride};
@@ -1812,6 +1835,7 @@ class Engine : public EngineBase {
       HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
       try {
         ge.launches = enqueue_apply(stream, dB, ldb, dX, ldx, nrhs, rank, kind, (D *const *)ge.slots, tfirst, tstride);
+        ge.map = cur_map;
       } catch (...) {
         hipGraph_t g = nullptr;
         (void)hipStreamEndCapture(stream, &g);
@@ -1826,6 +1850,7 @@ class Engine : public EngineBase {
     }
     it->second.stamp = ++clock;
     last_launches = it->second.launches;
+    last_map = it->second.map;
     // hand this call's pointers to the graph: a stream-ordered 16-byte copy from a pinned ring slot
     if (!io_ring) HIP_OK(hipHostMalloc((void **)&io_ring, kIoRing * 2 * sizeof(void *), hipHostMallocDefault));
     if (io_next && io_next % kIoRing == 0) HIP_OK(hipStreamSynchronize(st));  // never overtake a pending slot
@@ -2293,6 +2318,19 @@ class Engine : public EngineBase {
     o[13] = finalize_seconds;
     o[14] = bytes_inverses + bytes_top + bytes_tail;
     o[15] = capture_ms;
+  }
+  int launch_map(int32_t *o, int cap) const {
+    for (int i = 0; i < cap && i < (int)last_map.size(); ++i) o[i] = last_map[(size_t)i];
+    return (int)last_map.size();
+  }
+  int level_stats(int level, double *o, int cap) const {
+    if (level < 0 || level >= (int)host.levels.size()) return -1;
+    const auto &H = host.levels[(size_t)level];
+    const double v[] = {(double)H.m, (double)H.n, (double)H.L.nnz(), (double)H.U.nnz(), (double)H.E.nnz(), (double)H.F.nnz(),
+                        (double)H.Ls.nwf(), (double)H.Us.nwf(), (double)H.Lp.nbands(), (double)H.Up.nbands(), (double)H.top_n};
+    const int nv = (int)(sizeof(v) / sizeof(v[0]));
+    for (int i = 0; i < cap && i < nv; ++i) o[i] = v[i];
+    return nv;
   }
   // set-up / operator accounting beyond the 16 slots of hifamd_stats (hifir_amd.h hifamd_stats_ext)
   int stats_ext(double *o, int cap) const {
@@ -2811,6 +2849,14 @@ int64_t hifamd_nnz(HifAmdHdl h) { QUERY(ENG_D->nnz_total(), ENG_Z->nnz_total()) 
 int64_t hifamd_schur_size(HifAmdHdl h) { QUERY(q_schur_size(ENG_D), q_schur_size(ENG_Z)) }
 int64_t hifamd_schur_rank(HifAmdHdl h) { QUERY(q_schur_rank(ENG_D), q_schur_rank(ENG_Z)) }
 
+int hifamd_launch_map(HifAmdHdl h, int32_t *out, int cap) {
+  if (!h || !h->eng || (cap > 0 && !out)) return -1;
+  return h->vt == HIFAMD_D ? ENG_D->launch_map(out, cap) : ENG_Z->launch_map(out, cap);
+}
+int hifamd_level_stats(HifAmdHdl h, int level, double *out, int cap) {
+  if (!h || !h->eng || (cap > 0 && !out)) return -1;
+  return h->vt == HIFAMD_D ? ENG_D->level_stats(level, out, cap) : ENG_Z->level_stats(level, out, cap);
+}
 int hifamd_stats_ext(HifAmdHdl h, double *out, int cap) {
   if (!h || !h->eng || (cap > 0 && !out)) return -1;
   return h->vt == HIFAMD_D ? ENG_D->stats_ext(out, cap) : ENG_Z->stats_ext(out, cap);

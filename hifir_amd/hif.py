@@ -202,6 +202,48 @@ class HIF:
                 "tail_probe_relerr", "tail_max_abs", "tail_rejected", "tail_probe_tol", "tail_max_growth"]
         return {key: float(s[i]) for i, key in enumerate(keys[:max(0, k)])}
 
+    def level_stats(self, level):
+        s = np.zeros(16)
+        k = lib().hifamd_level_stats(self._h, int(level), _p(s), 16)
+        if k < 0:
+            raise HifAmdError(2, "no such level")
+        keys = ["m", "n", "nnz_L", "nnz_U", "nnz_E", "nnz_F", "wavefronts_L", "wavefronts_U", "bands_L", "bands_U", "top_rows"]
+        return {key: float(s[i]) for i, key in enumerate(keys[:k])}
+
+    def launch_map(self):
+        """(level, stage) of every kernel launch of the last batched apply, in launch order (hifamd_launch_map)."""
+        k = lib().hifamd_launch_map(self._h, None, 0)
+        o = np.zeros(max(k, 1), dtype=np.int32)
+        lib().hifamd_launch_map(self._h, _p(o), int(k))
+        return [(int(v) // 16, int(v) % 16) for v in o[:k]]
+
+    def level_bytes(self, nrhs):
+        """B_alg(nrhs) of SURVEY 8(d) level by level and stage by stage: {level: {stage: bytes}} with the stage codes of
+        launch_map(); the dense block's bytes sit at stage 4 of the level that owns it."""
+        sv = np.dtype(self.dtype).itemsize
+        si, sp, ss = 4, 8, 8
+        st = self.stats()
+        out = {}
+        nlev = int(st["sparse_levels"])
+        for l in range(nlev):
+            q = self.level_stats(l)
+            m, n = q["m"], q["n"]
+            nm = n - m
+            ldu = 2 * m * sv * nrhs + (q["nnz_L"] + q["nnz_U"]) * (sv + si) + m * sv + 2 * (m + 1) * sp  # one LDU solve
+            out[l] = {
+                1: 2 * n * sv * nrhs + n * (si + ss),  # S1: read + write n rows, p and s
+                2: ldu,
+                3: (m + 2 * nm) * sv * nrhs + q["nnz_E"] * (sv + si) + (nm + 1) * sp,
+                4: (st["dense_n"] ** 2 * sv) if l == nlev - 1 else 0.0,
+                5: (nm + 2 * m) * sv * nrhs + q["nnz_F"] * (sv + si) + (m + 1) * sp,
+                6: ldu,
+                7: 2 * n * sv * nrhs + n * (si + ss),  # S7: read + write n rows, q_inv and t
+            }
+        tot = sum(sum(v.values()) for v in out.values())
+        ref = self.algorithmic_bytes(nrhs)
+        assert abs(tot - ref) <= 1e-6 * ref, (tot, ref)
+        return out
+
     def algorithmic_bytes(self, nrhs):
         """B_alg(nrhs) = B_mat + nrhs * B_vec of SURVEY 8(d), for the hierarchy actually resident."""
         st = self.stats()

@@ -137,6 +137,15 @@ HifAmdStatus hifamd_stats(HifAmdHdl h, double *stats16);
  * was rejected (0 not, 1 not finite, 2 growth, 3 probe, 4 an error while it was formed), 10 / 11 the probe and growth
  * limits in force (HIFIR_AMD_TAIL_PROBE_TOL, HIFIR_AMD_TAIL_GROWTH).  -1 for a NULL handle. */
 int hifamd_stats_ext(HifAmdHdl h, double *out, int cap);
+/* Per-level sizes (what the SURVEY 8(d) byte formula needs level by level): 0 m, 1 n, 2 nnz(L_B), 3 nnz(U_B), 4 nnz(E),
+ * 5 nnz(F), 6 / 7 wavefronts of L / U, 8 / 9 launches ("bands") of the L / U plan, 10 rows of the combined top operator.
+ * Returns the number of values it knows (-1: NULL handle or no such level). */
+int hifamd_level_stats(HifAmdHdl h, int level, double *out, int cap);
+/* Which level and stage every kernel launch of the LAST batched apply belongs to, in launch order (for attributing a
+ * kernel trace): out[i] = 16 * level + stage, stage 1 S1 gather, 2 first LDU solve (with the fused S1), 3 S3 product with
+ * E, 4 dense block / tail operator, 5 S5 product with F, 6 second LDU solve (with the fused S5 / S7), 7 S7 scatter
+ * (prec_solve.hpp:359-411).  Returns the number of launches; writes min(cap, that). */
+int hifamd_launch_map(HifAmdHdl h, int32_t *out, int cap);
 /* level schedule of one triangular factor (host-side analysis; usable without a GPU):
  * which = 0 (L_B) / 1 (U_B).  *nwf = number of wavefronts; if order != NULL it receives the m row
  * ids in processing order and wf_ptr (nwf+1 entries) the wavefront boundaries into it. */

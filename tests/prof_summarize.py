@@ -112,52 +112,71 @@ if kt and os.path.exists(bj):
     agree.update(stamp())
     json.dump(agree, open(dst + "_apply_time_agreement.json", "w"), indent=1)
     print(json.dumps(agree))
-    # per-stage rooflines of the primary workload: kernel time per apply (same segmentation) against the
-    # stage group's share of B_alg (bench.py "algorithmic_bytes_by_stage", SURVEY 8(d) terms)
-    sb = line["roofline"].get("algorithmic_bytes_by_stage")
-    if sb:
-        # (k_strip_gemm_d is the combined top operator of a level's triangular solves)
-        group = {"k_gather_scale": "permute", "k_scatter_scale": "permute", "k_spmm_epi": "schur", "k_spmm_tile": "schur", "k_trsv_band": "ldu",
-                 "k_band_cd": "ldu", "k_trsv_wide": "ldu", "k_thin_update": "ldu", "k_tri_gemm_d": "ldu",
-                 "k_strip_gemm": "ldu", "k_dense_gemm": "dense", "k_row_gather": "dense"}
-        tms = {g: 0.0 for g in sb}
-        per_kernel = {}
+    # Per-LEVEL rooflines of the primary workload: every launch of an apply is attributed to its level and stage with
+    # the library's own launch map (hifamd_launch_map, carried in the bench line) and set against the SURVEY 8(d) bytes
+    # of exactly those stages (bench.py "algorithmic_bytes_by_level").  S1 runs inside the first LDU solve of a level
+    # and S7 / S5 inside (or right behind) the second one, so stages are grouped by the kernels that really move their
+    # bytes: in = S1 + first LDU, E = the S3 product, F+out = S5 + second LDU + S7; the tail operator (one product for
+    # every level from `tail` on, dense block included) carries ALL bytes of those levels.  No group can exceed the
+    # roofline by construction (bytes and time come from the same launches); a fraction > 1 is refused below.
+    lmap = line["roofline"].get("launch_map")
+    lbytes = line["roofline"].get("algorithmic_bytes_by_level")
+    if lmap and lbytes and len(lmap) == L_:
+        nlev = len(lbytes)
+        grp_of = {1: "in+LDU", 2: "in+LDU", 3: "E", 4: "dense/tail", 5: "F+LDU+out", 6: "F+LDU+out", 7: "F+LDU+out"}
+        to_ = line["config"].get("tail_operator") or {}
+        tail_level = int(to_["level"]) if to_.get("rows") and to_.get("level", -1) >= 0 else nlev
+        tms, cnt_l, per_kernel = {}, {}, {}
         napp = 0
         for (a_, b_) in bounds:
-            if b_ - a_ + 1 != cnts[0]:
-                continue
             napp += 1
-            for q in rows[a_:b_ + 1]:
+            for j, q in enumerate(rows[a_:b_ + 1]):
                 d_ = (int(q["End_Timestamp"]) - int(q["Start_Timestamp"])) / 1e6
-                for k_, g_ in group.items():
-                    if k_ in q["Kernel_Name"]:
-                        tms[g_] += d_
-                        e = per_kernel.setdefault(k_, [0, 0.0])
-                        e[0] += 1
-                        e[1] += d_
-                        break
-        if "k_gather_scale" not in per_kernel and tms["permute"] and tms["ldu"]:
-            # S1 is fused into the first L kernel (FirstL): its bytes are served inside "ldu" time, so the two groups
-            # are only meaningful together
-            both = sb["permute"] + sb["ldu"]
-            tboth = (tms["permute"] + tms["ldu"]) / napp
-            fused_note = {"algorithmic_bytes": both, "ms_per_apply": tboth, "achieved_GBs": both / (tboth * 1e-3) / 1e9,
-                          "frac_of_8TBs": both / (tboth * 1e-3) / 8e12,
-                          "note": "S1 (half of the permute bytes) runs inside the first L kernel of each level and S7 inside "
-                                  "the last U band (only the rows of the other bands and of the child keep a scatter "
-                                  "kernel); level 0's S5 product runs inside the second L solve: 'permute' alone overstates "
-                                  "its rate, 'ldu' alone understates it"}
-        else:
-            fused_note = None
-        stages = {g: {"algorithmic_bytes": sb[g], "ms_per_apply": tms[g] / napp,
-                      "achieved_GBs": sb[g] / (tms[g] / napp * 1e-3) / 1e9 if tms[g] else None,
-                      "frac_of_8TBs": sb[g] / (tms[g] / napp * 1e-3) / 8e12 if tms[g] else None} for g in sb}
-        stages["kernels"] = {k_: {"launches_per_apply": v[0] / napp, "ms_per_apply": v[1] / napp} for k_, v in per_kernel.items()}
-        if fused_note:
-            stages["permute+ldu"] = fused_note
+                lv, stg = lmap[j] // 16, lmap[j] % 16
+                key = (lv, grp_of.get(stg, "other"))
+                tms[key] = tms.get(key, 0.0) + d_
+                cnt_l[key] = cnt_l.get(key, 0) + 1
+                kn = q["Kernel_Name"].split("(")[0].replace("void hifamd::", "").replace("hifamd::", "").split("<")[0]
+                e = per_kernel.setdefault(kn, [0, 0.0])
+                e[0] += 1
+                e[1] += d_
+        table, tot_ms, tot_b = [], 0.0, 0.0
+        for lv in range(nlev):
+            lb = {int(k): v for k, v in lbytes[str(lv)].items()}
+            if lv > tail_level:
+                continue  # (inside the tail operator)
+            if lv == tail_level:
+                bts = {"dense/tail": sum(sum(float(v) for v in lbytes[str(q)].values()) for q in range(lv, nlev))}
+            else:
+                bts = {"in+LDU": lb[1] + lb[2], "E": lb[3], "dense/tail": lb[4], "F+LDU+out": lb[5] + lb[6] + lb[7]}
+            row = {"level": lv, "groups": {}}
+            lms, lby = 0.0, 0.0
+            for g_, by_ in bts.items():
+                ms_ = tms.get((lv, g_), 0.0) / napp
+                if by_ == 0 and ms_ == 0:
+                    continue
+                gbs = by_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else None
+                if gbs is not None and gbs / 8000.0 > 1.0:
+                    raise SystemExit(f"level {lv} group {g_}: {gbs:.0f} GB/s exceeds the roofline -- bytes and launches do not match")
+                row["groups"][g_] = {"launches": cnt_l.get((lv, g_), 0) / napp, "ms": ms_, "algorithmic_bytes": by_, "GBs": gbs,
+                                     "frac_of_8TBs": gbs / 8000.0 if gbs else None}
+                lms += ms_
+                lby += by_
+            row.update({"ms": lms, "algorithmic_bytes": lby, "GBs": lby / (lms * 1e-3) / 1e9 if lms else None,
+                        "frac_of_8TBs": lby / (lms * 1e-3) / 8e12 if lms else None})
+            if lv == tail_level:
+                row["note"] = f"levels {lv}..{nlev - 1} and the dense block as ONE operator product"
+            table.append(row)
+            tot_ms += lms
+            tot_b += lby
+        stages = {"per_level": table, "total": {"ms": tot_ms, "algorithmic_bytes": tot_b, "GBs": tot_b / (tot_ms * 1e-3) / 1e9,
+                                                 "frac_of_8TBs": tot_b / (tot_ms * 1e-3) / 8e12},
+                  "kernels": {k_: {"launches_per_apply": v[0] / napp, "ms_per_apply": v[1] / napp} for k_, v in per_kernel.items()}}
         stages.update(stamp())
         json.dump(stages, open(dst + "_stage_roofline.json", "w"), indent=1)
-        print(json.dumps(stages))
+        for r_ in table:
+            print("level %d: %.3f ms  %.2f GB  %.0f GB/s (%.1f %%)" % (r_["level"], r_["ms"], r_["algorithmic_bytes"] / 1e9, r_["GBs"] or 0,
+                                                                       100 * (r_["frac_of_8TBs"] or 0)), {g: round(v["ms"], 3) for g, v in r_["groups"].items()})
 
 out = {}
 f, w = one("pmc_fetch/*/*counter_collection.csv"), one("pmc_write/*/*counter_collection.csv")
