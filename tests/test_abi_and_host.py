@@ -297,3 +297,39 @@ def test_import_path_under_sanitizers(tmp_path, san):
     r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0, r.stderr[-4000:]
     assert r.stderr.count("-> ok") == 2 * len(files)
+
+
+def test_integration_doc_matches_headers():
+    """INTEGRATION.md names real entry points with their real signatures: the additive prototypes quoted in section 3 are
+    the ones of include/libhifir_amd_ext.h, token for token, and every `lhf...` / `hifamd_...` name the document mentions
+    is declared by the reference's libhifir.h (tests/golden/libhifir_symbols.txt), the extension header or
+    include/hifir_amd.h (round 2's document had drifted: argument order of lhfSetDevices, three names that do not exist)."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    ext = open(os.path.join(root, "include", "libhifir_amd_ext.h")).read()
+    amd = open(os.path.join(root, "include", "hifir_amd.h")).read()
+    norm = lambda t: re.sub(r"\s+", " ", t).strip()
+    proto_re = r"^(?:LhfStatus|int|Lhf[dz]HifHdl)\s+lhf\w+\([^;]*\);"
+    hdr_protos = [norm(p) for p in re.findall(proto_re, ext, flags=re.M)]
+    assert len(hdr_protos) == 14
+    blocks = re.findall(r"```c\n(.*?)```", doc, flags=re.S)
+    doc_protos = [norm(p) for b in blocks for p in re.findall(proto_re, b, flags=re.M)]
+    assert doc_protos == hdr_protos  # same prototypes, same order, same argument lists
+    ref_syms = set(open(os.path.join(root, "tests", "golden", "libhifir_symbols.txt")).read().split())
+    ext_syms = set(re.findall(r"\b(lhf\w+)\s*\(", ext))
+    amd_syms = set(re.findall(r"\b(hifamd_\w+)\s*\(", amd))
+    known = ref_syms | ext_syms
+    # names written with a type placeholder (lhf?Apply, lhf{d,z}Create, `lhf{d,s,z,c}CreateMatrix / DestroyMatrix / ...`)
+    # are expanded; plain names must exist as they stand
+    for name in set(re.findall(r"\blhf[A-Za-z]+\b", doc)):
+        assert name in known or any(name == s for s in known), name
+    for fam, rest in re.findall(r"lhf(?:\?|\{([a-z,]+)\})([A-Z][A-Za-z]+)", doc):
+        letters = fam.split(",") if fam else ["d", "z"]
+        for t in letters:
+            assert f"lhf{t}{rest}" in known, f"lhf{t}{rest}"
+    for name in set(re.findall(r"\bhifamd_[a-z_0-9]+\b", doc)):
+        if name.endswith("_"):
+            continue  # (a prefix such as hifamd_set_dense*)
+        assert name in amd_syms or any(s.startswith(name) for s in amd_syms), name
