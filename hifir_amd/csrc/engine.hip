@@ -402,6 +402,7 @@ class Engine : public EngineBase {
   // into 16-column slices (the heaviest component of a narrow band then runs on four compute units); a batch of fewer
   // than 49 columns runs EVERY component band sliced and launches only the slices it has.  HIFIR_AMD_CS=0: off.
   int cs_mode = 1;
+  int narrow_spmm = 1;   // HIFIR_AMD_NARROW_SPMM=0: batches of <= 32 columns keep the 64-lane Schur product kernel
   int cs_sparse = 0;     // HIFIR_AMD_CS_SPARSE=1: sparse-own bands (level 0) in column slices at full width too
   int cs_max_wgs = 0;    // HIFIR_AMD_CS_MAX_WGS (full batches: measured equal to k_band_cd at every band width)
   int act_cols = 64;     // columns of the 64-column arena that the tile being enqueued actually uses (enqueue_apply)
@@ -457,6 +458,7 @@ class Engine : public EngineBase {
     cs_mode = env_int("HIFIR_AMD_CS", 1);
     cs_max_wgs = env_int("HIFIR_AMD_CS_MAX_WGS", 0);
     cs_sparse = env_int("HIFIR_AMD_CS_SPARSE", 0);
+    narrow_spmm = env_int("HIFIR_AMD_NARROW_SPMM", 1);
     top_gemm = env_int("HIFIR_AMD_TOP_GEMM", 4);
     fuse_f = env_int("HIFIR_AMD_FUSE_F", 1) != 0;
     carry_wgs = std::max(1, env_int("HIFIR_AMD_CARRY_WGS", 256));
@@ -601,6 +603,7 @@ class Engine : public EngineBase {
       E->cs_mode = cs_mode;
       E->cs_max_wgs = cs_max_wgs;
       E->cs_sparse = cs_sparse;
+      E->narrow_spmm = narrow_spmm;
       for (const auto &P : host.levels) E->add_level_adjoint(P);
       if (host.has_dense && host.dense.kind == 2) {  // LUP: ?getrs 'T' / ?gemv 'C' (LUP.hpp:150,187)
         E->host.dense.kind = 2;
@@ -659,6 +662,7 @@ class Engine : public EngineBase {
       E->cs_mode = cs_mode;
       E->cs_max_wgs = cs_max_wgs;
       E->cs_sparse = cs_sparse;
+      E->narrow_spmm = narrow_spmm;
       E->max_nrhs = max_nrhs;
       E->Rmax = Rmax;
       E->host.has_dense = host.has_dense;
@@ -1509,6 +1513,13 @@ class Engine : public EngineBase {
                            L.s.as<double>(), roff, out);
         return;
       }
+    }
+    // a narrow batch in the 64-column arena: 64 / R rows per wave (R = 16 or 32 lanes per row)
+    if (logR == 6 && narrow_spmm && act_cols <= 32) {
+      const int lr = act_cols <= 16 ? 4 : 5;
+      hipLaunchKernelGGL((k_spmm_epi_narrow<D>), dim3(grid_for(nrows, lr)), dim3(256), 0, st, nrows, A.ptr.as<int32_t>(),
+                         A.col.as<int32_t>(), A.val.as<D>(), x, bin, ldb, nrhs, L.p.as<int32_t>(), L.s.as<double>(), roff, out, lr);
+      return;
     }
     hipLaunchKernelGGL((k_spmm_epi<D>), dim3(grid_for(nrows, logR)), dim3(256), 0, st, nrows, A.ptr.as<int32_t>(),
                        A.col.as<int32_t>(), A.val.as<D>(), x, bin, ldb, nrhs, L.p.as<int32_t>(), L.s.as<double>(), roff, out,

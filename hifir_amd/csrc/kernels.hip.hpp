@@ -1087,6 +1087,45 @@ __global__ void __launch_bounds__(256) k_spmm_epi(int64_t nrows, const int32_t *
 }
 
 // ---------------------------------------------------------------------------------------------
+// S3 / S5 for a NARROW batch in the 64-column arena (round 3): k_spmm_epi at R = 64 spends a whole wave -- and a 512-byte
+// (complex: 1 KB) gather -- on every nonzero, whatever the batch width.  Here a wave is G = 64 / R row groups of R lanes
+// (R = 16 or 32 >= nrhs): G rows side by side, each lane group walking ITS row's nonzeros in the reference's order
+// (column and value are fetched per lane; the R lanes of a group read the same address), eight gathers of R columns in
+// flight.  Arena rows stay 64 columns apart.  Same arithmetic as k_spmm_epi: a column's bits do not depend on the width.
+// ---------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256) k_spmm_epi_narrow(int64_t nrows, const int32_t *__restrict__ ptr,
+                                                         const int32_t *__restrict__ col, const T *__restrict__ val,
+                                                         const T *__restrict__ x, IoPtr<const T> bin_, int64_t ldb, int nrhs,
+                                                         const int32_t *__restrict__ p, const double *__restrict__ s,
+                                                         int64_t roff, T *__restrict__ out, int logR) {
+  const T *__restrict__ bin = bin_.get();
+  const LaneMap lm = lane_map(logR);
+  const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = wave * lm.G + lm.g; i < nrows; i += nwaves * lm.G) {
+    const int32_t k0 = ptr[i], k1 = ptr[i + 1];
+    T acc = vzero(T());
+    int32_t k = k0;
+    for (; k + 8 <= k1; k += 8) {
+      int32_t j_[8];
+      T a_[8], x_[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) j_[u] = col[k + u], a_[u] = val[k + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x_[u] = x[((int64_t)j_[u] << 6) + lm.c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = vadd(acc, vmul(x_[u], a_[u]));
+    }
+    for (; k < k1; ++k) acc = vadd(acc, vmul(x[((int64_t)col[k] << 6) + lm.c], val[k]));
+    const int32_t src = p[roff + i];
+    T rhs = vzero(T());
+    if (lm.c < nrhs) rhs = vscale(s[src], bin[(int64_t)src * ldb + lm.c]);
+    out[(i << 6) + lm.c] = vsub(rhs, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // S3 / S5 on the matrix cores (host.hpp SpmmTiles): out[i] = s[p[roff+i]] * b[p[roff+i]] - sum_j A(i,j) x[j] with the
 // rows in blocks of 16 and each block's distinct columns in groups of 4.  One wave per block: per group ONE coalesced
 // load of the 16 x 4 coefficient tile (A operand), the 4 source rows gathered as the B operands of the four
