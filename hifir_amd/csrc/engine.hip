@@ -1435,6 +1435,16 @@ class Engine : public EngineBase {
     } else {
       (void)ps0, (void)ps1, (void)with_f, (void)lu;
       if (extra || M.cd_sparse) throw Error(HIFAMD_HIFIR_ERROR, "internal error: carried prefix / sparse-own component band on a complex handle");
+      const int nslz = std::min(4, (act_cols + 15) / 16);
+      if (cs_mode && nslz < 4 && (int64_t)(g1 - g0) * nslz < (1LL << 30)) {  // a narrow batch: only the slices it has
+        const int32_t rows = (int32_t)((band_opt.cd_rows + 31) & ~(int64_t)31);
+        const size_t ldsz = (size_t)rows * (2 * 16 + 2) * sizeof(double) + (size_t)rows * 2 * sizeof(int32_t) + 16;
+        hipLaunchKernelGGL(k_band_cs_z<LOWER>, dim3((unsigned)((g1 - g0) * nslz)), dim3(256), ldsz, st, g0, M.wg_grp_ptr.as<int32_t>(),
+                           M.cd_desc.as<int32_t>(), M.rowid.as<int32_t>(), L.d.as<cplx>(), L.w.as<cplx>(), L.v.as<cplx>(),
+                           M.tinv.as<double>(), M.mid_col.as<int32_t>(), M.mid_val.as<cplx>(), M.mid_lrow.as<uint8_t>(), pre ? 0 : 1,
+                           (int32_t)nslz, rows, fl);
+        return;
+      }
       hipLaunchKernelGGL(k_band_cd_z<LOWER>, dim3((unsigned)(g1 - g0)), dim3(1024), cd_lds_bytes_z(), st, g0, M.wg_grp_ptr.as<int32_t>(),
                          M.cd_desc.as<int32_t>(), M.rowid.as<int32_t>(), L.d.as<cplx>(), L.w.as<cplx>(), L.v.as<cplx>(),
                          M.tinv.as<double>(), M.mid_col.as<int32_t>(), M.mid_val.as<cplx>(), M.mid_lrow.as<uint8_t>(), pre ? 0 : 1,

@@ -2888,6 +2888,203 @@ __global__ void __launch_bounds__(256) k_band_cs(int32_t wg0, const int32_t *__r
 }
 
 // ---------------------------------------------------------------------------------------------
+// Column-sliced component band for COMPLEX data (round 3): k_band_cd_z for ONE slice of 16 complex columns per
+// workgroup (blockIdx.x = component-workgroup * nsl + slice), the complex twin of k_band_cs.  A batch of at most 48
+// columns launches only the slices it has: BASELINE config 5 (nrhs = 16) moves a quarter of the vector bytes and
+// issues a quarter of the gathers of the 64-column kernel.  4 waves; lane group q = 4 wave + g (16 lanes = 16 complex
+// columns) takes chunk q of the descriptor: its rows' right-hand sides go into two real LDS planes [rows][16], its
+// entries are fetched 16 at a time per lane group and broadcast with DPP row_newbcast, four 256-byte gathers per lane
+// group in flight; the inverse product is four real MFMA streams per 16-row strip (x_re = P_re t_re - P_im t_im,
+// x_im = P_re t_im + P_im t_re), strips dealt heaviest first in snake order.  Per row and column the arithmetic and
+// its order are k_band_cd_z's: the same bits.  No carried prefixes, no sparse-own variant (complex plans have neither).
+// ---------------------------------------------------------------------------------------------
+template <bool LOWER>
+__global__ void __launch_bounds__(256) k_band_cs_z(int32_t wg0, const int32_t *__restrict__ wg_grp_ptr,
+                                                   const int32_t *__restrict__ cd_desc, const int32_t *__restrict__ rowid,
+                                                   const cplx *__restrict__ d, cplx *w, cplx *v,
+                                                   const double *__restrict__ tinv, const int32_t *__restrict__ mid_col,
+                                                   const cplx *__restrict__ mid_val, const uint8_t *__restrict__ mid_lrow,
+                                                   int first_u, int32_t nsl, int32_t lds_rows, FirstL<cplx> fl) {
+  extern __shared__ double cs_buf[];
+  double *t_re = cs_buf, *t_im = cs_buf + (size_t)lds_rows * 16;
+  double *s_hdx = t_im + (size_t)lds_rows * 16, *s_hdy = s_hdx + lds_rows;
+  int32_t *s_rowid = reinterpret_cast<int32_t *>(s_hdy + lds_rows);
+  int32_t *s_hp = s_rowid + lds_rows;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int32_t bw = (int32_t)blockIdx.x / nsl, slice = (int32_t)blockIdx.x - bw * nsl;
+  const int grp = lane >> 4, l16 = lane & 15, gq = wave * 4 + grp;
+  const int cc = slice * 16 + l16;
+  cplx *x = LOWER ? w : v;
+  const bool div_u = !LOWER && first_u;
+  const bool first_l = LOWER && first_u && fl.on();
+  const cplx *rhs = div_u ? (const cplx *)w : (first_l ? fl.bin.get() : (const cplx *)x);
+  const int64_t rstride = first_l ? fl.ldb : 64;
+  const int rcol = first_l ? min(cc, fl.nrhs - 1) : cc;
+  const int32_t c_first = wg_grp_ptr[wg0 + bw], c_last = wg_grp_ptr[wg0 + bw + 1];
+  const int kq = grp;
+  for (int32_t c = c_first; c < c_last; ++c) {
+    const int32_t *dsc = cd_desc + (int64_t)c * 28;
+    const int32_t s0 = dsc[0], nb = dsc[1], mid0 = dsc[2];
+    const int64_t inv_off = ((int64_t)(uint32_t)dsc[5] << 32) | (uint32_t)dsc[4];
+    const uint8_t *wrow = reinterpret_cast<const uint8_t *>(dsc + 6);
+    const uint16_t *wmid = reinterpret_cast<const uint16_t *>(dsc + 11);
+    const int r0 = wrow[gq], nr = (int)wrow[gq + 1] - r0;
+    const int32_t e0 = mid0 + (int32_t)wmid[gq], ne = (int32_t)wmid[gq + 1] - (int32_t)wmid[gq];
+    const int lda = (nb + 31) & ~31;
+    // ---- phase 0: row ids and per-row scalars
+    for (int32_t t = (int32_t)threadIdx.x; t < nb; t += 256) {
+      const int32_t i = rowid[s0 + t];
+      s_rowid[t] = i;
+      if (div_u) {
+        const cplx dd = d[i];
+        s_hdx[t] = dd.x, s_hdy[t] = dd.y;
+      }
+      if (first_l) {
+        const int32_t pp = fl.p[i];
+        s_hp[t] = pp;
+        s_hdx[t] = fl.s[pp];
+      }
+    }
+    int32_t colv = 0, lrv = 0;
+    cplx valv = cplx{0.0, 0.0};
+    if (l16 < ne) {
+      colv = mid_col[e0 + l16];
+      valv = mid_val[e0 + l16];
+      lrv = mid_lrow[e0 + l16];
+    }
+    __syncthreads();
+    // ---- phase 1a: right-hand sides of this lane group's rows into the two LDS planes, four rows in flight
+    const int nrmax = wave_max4(nr);
+    for (int j = 0; j < nrmax; j += 4) {
+      cplx t_[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = r0 + min(j + q, max(nr - 1, 0));
+        const int32_t i = first_l ? s_hp[r] : s_rowid[r];
+        t_[q] = (j + q < nr) ? rhs[(int64_t)i * rstride + rcol] : cplx{0.0, 0.0};
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (j + q < nr) {
+          const int r = r0 + j + q;
+          cplx val = t_[q];
+          if (div_u)
+            val = vdiv(val, cplx{s_hdx[r], s_hdy[r]});
+          else if (first_l)
+            val = cc < fl.nrhs ? vscale(s_hdx[r], val) : cplx{0.0, 0.0};
+          t_re[(r << 4) + l16] = val.x;
+          t_im[(r << 4) + l16] = val.y;
+        }
+    }
+    // ---- phase 1b: this lane group's entries, items of 16, four gathers per batch
+    int cur = -1;
+    cplx acc = cplx{0.0, 0.0};
+    const int32_t nemax = wave_max4(ne);
+    for (int32_t base = 0; base < nemax; base += 16) {
+      int32_t colv2 = 0, lrv2 = 0;
+      cplx valv2 = cplx{0.0, 0.0};
+      if (base + 16 + l16 < ne) {
+        colv2 = mid_col[e0 + base + 16 + l16];
+        valv2 = mid_val[e0 + base + 16 + l16];
+        lrv2 = mid_lrow[e0 + base + 16 + l16];
+      }
+      const int32_t left = ne - base;
+      static_for<0, 4>([&](auto ib) {
+        constexpr int T0 = 4 * decltype(ib)::value;
+        if (T0 < nemax - base) {
+          int32_t j_[4], r_[4];
+          cplx a_[4], xv_[4];
+          static_for<0, 4>([&](auto iu) {
+            constexpr int u = decltype(iu)::value;
+            j_[u] = bc16<T0 + u>(colv);
+            a_[u] = cplx{bc16<T0 + u>(valv.x), bc16<T0 + u>(valv.y)};
+            r_[u] = bc16<T0 + u>(lrv);
+          });
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (T0 + u < left) xv_[u] = x[((int64_t)j_[u] << 6) + cc];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (T0 + u < left) {
+              if (r_[u] != cur) {
+                if (cur >= 0) {
+                  t_re[(cur << 4) + l16] = acc.x;
+                  t_im[(cur << 4) + l16] = acc.y;
+                }
+                cur = r_[u];
+                acc = cplx{t_re[(cur << 4) + l16], t_im[(cur << 4) + l16]};
+              }
+              acc = vsub(acc, vmul(a_[u], xv_[u]));
+            }
+        }
+      });
+      colv = colv2;
+      valv = valv2;
+      lrv = lrv2;
+    }
+    if (cur >= 0) {
+      t_re[(cur << 4) + l16] = acc.x;
+      t_im[(cur << 4) + l16] = acc.y;
+    }
+    // (rows nb .. lda - 1 are zero for the inverse product; lds_rows is a multiple of 32)
+    for (int t = nb * 16 + (int)threadIdx.x; t < lda * 16; t += 256) t_re[t] = 0.0, t_im[t] = 0.0;
+    __syncthreads();
+    // ---- phase 2: x = Tinv * t on the real matrix cores, four products per strip
+    const int S = (nb + 15) >> 4;
+    const double *Are = tinv + inv_off, *Aim = Are + ((int64_t)((nb + 15) & ~15) * lda);  // plane_elems(nb, lda)
+    for (int rnd = 0; 4 * rnd < S; ++rnd) {
+      const int q = 4 * rnd + ((rnd & 1) ? 3 - wave : wave);
+      if (q >= S) continue;
+      const int strip = S - 1 - q;
+      const int kend = min(nb, 16 * (strip + 1));
+      const int nk = (kend + 3) >> 2;  // k-steps of four columns
+      const double *Apr = Are + ((int64_t)strip * lda) * 16 + l16 + (int64_t)kq * 16;
+      const double *Api = Aim + ((int64_t)strip * lda) * 16 + l16 + (int64_t)kq * 16;
+      const double *Bre = t_re + l16, *Bim = t_im + l16;
+      v4f64 a_rr = v4f64{0.0, 0.0, 0.0, 0.0}, a_ii = a_rr, a_ri = a_rr, a_ir = a_rr;
+      constexpr int KU = 4;
+      double pr0[KU], pi0[KU], pr1[KU], pi1[KU];
+#define HIFAMD_CSZ_LOAD(pr, pi, t_)                                                       \
+  _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                        \
+    pr[u] = Apr[(int64_t)(KU * (t_) + u) * 64];                                           \
+    pi[u] = Api[(int64_t)(KU * (t_) + u) * 64];                                           \
+  }
+#define HIFAMD_CSZ_MFMA(pr, pi, t_)                                                       \
+  _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                        \
+    const int kb_ = 4 * (KU * (t_) + u) + kq;                                             \
+    const double br_ = Bre[kb_ << 4], bi_ = Bim[kb_ << 4];                                \
+    a_rr = __builtin_amdgcn_mfma_f64_16x16x4f64(pr[u], br_, a_rr, 0, 0, 0);               \
+    a_ii = __builtin_amdgcn_mfma_f64_16x16x4f64(pi[u], bi_, a_ii, 0, 0, 0);               \
+    a_ri = __builtin_amdgcn_mfma_f64_16x16x4f64(pr[u], bi_, a_ri, 0, 0, 0);               \
+    a_ir = __builtin_amdgcn_mfma_f64_16x16x4f64(pi[u], br_, a_ir, 0, 0, 0);               \
+  }
+      // (sets of KU = 4 k-steps = 16 columns: the operand planes and the LDS rows are zero padded up to lda, a multiple
+      //  of 32, so a set never leaves the strip; k-steps past nk add exact zeros)
+      const int nsets = (nk + KU - 1) / KU;
+      int t = 0;
+      HIFAMD_CSZ_LOAD(pr0, pi0, 0)
+      while (t < nsets) {
+        if (t + 1 < nsets) HIFAMD_CSZ_LOAD(pr1, pi1, t + 1)
+        HIFAMD_CSZ_MFMA(pr0, pi0, t)
+        if (t + 1 >= nsets) break;
+        if (t + 2 < nsets) HIFAMD_CSZ_LOAD(pr0, pi0, t + 2)
+        HIFAMD_CSZ_MFMA(pr1, pi1, t + 1)
+        t += 2;
+      }
+#undef HIFAMD_CSZ_LOAD
+#undef HIFAMD_CSZ_MFMA
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * strip + kq + 4 * r;
+        if (row < nb) x[((int64_t)s_rowid[row] << 6) + cc] = cplx{a_rr[r] - a_ii[r], a_ri[r] + a_ir[r]};
+      }
+    }
+    __syncthreads();  // (the next component overwrites the LDS planes)
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Component-dense band for COMPLEX data (gfx950 has no complex MFMA): the same scheme as k_band_cd<LOWER, false> --
 // a dependency component per workgroup, LDS-resident, x_c = Tinv_c (rhs_c - older-source sums) -- with the component's
 // right-hand sides kept as TWO real planes in LDS (re[rows][64], im[rows][64]) and the explicit inverse as two real
