@@ -63,7 +63,7 @@ def test_solve_single_rhs(cache, name):
 
 
 @pytest.mark.parametrize("name", HIER_NAMES)
-@pytest.mark.parametrize("nrhs", [1, 2, 3, 8, 17, 64, 100])
+@pytest.mark.parametrize("nrhs", [1, 2, 3, 8, 17, 33, 48, 49, 64, 100])
 def test_solve_batch(cache, name, nrhs):
     levels, d, M, O = _get(cache, name)
     n = len(d["b"])
@@ -217,6 +217,28 @@ def test_rotating_buffers_share_one_graph(cache):
     for k in (0, 5, 11):
         Xo = O.solve_batch(Bs[k].cpu().numpy(), threads=4)
         assert relerr(Xs[k].cpu().numpy(), Xo) <= TOL
+
+
+@pytest.mark.parametrize("name", HIER_NAMES)
+def test_column_bits_do_not_depend_on_the_batch_width(cache, name):
+    # Batches of fewer than 49 columns run the component bands in 16-column slices (k_band_cs / k_band_cs_z), the Schur
+    # products with 64 / R rows per wave (k_spmm_epi_narrow) and the operator products on the column tiles they have;
+    # 49 ... 64 columns run the 64-column kernels: every width must produce the SAME bits for a column (the arithmetic
+    # per row and column is the same sequence of operations in every kernel), forwards and conjugate-transposed
+    levels, d, M, O = _get(cache, name)
+    n = int(levels[0]["n"])
+    rng = np.random.default_rng(99)
+    B = rng.uniform(-1, 1, size=(n, 64)).astype(d["b"].dtype)
+    if np.iscomplexobj(d["b"]):
+        B = B + 1j * rng.uniform(-1, 1, size=(n, 64))
+    for tr in (False, True):
+        X = M.solve_mrhs(B, trans=tr)
+        for k in (1, 5, 16, 17, 32, 33, 48, 49):
+            Xk = M.solve_mrhs(np.ascontiguousarray(B[:, :k]), trans=tr)
+            assert np.array_equal(Xk, X[:, :k]), (tr, k, relerr(Xk, X[:, :k]))
+        # ... and columns in the middle of the batch, as a shard of an RHS-sharded job sees them
+        Xm = M.solve_mrhs(np.ascontiguousarray(B[:, 40:48]), trans=tr)
+        assert np.array_equal(Xm, X[:, 40:48])
 
 
 @pytest.mark.parametrize("name", ["cd2d_48", "young1c"])
