@@ -153,6 +153,7 @@ struct DevCsr {
   DevBuf f_desc, f_col, f_val, f_lrow;  // L only: the streams with the level's F entries appended (host.hpp build_cd_streams_fused)
   bool f_fused = false;
   bool cd_sparse = false;
+  std::vector<int32_t> band_chunk_max;  // component bands: most entries of one wave chunk of the band (the serial walk of its slowest wave)
   int32_t own_cap = kCdOwnCap;  // sparse-own plans: most own nonzeros of one component, rounded up to 64 (sizes the kernels' LDS)
   std::vector<int32_t> band_wg_ptr, band_slot_ptr, host_wg_grp_ptr;
   std::vector<uint8_t> band_prefix, band_dense, band_fused, band_cd, band_old;
@@ -178,6 +179,7 @@ struct DevCsr {
     wg_slot.alias(o.wg_slot);
     csplit.alias(o.csplit);
     own_cap = o.own_cap;
+    band_chunk_max = o.band_chunk_max;
     grp_inv_off.alias(o.grp_inv_off);
     cd_desc.alias(o.cd_desc);
     mid_col.alias(o.mid_col);
@@ -241,6 +243,14 @@ struct DevCsr {
         mid_val.upload(mv, 80);
         mid_lrow.upload(P->mid_lrow, 80);
         cd_sparse = P->cd_sparse;
+        band_chunk_max.assign(P->band_wg_ptr.size() - 1, 0);
+        for (size_t b = 0; b + 1 < P->band_wg_ptr.size(); ++b) {
+          if (P->band_cd.empty() || !P->band_cd[b] || P->cd_desc.empty()) continue;
+          for (int32_t c = P->wg_grp_ptr[(size_t)P->band_wg_ptr[b]]; c < P->wg_grp_ptr[(size_t)P->band_wg_ptr[b + 1]]; ++c) {
+            const uint16_t *wm = reinterpret_cast<const uint16_t *>(&P->cd_desc[(size_t)c * kCdDescWords + 11]);
+            for (int q = 0; q < 16; ++q) band_chunk_max[b] = std::max<int32_t>(band_chunk_max[b], (int32_t)wm[q + 1] - (int32_t)wm[q]);
+          }
+        }
         if (cd_sparse) {
           int32_t mx = 0;
           for (size_t c = 0; c * kCdDescWords < P->cd_desc.size(); ++c) mx = std::max(mx, P->cd_desc[c * kCdDescWords + 21]);
@@ -402,6 +412,12 @@ class Engine : public EngineBase {
   // into 16-column slices (the heaviest component of a narrow band then runs on four compute units); a batch of fewer
   // than 49 columns runs EVERY component band sliced and launches only the slices it has.  HIFIR_AMD_CS=0: off.
   int cs_mode = 1;
+  // Two launches for a component band whose slowest wave would walk many entries: the entries of ALL its rows that refer
+  // to rows outside their component go to a chip-wide prefix pass (every wave of the chip takes rows, perfectly balanced),
+  // and the band kernel is left with right-hand sides -> inverse product -> stores.  One launch more (~ 8 us) against the
+  // serial walk of the band's longest chunk at ~ 120 ns per entry.  HIFIR_AMD_CD_SPLIT_MIN: entries of the
+  // longest chunk from which a band is split (0 = never); HIFIR_AMD_CD_SPLIT_WGS: only bands of at most this many components
+  int cd_split_min = 0, cd_split_wgs = 600;
   int narrow_spmm = 1;   // HIFIR_AMD_NARROW_SPMM=0: batches of <= 32 columns keep the 64-lane Schur product kernel
   int cs_sparse = 0;     // HIFIR_AMD_CS_SPARSE=1: sparse-own bands (level 0) in column slices at full width too
   int cs_max_wgs = 0;    // HIFIR_AMD_CS_MAX_WGS (full batches: measured equal to k_band_cd at every band width)
@@ -459,6 +475,8 @@ class Engine : public EngineBase {
     cs_max_wgs = env_int("HIFIR_AMD_CS_MAX_WGS", 0);
     cs_sparse = env_int("HIFIR_AMD_CS_SPARSE", 0);
     narrow_spmm = env_int("HIFIR_AMD_NARROW_SPMM", 1);
+    cd_split_min = env_int("HIFIR_AMD_CD_SPLIT_MIN", 0);
+    cd_split_wgs = env_int("HIFIR_AMD_CD_SPLIT_WGS", 600);
     top_gemm = env_int("HIFIR_AMD_TOP_GEMM", 4);
     fuse_f = env_int("HIFIR_AMD_FUSE_F", 1) != 0;
     carry_wgs = std::max(1, env_int("HIFIR_AMD_CARRY_WGS", 256));
@@ -604,6 +622,8 @@ class Engine : public EngineBase {
       E->cs_max_wgs = cs_max_wgs;
       E->cs_sparse = cs_sparse;
       E->narrow_spmm = narrow_spmm;
+      E->cd_split_min = cd_split_min;
+      E->cd_split_wgs = cd_split_wgs;
       for (const auto &P : host.levels) E->add_level_adjoint(P);
       if (host.has_dense && host.dense.kind == 2) {  // LUP: ?getrs 'T' / ?gemv 'C' (LUP.hpp:150,187)
         E->host.dense.kind = 2;
@@ -663,6 +683,8 @@ class Engine : public EngineBase {
       E->cs_max_wgs = cs_max_wgs;
       E->cs_sparse = cs_sparse;
       E->narrow_spmm = narrow_spmm;
+      E->cd_split_min = cd_split_min;
+      E->cd_split_wgs = cd_split_wgs;
       E->max_nrhs = max_nrhs;
       E->Rmax = Rmax;
       E->host.has_dense = host.has_dense;
@@ -1227,13 +1249,26 @@ class Engine : public EngineBase {
       // the kernel that touches a U row first starts it from w[i] / d[i] (the L kernels no longer write v).
       // pre: the band's rows start at split[] and [ptr, split) is folded in by a prefix pass first -- its own launch,
       // unless the previous band's launch carried it
-      const int pre = (M.band_prefix[b] || fused) ? 1 : 0;
+      int pre = (M.band_prefix[b] || fused) ? 1 : 0;
+      // a component band split into a chip-wide prefix pass over ALL outside sources + the band kernel without its walk
+      const bool cd_two = cd_split_min > 0 && logR == 6 && act_cols > 48 && !M.band_cd.empty() && M.band_cd[b] && !M.band_dense[b] &&
+                          !M.cd_sparse && !(LOWER && with_f) && b < M.band_chunk_max.size() && M.band_chunk_max[b] >= cd_split_min &&
+                          g1 - g0 <= cd_split_wgs && sizeof(T) == sizeof(double);
+      if (cd_two) {
+        const int64_t s0 = M.band_slot_ptr[b], s1 = M.band_slot_ptr[b + 1];
+        const bool touched = fused && have_carried;  // [ptr, split) was folded in (first touch included) by the previous launch
+        hipLaunchKernelGGL((k_trsv_wide<D, LOWER, true>), dim3(grid_for(s1 - s0, logR)), dim3(256), 0, st, s0, s1,
+                           (touched ? M.split : M.ptr).template as<int32_t>(), M.csplit.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(),
+                           M.rowid.as<int32_t>(), L.d.as<D>(), w, v, logR, touched ? 0 : 1, (D *)nullptr, 0, touched ? no_fl() : fl);
+        ++count;
+        pre = 1;  // (the band kernel finds its rows touched)
+      }
       // block-dense band at R = 64: the prefix pass delivers the rows of the band's first block straight into the
       // block product's right-hand side (nothing else contributes to them), so that block needs no k_thin_update
       const int32_t qb0 = M.band_dense[b] ? M.band_blk_ptr[b] : -1;
       const bool direct = pre && M.band_dense[b] && logR == 6 && qb0 < M.band_blk_ptr[b + 1] &&
                           M.blk_slot0[(size_t)qb0] == M.band_slot_ptr[b];
-      if (pre && !(fused && have_carried)) {  // (a fused band whose predecessor could not carry it: its own launch)
+      if (pre && !cd_two && !(fused && have_carried)) {  // (a fused band whose predecessor could not carry it: its own launch)
         const int64_t s0 = M.band_slot_ptr[b], s1 = M.band_slot_ptr[b + 1];
         hipLaunchKernelGGL((k_trsv_wide<D, LOWER, true>), dim3(grid_for(s1 - s0, logR)), dim3(256), 0, st, s0, s1,
                            M.ptr.as<int32_t>(), M.split.as<int32_t>(), M.col.as<int32_t>(), M.val.as<D>(),
@@ -1260,7 +1295,7 @@ class Engine : public EngineBase {
         if (cdb) {
           // (the fused S7 -- LastU -- belongs to the LAST band of the final U solve only)
           launch_band_cd<LOWER>(st, L, M, g0, g1, pre, ps0, ps1, extra, fl, LOWER && with_f,
-                                (!LOWER && lup && b + 1 == nb) ? *lup : no_lu(), b);
+                                (!LOWER && lup && b + 1 == nb) ? *lup : no_lu(), b, cd_two);
           ++count;
           continue;
         }
@@ -1399,7 +1434,8 @@ class Engine : public EngineBase {
   }
   template <bool LOWER>
   void launch_band_cd(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t g0, int32_t g1, int pre, int32_t ps0,
-                      int32_t ps1, unsigned extra, const FL &fl, bool with_f = false, const LU &lu = no_lu(), size_t band = 0) {
+                      int32_t ps1, unsigned extra, const FL &fl, bool with_f = false, const LU &lu = no_lu(), size_t band = 0,
+                      bool no_walk = false) {
     if constexpr (std::is_same<T, double>::value) {
       // LDS: the component's right-hand sides + its row ids (the attribute for > 64 KB is set in bind_device)
       const size_t lds = cd_lds_bytes(M.cd_sparse, M.own_cap);
@@ -1419,7 +1455,7 @@ class Engine : public EngineBase {
                            L.w.as<double>(), L.v.as<double>(), M.tinv.as<double>(), (with_f ? M.f_col : M.mid_col).template as<int32_t>(),
                            (with_f ? M.f_val : M.mid_val).template as<double>(), (with_f ? M.f_lrow : M.mid_lrow).template as<uint8_t>(),
                            pre ? 0 : 1, (int32_t)(g1 - g0), (int32_t)nsl, ps0, ps1, single_c0,
-                           lds_rows, M.own_cap, cd_dbg, fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
+                           lds_rows, M.own_cap, cd_dbg | (no_walk ? 1 : 0), fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
                            M.own_lvl.as<uint8_t>(), lu);
         return;
       }
@@ -1430,7 +1466,7 @@ class Engine : public EngineBase {
                          L.w.as<double>(), L.v.as<double>(), M.tinv.as<double>(), (with_f ? M.f_col : M.mid_col).template as<int32_t>(),
                          (with_f ? M.f_val : M.mid_val).template as<double>(), (with_f ? M.f_lrow : M.mid_lrow).template as<uint8_t>(),
                          pre ? 0 : 1, (int32_t)(g1 - g0), ps0, ps1, single_c0,
-                         lds_rows, M.own_cap, cd_dbg, fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
+                         lds_rows, M.own_cap, cd_dbg | (no_walk ? 1 : 0), fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
                          M.own_lvl.as<uint8_t>(), lu);
     } else {
       (void)ps0, (void)ps1, (void)with_f, (void)lu;
