@@ -506,7 +506,7 @@ class Engine : public EngineBase {
     // no sparse-own components, no combined top (both real-only)
     if (sizeof(T) != sizeof(double) && band_opt.dense_block > 0) band_opt.cd_rows = std::min(144, env_int("HIFIR_AMD_CD_ROWS_Z", 96));
     band_opt.cd_max_nnz = env_int("HIFIR_AMD_CD_NNZ", 4000);  // (a band lasts as long as its heaviest component: 4.53 -> 4.44 ms)
-    band_opt.cd_sparse_rows = std::min(192, env_int("HIFIR_AMD_CD_SPARSE_ROWS", 192));  // 0: thin triangles keep the flag bands
+    band_opt.cd_sparse_rows = std::min(240, env_int("HIFIR_AMD_CD_SPARSE_ROWS", 192));  // 0: thin triangles keep the flag bands
     band_opt.top_max = env_int("HIFIR_AMD_TOP_ROWS", 4096);      // combined top operator (host.hpp choose_top); 0 = off
     band_opt.top_few_wgs = env_int("HIFIR_AMD_TOP_WGS", 96);
     if (sizeof(T) != sizeof(double)) band_opt.top_max = 0, band_opt.cd_sparse_rows = 0, band_opt.cd_max_nnz = env_int("HIFIR_AMD_CD_NNZ_Z", 0);
@@ -524,10 +524,10 @@ class Engine : public EngineBase {
     if (sizeof(T) == sizeof(double) && band_opt.cd_rows > 0) {  // k_band_cd keeps a component in up to 128 KB of LDS
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(false)));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(false)));
-      HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(true)));
-      HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(true)));
-      HIP_OK(hipFuncSetAttribute((const void *)k_band_cs<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_lds_bytes(true)));
-      HIP_OK(hipFuncSetAttribute((const void *)k_band_cs<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cs_lds_bytes(true)));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(cd_lds_bytes(true), 160 * 1024)));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(cd_lds_bytes(true), 160 * 1024)));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cs<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(cs_lds_bytes(true), 160 * 1024)));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cs<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(cs_lds_bytes(true), 160 * 1024)));
     }
     HIP_OK(hipFuncSetAttribute((const void *)k_top_gemm<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTopGemmLds));
     HIP_OK(hipFuncSetAttribute((const void *)k_top_gemm<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTopGemmLds));
@@ -1439,6 +1439,8 @@ class Engine : public EngineBase {
     if constexpr (std::is_same<T, double>::value) {
       // LDS: the component's right-hand sides + its row ids (the attribute for > 64 KB is set in bind_device)
       const size_t lds = cd_lds_bytes(M.cd_sparse, M.own_cap);
+      if (lds > 160 * 1024)  // (only with HIFIR_AMD_CD_SPARSE_ROWS / HIFIR_AMD_CD_ROWS raised beyond their defaults)
+        throw Error(HIFAMD_HIFIR_ERROR, "component band needs more than 160 KB of LDS: lower HIFIR_AMD_CD_SPARSE_ROWS / HIFIR_AMD_CD_ROWS");
       const int32_t lds_rows = cd_lds_rows(M.cd_sparse);
       // one component per workgroup (the usual case): the kernel derives the component from blockIdx
       const int32_t c0 = M.host_wg_grp_ptr[(size_t)g0], c1 = M.host_wg_grp_ptr[(size_t)g1];
