@@ -215,8 +215,16 @@ void analyze_level(HostLevel<T> &H, const BandOptions &band_opt, bool dump = fal
         }
         for (int32_t q = s0; q < s1; ++q) rowmax = std::max(rowmax, P.csplit[(size_t)q] - P.split[(size_t)q]);
       }
-      std::fprintf(stderr, "PLAN2 level=%zu tri=%c band=%ld comp_entries_max=%d chunk_entries_max=%d row_entries_max=%d\n", level_no,
-                   tri ? 'U' : 'L', (long)b, ne_max, ck16, rowmax);
+      int64_t runs = 0, span_sum = 0;  // address locality of the band's rows: runs of consecutive row ids, id span per component
+      for (int32_t q = s0; q < s1; ++q) runs += (q == s0 || A.rowid[(size_t)q] != A.rowid[(size_t)q - 1] + 1);
+      for (int32_t c = P.wg_grp_ptr[(size_t)g0]; c < P.wg_grp_ptr[(size_t)g1]; ++c) {
+        int32_t lo = std::numeric_limits<int32_t>::max(), hi = -1;
+        for (int32_t q = P.grp_slot_ptr[(size_t)c]; q < P.grp_slot_ptr[(size_t)c + 1]; ++q)
+          lo = std::min(lo, A.rowid[(size_t)q]), hi = std::max(hi, A.rowid[(size_t)q]);
+        if (hi >= lo) span_sum += hi - lo + 1;
+      }
+      std::fprintf(stderr, "PLAN2 level=%zu tri=%c band=%ld comp_entries_max=%d chunk_entries_max=%d row_entries_max=%d id_runs=%ld id_span_sum=%ld\n", level_no,
+                   tri ? 'U' : 'L', (long)b, ne_max, ck16, rowmax, (long)runs, (long)span_sum);
       int64_t own = 0, prevb = 0;  // nonzeros inside the rows' own component / gathered by the band kernel itself
       for (int32_t q = s0; q < s1; ++q) {
         own += A.ptr[(size_t)q + 1] - P.csplit[(size_t)q];
