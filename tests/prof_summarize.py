@@ -28,6 +28,16 @@ def stamp():
         dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "hifir_amd/csrc", "include"], text=True).strip())
     except Exception:
         head, dirty = None, None
+    # what the profiled run itself recorded (tests/run_profiles.sh) wins over the tree's state at summarizing time
+    ran = os.path.join(src, "lib.sha256")
+    if os.path.exists(ran):
+        ran_sha = open(ran).read().strip()
+        if ran_sha != sha:
+            dirty = None  # (the tree moved on: its state says nothing about the build that ran)
+        sha = ran_sha
+        gh = os.path.join(src, "git_head")
+        if os.path.exists(gh) and open(gh).read().strip():
+            head = open(gh).read().strip()
     return {"lib_sha256": sha, "git_head": head, "csrc_dirty": dirty}
 
 

@@ -9,6 +9,9 @@ TAG=${1:-r02}
 R=$PWD
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
+# (what ran: the summaries are stamped with THIS, not with whatever library lies in the tree when they are made)
+sha256sum hifir_amd/libhifir_amd.so | cut -d" " -f1 > $OUT/lib.sha256
+cat .git_head > $OUT/git_head 2>/dev/null || true
 python bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 $R/bench.py \
