@@ -21,6 +21,7 @@ SIGNATURES = {
     "hifamd_add_level": (_int, [_vp, _i64, _i64] + [_vp] * 9 + [_i64] + [_vp] * 10),
     "hifamd_set_nsp_const": (_int, [_vp, _int, _i64, _i64]),
     "hifamd_save": (_int, [_vp, C.c_char_p]),
+    "hifamd_save_ex": (_int, [_vp, C.c_char_p, _int]),
     "hifamd_load": (_int, [C.c_char_p, _int, C.POINTER(_vp)]),
     "hifamd_set_dense": (_int, [_vp, _i64, _vp, _dbl]),
     "hifamd_set_dense_symm": (_int, [_vp, _i64, _vp, _int]),

@@ -586,9 +586,19 @@ class Engine : public EngineBase {
     const int64_t parent_nm = host.levels.empty() ? -1 : host.levels.back().n - host.levels.back().m;
     HostLevel<T> H = import_level<T>(parent_nm, m, n, Lcp, Lri, Lv, Ucp, Uri, Uv, Ecp, Eri, Ev, F_ncols, Fcp, Fri, Fv, d, s,
                                      t, p, p_inv, q, q_inv);
-    analyze_level(H, band_opt, env_int("HIFIR_AMD_PLAN_DUMP", 0) != 0, host.levels.size());
+    // (hifamd_load of a file that carries the analysis of its levels -- import.hpp load_analysis: adopted, not redone)
+    const size_t li = host.levels.size();
+    const auto t_an0 = std::chrono::steady_clock::now();
+    if (li < cached_analysis.size() && adopt_analysis(H, cached_analysis[li], band_opt))
+      ++levels_from_cache;
+    else
+      analyze_level(H, band_opt, env_int("HIFIR_AMD_PLAN_DUMP", 0) != 0, li);
+    analysis_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_an0).count();
     host.levels.push_back(std::move(H));
   }
+  std::vector<LevelAnalysis<T>> cached_analysis;  // (alive during hifamd_load only)
+  int64_t levels_from_cache = 0;
+  double analysis_seconds = 0.0;  // host seconds spent analyzing (or adopting the analysis of) the levels
 
   // the adjoint of one imported level (see `adj` above)
   void add_level_adjoint(const HostLevel<T> &P) {
@@ -2285,11 +2295,21 @@ class Engine : public EngineBase {
   }
 
   // ---- on-disk form of the imported hierarchy (import.hpp save_hierarchy / load_hierarchy) -----------------
-  void save(std::FILE *f) const {
+  void save(std::FILE *f, int flags = 0) const {
     if (adjoint || is_twin) throw Error(HIFAMD_HIFIR_ERROR, "internal engines are not saved");
     save_hierarchy(f, host);
+    if (flags & HIFAMD_SAVE_ANALYSIS) save_analysis(f, host, band_opt);
   }
-  void load(std::FILE *f) { load_hierarchy<T>(f, *this); }
+  void load(std::FILE *f) {
+    if (env_int("HIFIR_AMD_LOAD_ANALYSIS", 1)) load_analysis<T>(f, band_opt, cached_analysis);
+    try {
+      load_hierarchy<T>(f, *this);
+    } catch (...) {
+      std::vector<LevelAnalysis<T>>().swap(cached_analysis);
+      throw;
+    }
+    std::vector<LevelAnalysis<T>>().swap(cached_analysis);
+  }
 
   // development aid: one checksum per device-resident array (order documented in tests), to tell which
   // upload differs when two handles built from the same hierarchy disagree
@@ -2394,7 +2414,8 @@ class Engine : public EngineBase {
   // set-up / operator accounting beyond the 16 slots of hifamd_stats (hifir_amd.h hifamd_stats_ext)
   int stats_ext(double *o, int cap) const {
     const double v[] = {finalize_seconds, capture_ms,     bytes_inverses,  bytes_top,     bytes_tail,           (double)tail_n,
-                        (double)tail_level, tail_probe_err, tail_max_abs, (double)tail_rejected, tail_probe_tol, tail_max_growth};
+                        (double)tail_level, tail_probe_err, tail_max_abs, (double)tail_rejected, tail_probe_tol, tail_max_growth,
+                        (double)levels_from_cache, analysis_seconds};
     const int nv = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < cap && i < nv; ++i) o[i] = v[i];
     return nv;
@@ -2808,15 +2829,18 @@ int hifamd_debug_checksums(HifAmdHdl h, uint64_t *out, int cap) {
 
 static const char kFileMagic[8] = {'H', 'I', 'F', 'A', 'M', 'D', '1', 0};
 
-HifAmdStatus hifamd_save(HifAmdHdl h, const char *path) {
+HifAmdStatus hifamd_save(HifAmdHdl h, const char *path) { return hifamd_save_ex(h, path, 0); }
+
+HifAmdStatus hifamd_save_ex(HifAmdHdl h, const char *path, int flags) {
   API_BEGIN
   if (!path) throw Error(HIFAMD_NULL_OBJ, "NULL path");
+  if (flags & ~HIFAMD_SAVE_ANALYSIS) throw Error(HIFAMD_BAD_PREC, "unknown hifamd_save_ex flag");
   std::FILE *f = std::fopen(path, "wb");
   if (!f) throw Error(HIFAMD_HIFIR_ERROR, std::string("cannot open for writing: ") + path);
   try {
     const int64_t vt = h->vt;
     if (std::fwrite(kFileMagic, 8, 1, f) != 1 || std::fwrite(&vt, 8, 1, f) != 1) throw Error(HIFAMD_HIFIR_ERROR, "short write");
-    DISPATCH(ENG_D->save(f), ENG_Z->save(f))
+    DISPATCH(ENG_D->save(f, flags), ENG_Z->save(f, flags))
   } catch (...) {
     std::fclose(f);
     throw;

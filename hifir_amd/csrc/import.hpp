@@ -537,4 +537,350 @@ void load_hierarchy(std::FILE *f, Sink &sink) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Optional trailer of a hierarchy file: the ANALYSIS of every level (hifamd_save_ex, flag HIFAMD_SAVE_ANALYSIS) -- the
+// wavefront schedules, the band plans and the slot-ordered triangles that analyze_level derives (on a 256^3 grid: 24 s
+// of the 45 s a rank spends between hifamd_load and its first apply).  A process that loads such a file with the SAME
+// planner options skips that work: ranks other than the one that factorized, restarts.  What is cheap and deterministic
+// (block cutting, component streams: plan_dense_blocks / build_cd_streams) is recomputed, not stored.
+// Layout, behind the records of save_hierarchy:  "HIFAMDA1", sizeof(T), planner options (doubles), per level a block of
+// scalars and vectors, "HIFAMDAF", offset of the trailer, FNV-1a 64 of its bytes.  A loader that does not know the
+// trailer never reads it; one that does verifies magic, checksum and options (load_analysis), then level by level every
+// size and index range against the factors it has just imported (adopt_analysis: the slot-ordered triangles are REBUILT
+// from the imported ones through the stored origins, so the trailer carries no matrix value and fits any factors of the
+// same sparsity pattern), and falls back to analyze_level when anything is off -- a damaged trailer costs time; with a
+// valid checksum and edited plan arrays it can give wrong numbers, but no index out of range reaches a kernel;
+// check_level_invariants at finalize applies to cached plans as to computed ones.
+// ---------------------------------------------------------------------------------------------
+struct HashIo {
+  std::FILE *f;
+  uint64_t h = 1469598103934665603ull;
+  bool ok = true;
+  unsigned char pend[8];
+  size_t npend = 0;
+  // FNV-1a over 8-byte words of the byte STREAM (independent of how the stream is cut into calls; the arrays are
+  // gigabytes on the grids this exists for, hence words); value(): the bytes of an unfinished word are mixed one by one
+  void mix(const void *p, size_t n) {
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    size_t i = 0;
+    if (npend) {
+      while (npend < 8 && i < n) pend[npend++] = b[i++];
+      if (npend < 8) return;
+      uint64_t w;
+      std::memcpy(&w, pend, 8);
+      h = (h ^ w) * 1099511628211ull;
+      npend = 0;
+    }
+    for (; i + 8 <= n; i += 8) {
+      uint64_t w;
+      std::memcpy(&w, b + i, 8);
+      h = (h ^ w) * 1099511628211ull;
+    }
+    while (i < n) pend[npend++] = b[i++];
+  }
+  uint64_t value() const {
+    uint64_t r = h;
+    for (size_t i = 0; i < npend; ++i) r = (r ^ pend[i]) * 1099511628211ull;
+    return r;
+  }
+  void wr(const void *p, size_t n) {
+    if (n && std::fwrite(p, 1, n, f) != n) throw Error(kHifirError, "short write");
+    mix(p, n);
+  }
+  bool rd(void *p, size_t n) {
+    if (n && std::fread(p, 1, n, f) != n) return ok = false;
+    mix(p, n);
+    return true;
+  }
+};
+template <class V>
+void tput(HashIo &io, const std::vector<V> &v) {
+  const int64_t cnt = (int64_t)v.size();
+  io.wr(&cnt, 8);
+  io.wr(v.data(), (size_t)cnt * sizeof(V));
+  const char zeros[8] = {0};
+  io.wr(zeros, (8 - ((size_t)cnt * sizeof(V)) % 8) % 8);
+}
+template <class V>
+bool tget(HashIo &io, std::vector<V> &v, int64_t bytes_left) {
+  int64_t cnt = 0;
+  if (!io.rd(&cnt, 8) || cnt < 0 || (uint64_t)cnt > (uint64_t)bytes_left / sizeof(V)) return io.ok = false;
+  v.resize((size_t)cnt);
+  char skip[8];
+  return io.rd(v.data(), (size_t)cnt * sizeof(V)) && io.rd(skip, (8 - ((size_t)cnt * sizeof(V)) % 8) % 8);
+}
+// every planner option that shapes a plan, as doubles (a trailer made under other options is ignored)
+inline std::vector<double> band_option_words(const BandOptions &o, size_t sizeof_t) {
+  return {1.0 /* trailer version */, (double)sizeof_t, (double)kCdDescWords, (double)kCdOwnCap, (double)o.thin_rows, (double)o.band_depth,
+          (double)o.max_comp_weight, (double)o.max_wg_rows, (double)o.max_wgs, (double)o.dense_block, (double)o.fuse,
+          (double)o.fuse_reorder, (double)o.fuse_max_wgs, (double)o.dense_min_rows, (double)o.cd_rows, o.cd_min_row_nnz,
+          (double)o.cd_fuse_max_wgs, (double)o.cd_max_nnz, (double)o.cd_sparse_max_depth, (double)o.cd_sparse_rows,
+          (double)o.top_max, (double)o.top_few_wgs, o.dense_max_growth};
+}
+static const char kAnaMagic[8] = {'H', 'I', 'F', 'A', 'M', 'D', 'A', '1'};
+static const char kAnaFoot[8] = {'H', 'I', 'F', 'A', 'M', 'D', 'A', 'F'};
+
+// what analyze_level derives and the trailer carries.  The slot-ordered triangles travel as ORIGINS: entry k of the
+// slot-ordered row form is entry origin[k] of the row form as imported (ccs_to_csr) -- no matrix value is stored twice,
+// and an adopted triangle is by construction the imported one with its rows permuted and reordered inside
+template <class T>
+struct LevelAnalysis {
+  int64_t m = 0, nzL = 0, nzU = 0;
+  std::vector<int32_t> originL, originU;
+  Schedule Ls, Us;
+  BandPlan Lp, Up;  // (core arrays only: block cutting and component streams are rebuilt)
+  std::vector<uint8_t> top;
+  int64_t top_n = 0;
+  int32_t top_bandL = -1, top_bandU = -1;
+};
+// Ap: slot-ordered (rowid = slot -> row), A0: the same matrix as imported (rowid = identity)
+template <class T>
+std::vector<int32_t> csr_origin(const Csr<T> &Ap, const Csr<T> &A0) {
+  std::vector<int32_t> origin(Ap.col.size());
+  std::vector<std::pair<int32_t, int32_t>> byc;
+  for (int64_t q = 0; q < Ap.nrows; ++q) {
+    const int32_t i = Ap.rowid[(size_t)q];
+    byc.clear();
+    for (int32_t k = A0.ptr[(size_t)i]; k < A0.ptr[(size_t)i + 1]; ++k) byc.emplace_back(A0.col[(size_t)k], k);
+    std::sort(byc.begin(), byc.end());
+    for (int32_t k = Ap.ptr[(size_t)q]; k < Ap.ptr[(size_t)q + 1]; ++k) {
+      auto it = std::lower_bound(byc.begin(), byc.end(), std::make_pair(Ap.col[(size_t)k], (int32_t)-1));
+      if (it == byc.end() || it->first != Ap.col[(size_t)k]) throw Error(kHifirError, "internal error: slot-ordered triangle differs from the imported one");
+      origin[(size_t)k] = it->second;
+    }
+  }
+  return origin;
+}
+// the inverse: false when order is not a permutation or origin is not, row by row, a bijection onto the imported row
+template <class T>
+bool csr_from_origin(const Csr<T> &A0, const std::vector<int32_t> &order, const std::vector<int32_t> &origin, Csr<T> &out) {
+  const int64_t m = A0.nrows, nz = (int64_t)A0.col.size();
+  if ((int64_t)order.size() != m || (int64_t)origin.size() != nz || !is_permutation(order, m)) return false;
+  out.nrows = m, out.ncols = A0.ncols;
+  out.rowid = order;
+  out.ptr.assign((size_t)m + 1, 0);
+  for (int64_t q = 0; q < m; ++q) {
+    const int32_t i = order[(size_t)q];
+    out.ptr[(size_t)q + 1] = out.ptr[(size_t)q] + (A0.ptr[(size_t)i + 1] - A0.ptr[(size_t)i]);
+  }
+  out.col.resize((size_t)nz), out.val.resize((size_t)nz);
+  std::vector<uint8_t> seen((size_t)nz, 0);
+  for (int64_t q = 0; q < m; ++q) {
+    const int32_t i = order[(size_t)q], a = A0.ptr[(size_t)i], e = A0.ptr[(size_t)i + 1];
+    for (int32_t k = out.ptr[(size_t)q]; k < out.ptr[(size_t)q + 1]; ++k) {
+      const int32_t o = origin[(size_t)k];
+      if (o < a || o >= e || seen[(size_t)o]) return false;
+      seen[(size_t)o] = 1;
+      out.col[(size_t)k] = A0.col[(size_t)o], out.val[(size_t)k] = A0.val[(size_t)o];
+    }
+  }
+  return true;
+}
+inline void tput_plan(HashIo &io, const BandPlan &P) {
+  const int64_t sp = P.cd_sparse ? 1 : 0;
+  io.wr(&sp, 8);
+  tput(io, P.order), tput(io, P.grp_slot_ptr), tput(io, P.wg_grp_ptr), tput(io, P.band_wg_ptr), tput(io, P.band_prefix);
+  tput(io, P.band_fused), tput(io, P.band_dense), tput(io, P.band_cd), tput(io, P.band_old), tput(io, P.srcslot);
+  tput(io, P.split), tput(io, P.csplit);
+}
+inline bool tget_plan(HashIo &io, BandPlan &P, int64_t left) {
+  int64_t sp = 0;
+  if (!io.rd(&sp, 8) || (sp != 0 && sp != 1)) return io.ok = false;
+  P.cd_sparse = sp != 0;
+  return tget(io, P.order, left) && tget(io, P.grp_slot_ptr, left) && tget(io, P.wg_grp_ptr, left) && tget(io, P.band_wg_ptr, left) &&
+         tget(io, P.band_prefix, left) && tget(io, P.band_fused, left) && tget(io, P.band_dense, left) && tget(io, P.band_cd, left) &&
+         tget(io, P.band_old, left) && tget(io, P.srcslot, left) && tget(io, P.split, left) && tget(io, P.csplit, left);
+}
+template <class T>
+void save_analysis(std::FILE *f, const HostHierarchy<T> &host, const BandOptions &opt) {
+  const long at = std::ftell(f);
+  if (at < 0) throw Error(kHifirError, "hierarchy file: tell failed");
+  HashIo io{f};
+  io.wr(kAnaMagic, 8);
+  const std::vector<double> ow = band_option_words(opt, sizeof(T));
+  tput(io, ow);
+  const int64_t nl = (int64_t)host.levels.size();
+  io.wr(&nl, 8);
+  for (const auto &H : host.levels) {
+    const int64_t sc[6] = {H.m, (int64_t)H.Lr.col.size(), (int64_t)H.Ur.col.size(), H.top_n, H.top_bandL, H.top_bandU};
+    io.wr(sc, sizeof(sc));
+    tput(io, csr_origin(H.Lr, ccs_to_csr(H.L, false)));
+    tput(io, csr_origin(H.Ur, ccs_to_csr(H.U, true)));
+    tput(io, H.Ls.order), tput(io, H.Ls.wf_ptr), tput(io, H.Us.order), tput(io, H.Us.wf_ptr);
+    tput_plan(io, H.Lp), tput_plan(io, H.Up);
+    tput(io, H.top);
+  }
+  const int64_t foot[2] = {(int64_t)at, (int64_t)io.value()};
+  if (std::fwrite(kAnaFoot, 8, 1, f) != 1 || std::fwrite(foot, 16, 1, f) != 1) throw Error(kHifirError, "short write");
+}
+
+// index ranges of a cached plan: everything build_cd_streams / plan_dense_blocks and the upload index with
+template <class T>
+bool cached_plan_ok(const BandPlan &P, const Csr<T> &A, int64_t m, int64_t nz, const BandOptions &opt) {
+  if (A.nrows != m || A.ncols != m || (int64_t)A.ptr.size() != m + 1 || (int64_t)A.col.size() != nz || (int64_t)A.val.size() != nz ||
+      (int64_t)A.rowid.size() != m)
+    return false;
+  if (A.ptr[0] != 0 || A.ptr[(size_t)m] != nz) return false;
+  for (int64_t i = 0; i < m; ++i)
+    if (A.ptr[(size_t)i + 1] < A.ptr[(size_t)i]) return false;
+  for (int64_t k = 0; k < nz; ++k)
+    if (A.col[(size_t)k] < 0 || A.col[(size_t)k] >= m) return false;
+  if (!is_permutation(A.rowid, m) || P.order != A.rowid) return false;
+  auto mono = [](const std::vector<int32_t> &v, int64_t last) {
+    if (v.empty() || v[0] != 0 || v.back() != last) return false;
+    for (size_t i = 0; i + 1 < v.size(); ++i)
+      if (v[i + 1] < v[i]) return false;
+    return true;
+  };
+  if (!mono(P.grp_slot_ptr, m) || !mono(P.wg_grp_ptr, (int64_t)P.grp_slot_ptr.size() - 1) ||
+      !mono(P.band_wg_ptr, (int64_t)P.wg_grp_ptr.size() - 1))
+    return false;
+  const size_t nb = P.band_wg_ptr.size() - 1;
+  auto per_band = [&](const std::vector<uint8_t> &v, bool may_be_empty) { return v.size() == nb || (may_be_empty && v.empty()); };
+  if (!per_band(P.band_prefix, false) || !per_band(P.band_dense, false) || !per_band(P.band_fused, true) || !per_band(P.band_cd, true) ||
+      !per_band(P.band_old, true))
+    return false;
+  if ((int64_t)P.split.size() != m || (int64_t)P.srcslot.size() != nz || (!P.csplit.empty() && (int64_t)P.csplit.size() != m)) return false;
+  for (int64_t s = 0; s < m; ++s) {
+    const int32_t a = A.ptr[(size_t)s], e = A.ptr[(size_t)s + 1], sp = P.split[(size_t)s];
+    if (sp < a || sp > e) return false;
+    if (!P.csplit.empty() && (P.csplit[(size_t)s] < sp || P.csplit[(size_t)s] > e)) return false;
+  }
+  {  // a nonzero's source slot IS the slot of its column's row: nothing to choose
+    std::vector<int32_t> slot_of((size_t)m);
+    for (int64_t q = 0; q < m; ++q) slot_of[(size_t)A.rowid[(size_t)q]] = (int32_t)q;
+    for (int64_t k = 0; k < nz; ++k)
+      if (P.srcslot[(size_t)k] != slot_of[(size_t)A.col[(size_t)k]]) return false;
+  }
+  // what plan_dense_blocks will lay out for these flags: schemes the options in force do not have are refused, and so
+  // is a volume of explicit inverses no plan of THIS triangle can have (flags of a damaged trailer must not make the
+  // loader allocate without bound: planned volumes are 13-15 x the nonzeros on the grids measured)
+  double inv_elems = 0.0;
+  for (size_t b = 0; b < nb; ++b) {
+    const bool cd = !P.band_cd.empty() && P.band_cd[b];
+    if (cd) {  // (component streams index rows with a byte)
+      if (P.csplit.empty() || opt.cd_rows <= 0 || opt.dense_block <= 0 || (P.cd_sparse && opt.cd_sparse_rows <= 0)) return false;
+      for (int32_t g = P.band_wg_ptr[b]; g < P.band_wg_ptr[b + 1]; ++g)
+        for (int32_t c = P.wg_grp_ptr[(size_t)g]; c < P.wg_grp_ptr[(size_t)g + 1]; ++c) {
+          const int32_t rows = P.grp_slot_ptr[(size_t)c + 1] - P.grp_slot_ptr[(size_t)c];
+          if (rows < 1 || rows > 255) return false;
+          if (!P.cd_sparse) inv_elems += (double)plane_elems(rows, round_up32(rows));
+          // a component's own nonzeros [csplit, end) refer to EARLIER rows of the same component
+          const int32_t s0 = P.grp_slot_ptr[(size_t)c];
+          for (int32_t r = 0; r < rows; ++r)
+            for (int32_t k = P.csplit[(size_t)(s0 + r)]; k < A.ptr[(size_t)(s0 + r) + 1]; ++k)
+              if (P.srcslot[(size_t)k] < s0 || P.srcslot[(size_t)k] >= s0 + r) return false;
+        }
+    } else if (P.band_dense[b]) {
+      if (opt.dense_block <= 0) return false;
+      const int32_t g = P.band_wg_ptr[b];
+      const int64_t rows = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)P.band_wg_ptr[b + 1]]] - P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)g]];
+      const int64_t nblk = (rows + opt.dense_block - 1) / opt.dense_block;
+      inv_elems += (double)nblk * (double)plane_elems(std::min<int64_t>(rows, opt.dense_block), round_up32(std::min<int64_t>(rows, opt.dense_block)));
+    }
+  }
+  if (inv_elems > 256.0 * (double)nz + 67108864.0) return false;
+  return true;
+}
+inline bool cached_schedule_ok(const Schedule &S, int64_t m) {
+  if ((int64_t)S.order.size() != m || S.wf_ptr.empty() || S.wf_ptr[0] != 0 || S.wf_ptr.back() != m) return false;
+  for (size_t i = 0; i + 1 < S.wf_ptr.size(); ++i)
+    if (S.wf_ptr[i + 1] < S.wf_ptr[i]) return false;
+  return is_permutation(S.order, m);
+}
+
+// Reads the trailer of an open hierarchy file, if it has one that fits `opt`; the file position is restored.
+// false: no (usable) trailer -- the caller analyzes as usual.
+template <class T>
+bool load_analysis(std::FILE *f, const BandOptions &opt, std::vector<LevelAnalysis<T>> &out) {
+  out.clear();
+  const long here = std::ftell(f);
+  if (here < 0) return false;
+  bool good = false;
+  do {
+    if (std::fseek(f, 0, SEEK_END) != 0) break;
+    const long end = std::ftell(f);
+    if (end < here + 24 || std::fseek(f, end - 24, SEEK_SET) != 0) break;
+    char foot[8];
+    int64_t fo[2];
+    if (std::fread(foot, 8, 1, f) != 1 || std::fread(fo, 16, 1, f) != 1 || std::memcmp(foot, kAnaFoot, 8) != 0) break;
+    if (fo[0] < here || fo[0] > end - 24 - 8 || std::fseek(f, (long)fo[0], SEEK_SET) != 0) break;
+    const int64_t left = end - 24 - fo[0];  // no array of the trailer can be longer than the trailer
+    HashIo io{f};
+    char magic[8];
+    if (!io.rd(magic, 8) || std::memcmp(magic, kAnaMagic, 8) != 0) break;
+    std::vector<double> ow;
+    if (!tget(io, ow, left) || ow != band_option_words(opt, sizeof(T))) break;
+    int64_t nl = 0;
+    if (!io.rd(&nl, 8) || nl < 1 || nl > 4096) break;
+    out.resize((size_t)nl);
+    bool all = true;
+    for (int64_t l = 0; l < nl && all; ++l) {
+      LevelAnalysis<T> &A = out[(size_t)l];
+      int64_t sc[6];
+      all = io.rd(sc, sizeof(sc)) && tget(io, A.originL, left) && tget(io, A.originU, left) && tget(io, A.Ls.order, left) &&
+            tget(io, A.Ls.wf_ptr, left) && tget(io, A.Us.order, left) && tget(io, A.Us.wf_ptr, left) && tget_plan(io, A.Lp, left) &&
+            tget_plan(io, A.Up, left) && tget(io, A.top, left);
+      if (!all) break;
+      A.m = sc[0], A.nzL = sc[1], A.nzU = sc[2], A.top_n = sc[3], A.top_bandL = (int32_t)sc[4], A.top_bandU = (int32_t)sc[5];
+    }
+    if (!all || std::ftell(f) != end - 24 || (int64_t)io.value() != fo[1]) break;
+    good = true;
+  } while (false);
+  if (!good) out.clear();
+  if (std::fseek(f, here, SEEK_SET) != 0) throw Error(kHifirError, "hierarchy file: seek failed");
+  return good;
+}
+
+// a level whose analysis came from the trailer: the slot-ordered triangles rebuilt from the imported ones, every size and
+// index range checked against them, then the cached arrays in place of analyze_level's and the cheap rest rebuilt.
+// false (H untouched): the trailer does not fit this level -- the caller analyzes as usual
+template <class T>
+bool adopt_analysis(HostLevel<T> &H, LevelAnalysis<T> &A, const BandOptions &opt) {
+  const int64_t m = H.m;
+  if (A.m != m || A.nzL != (int64_t)H.Lr.col.size() || A.nzU != (int64_t)H.Ur.col.size()) return false;
+  Csr<T> Lr, Ur;
+  bool okL = false, okU = false;  // (the two triangles side by side, like their analysis)
+  par2([&] { okL = csr_from_origin(H.Lr, A.Lp.order, A.originL, Lr) && cached_plan_ok(A.Lp, Lr, m, A.nzL, opt) &&
+                   (m == 0 || cached_schedule_ok(A.Ls, m)); },
+       [&] { okU = csr_from_origin(H.Ur, A.Up.order, A.originU, Ur) && cached_plan_ok(A.Up, Ur, m, A.nzU, opt) &&
+                   (m == 0 || cached_schedule_ok(A.Us, m)); });
+  if (!okL || !okU) return false;
+  if (!A.top.empty()) {  // the combined top operator: L's last band and U's first hold exactly the flagged rows
+    const int64_t nbL = (int64_t)A.Lp.band_wg_ptr.size() - 1, nbU = (int64_t)A.Up.band_wg_ptr.size() - 1;
+    if ((int64_t)A.top.size() != m || nbL < 1 || nbU < 1 || A.top_bandL != nbL - 1 || A.top_bandU != 0 || A.top_n < 1 ||
+        A.top_n > m || opt.top_max <= 0)
+      return false;
+    int64_t cnt = 0;
+    for (uint8_t t : A.top) cnt += t != 0;
+    if (cnt != A.top_n) return false;
+    auto band_is_top = [&](const BandPlan &P, const Csr<T> &M, int64_t b) {
+      const int32_t s0 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b]]];
+      const int32_t s1 = P.grp_slot_ptr[(size_t)P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b + 1]]];
+      if (s1 - s0 != A.top_n) return false;
+      for (int32_t q = s0; q < s1; ++q)
+        if (!A.top[(size_t)M.rowid[(size_t)q]]) return false;
+      return true;
+    };
+    if (!band_is_top(A.Lp, Lr, nbL - 1) || !band_is_top(A.Up, Ur, 0)) return false;
+  } else if (A.top_n != 0 || A.top_bandL != -1 || A.top_bandU != -1) {
+    return false;
+  }
+  H.Lr = std::move(Lr), H.Ur = std::move(Ur);
+  H.Ls = std::move(A.Ls), H.Us = std::move(A.Us);
+  H.Lp = std::move(A.Lp), H.Up = std::move(A.Up);
+  H.top = std::move(A.top);
+  H.top_n = A.top_n, H.top_bandL = A.top_bandL, H.top_bandU = A.top_bandU;
+  par2(
+      [&] {
+        H.Ltinv_elems = plan_dense_blocks<T>(H.Lp, opt);
+        build_cd_streams(H.Lp, H.Lr.ptr);
+      },
+      [&] {
+        H.Utinv_elems = plan_dense_blocks<T>(H.Up, opt);
+        build_cd_streams(H.Up, H.Ur.ptr);
+      });
+  return true;
+}
+
 }  // namespace hifamd

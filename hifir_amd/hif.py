@@ -90,9 +90,11 @@ class HIF:
         self.finalize(max_nrhs)
         return self
 
-    def save(self, path):
-        """Write the imported hierarchy (the add_level / set_dense arguments) to a file (hifamd_save)."""
-        _check(lib().hifamd_save(self._h, os.fsencode(path)))
+    def save(self, path, analysis=False):
+        """Write the imported hierarchy (the add_level / set_dense arguments) to a file (hifamd_save).  analysis=True
+        appends the host analysis of every level (hifamd_save_ex, HIFAMD_SAVE_ANALYSIS): a load under the same planner
+        options adopts it instead of analyzing again (stats_ext()["analysis_cached_levels"])."""
+        _check(lib().hifamd_save_ex(self._h, os.fsencode(path), 1 if analysis else 0))
 
     @classmethod
     def load(cls, path, max_nrhs=64, device=-1):
@@ -199,7 +201,8 @@ class HIF:
         s = np.zeros(16)
         k = lib().hifamd_stats_ext(self._h, _p(s), 16)
         keys = ["finalize_s", "graph_capture_ms", "bytes_inverses", "bytes_top", "bytes_tail", "tail_rows", "tail_level",
-                "tail_probe_relerr", "tail_max_abs", "tail_rejected", "tail_probe_tol", "tail_max_growth"]
+                "tail_probe_relerr", "tail_max_abs", "tail_rejected", "tail_probe_tol", "tail_max_growth",
+                "analysis_cached_levels", "analysis_s"]
         return {key: float(s[i]) for i, key in enumerate(keys[:max(0, k)])}
 
     def level_stats(self, level):

@@ -115,6 +115,15 @@ HifAmdStatus hifamd_finalize(HifAmdHdl h, int64_t max_nrhs);
  * counted arrays; the dense block as int64 nd, double rrqr_cond and a counted column-major array. */
 HifAmdStatus hifamd_save(HifAmdHdl h, const char *path);
 HifAmdStatus hifamd_load(const char *path, int device, HifAmdHdl *out);
+/* hifamd_save with options.  HIFAMD_SAVE_ANALYSIS appends the ANALYSIS of every level (wavefront schedules, band plans,
+ * slot-ordered triangles: what hifamd_add_level derives on the host, e.g. 24 s of the 45 s between load and first apply
+ * on a 256^3 grid) as a checksummed trailer behind the records above.  hifamd_load adopts it when it was made with the
+ * planner options in force (HIFIR_AMD_* environment) and fits the factors' sparsity pattern (it holds no matrix values),
+ * verifies every size and index range first, and analyzes as usual otherwise (also with HIFIR_AMD_LOAD_ANALYSIS=0): a trailer changes how long a load
+ * takes, never its result -- hifamd_stats_ext slot 12 tells how many levels came from it.  A reader that does not know
+ * the trailer ignores it.  No reference counterpart. */
+#define HIFAMD_SAVE_ANALYSIS 1
+HifAmdStatus hifamd_save_ex(HifAmdHdl h, const char *path, int flags);
 
 /* ---- queries (cf. lhf?GetLevels/GetNnz/GetSchurSize/GetSchurRank, libhifir.h:722-740) ------ */
 int hifamd_value_type(HifAmdHdl h);     /* HIFAMD_D / HIFAMD_Z of the handle (what hifamd_load found in the file); -1 for NULL */
@@ -135,7 +144,9 @@ HifAmdStatus hifamd_stats(HifAmdHdl h, double *stats16);
  * operators, 4 bytes of the tail operator, 5 rows of the tail operator (0: the recursion runs), 6 its first level,
  * 7 relative difference product vs recursion on the finalize-time probe, 8 max |entry| of the tail operator, 9 why it
  * was rejected (0 not, 1 not finite, 2 growth, 3 probe, 4 an error while it was formed), 10 / 11 the probe and growth
- * limits in force (HIFIR_AMD_TAIL_PROBE_TOL, HIFIR_AMD_TAIL_GROWTH).  -1 for a NULL handle. */
+ * limits in force (HIFIR_AMD_TAIL_PROBE_TOL, HIFIR_AMD_TAIL_GROWTH), 12 levels whose analysis came from the trailer of the
+ * file the handle was loaded from (hifamd_save_ex), 13 host seconds spent analyzing the levels (or adopting their
+ * analysis).  -1 for a NULL handle. */
 int hifamd_stats_ext(HifAmdHdl h, double *out, int cap);
 /* Per-level sizes (what the SURVEY 8(d) byte formula needs level by level): 0 m, 1 n, 2 nnz(L_B), 3 nnz(U_B), 4 nnz(E),
  * 5 nnz(F), 6 / 7 wavefronts of L / U, 8 / 9 launches ("bands") of the L / U plan, 10 rows of the combined top operator.

@@ -57,7 +57,9 @@ LhfStatus lhfzSyncDevices(const LhfzHifHdl hif);
 
 /* Export / import of the factored hierarchy in the on-disk format of hifamd_save / hifamd_load (include/hifir_amd.h):
  * factorize once where the host factorization is affordable, apply on GPU nodes without refactorizing.  A loaded
- * handle serves Apply / Solve / the size queries; lhf?Refactorize gives it a host factorization again. */
+ * handle serves Apply / Solve / the size queries; lhf?Refactorize gives it a host factorization again.
+ * With HIFIR_AMD_SAVE_ANALYSIS=1 in the environment the file also carries the host analysis of every level
+ * (hifamd_save_ex, HIFAMD_SAVE_ANALYSIS): the ranks that load it skip that work. */
 LhfStatus lhfdSaveHierarchy(const LhfdHifHdl hif, const char *path);
 LhfStatus lhfzSaveHierarchy(const LhfzHifHdl hif, const char *path);
 LhfdHifHdl lhfdLoadHierarchy(const char *path);

@@ -645,7 +645,9 @@ LHF_MATRIX_API(c, cflt, float _Complex)
   LhfStatus lhf##T##SaveHierarchy(const Lhf##T##HifHdl hif, const char *path) {                                       \
     if (!hif) return LHF_NULL_OBJ;                                                                                    \
     if (hif->gpu.empty()) return fail("MILU-Prec is empty!");                                                         \
-    return from_amd(hifamd_save(hif->gpu[0], path));                                                                  \
+    /* (HIFIR_AMD_SAVE_ANALYSIS=1: with the analysis trailer -- the other ranks of a job skip the host analysis) */     \
+    const char *ana = std::getenv("HIFIR_AMD_SAVE_ANALYSIS");                                                          \
+    return from_amd(hifamd_save_ex(hif->gpu[0], path, (ana && ana[0] && ana[0] != '0') ? HIFAMD_SAVE_ANALYSIS : 0));   \
   }                                                                                                                   \
   Lhf##T##HifHdl lhf##T##LoadHierarchy(const char *path) { return hif_load<Lhf##T##Hif, V>(path); }
 

@@ -24,6 +24,8 @@ struct Sink {  // what Engine<T> does on import, without a device
   HostHierarchy<T> host;
   BandOptions opt;
   bool analyze = true;
+  std::vector<LevelAnalysis<T>> cached;  // the analysis trailer of the file being loaded (load_bytes), if adopted
+  int adopted = 0;
   void add_level(int64_t m, int64_t n, const int64_t *Lcp, const int32_t *Lri, const T *Lv, const int64_t *Ucp,
                  const int32_t *Uri, const T *Uv, const int64_t *Ecp, const int32_t *Eri, const T *Ev, int64_t F_ncols,
                  const int64_t *Fcp, const int32_t *Fri, const T *Fv, const T *d, const double *s, const double *t,
@@ -31,7 +33,11 @@ struct Sink {  // what Engine<T> does on import, without a device
     const int64_t parent_nm = host.levels.empty() ? -1 : host.levels.back().n - host.levels.back().m;
     HostLevel<T> H = import_level<T>(parent_nm, m, n, Lcp, Lri, Lv, Ucp, Uri, Uv, Ecp, Eri, Ev, F_ncols, Fcp, Fri, Fv, d, s, t,
                                      p, p_inv, q, q_inv);
-    if (analyze) analyze_level(H, opt);
+    const size_t li = host.levels.size();
+    if (li < cached.size() && adopt_analysis(H, cached[li], opt))
+      ++adopted;
+    else if (analyze)
+      analyze_level(H, opt);
     host.levels.push_back(std::move(H));
   }
   // (hostile-file runs -- analyze == false -- only care that the block arrives with the right size)
@@ -61,12 +67,14 @@ static std::vector<unsigned char> slurp(const char *path) {
 }
 
 template <class T>
-static void load_bytes(const std::vector<unsigned char> &bytes, Sink<T> &S) {
+static void load_bytes(const std::vector<unsigned char> &bytes, Sink<T> &S, bool trailer = false) {
   std::FILE *f = fmemopen((void *)bytes.data(), bytes.size(), "rb");
   if (!f) throw std::runtime_error("fmemopen failed");
   try {
     if (std::fseek(f, 16, SEEK_SET) != 0) throw Error(kBadPrec, "truncated hierarchy file");
+    if (trailer) load_analysis<T>(f, S.opt, S.cached);  // (what Engine::load does first)
     load_hierarchy<T>(f, S);
+    S.cached.clear();
   } catch (...) {
     std::fclose(f);
     throw;
@@ -85,7 +93,12 @@ static bool same_csr(const Csr<T> &a, const Csr<T> &b) {
 static bool same_plan(const BandPlan &a, const BandPlan &b) {
   return same(a.order, b.order) && same(a.grp_slot_ptr, b.grp_slot_ptr) && same(a.wg_grp_ptr, b.wg_grp_ptr) &&
          same(a.band_wg_ptr, b.band_wg_ptr) && same(a.srcslot, b.srcslot) && same(a.split, b.split) &&
-         same(a.band_dense, b.band_dense) && same(a.band_fused, b.band_fused) && same(a.blk_slot0, b.blk_slot0);
+         same(a.band_dense, b.band_dense) && same(a.band_fused, b.band_fused) && same(a.blk_slot0, b.blk_slot0) &&
+         same(a.blk_slot1, b.blk_slot1) && same(a.blk_inv_off, b.blk_inv_off) && same(a.band_blk_ptr, b.band_blk_ptr) &&
+         same(a.grp_inv_off, b.grp_inv_off) && same(a.band_prefix, b.band_prefix) && same(a.band_cd, b.band_cd) &&
+         same(a.band_old, b.band_old) && same(a.csplit, b.csplit) && same(a.mid_k, b.mid_k) && same(a.mid_lrow, b.mid_lrow) &&
+         same(a.cd_desc, b.cd_desc) && same(a.own_k, b.own_k) && same(a.own_lsrc, b.own_lsrc) && same(a.own_lvl, b.own_lvl) &&
+         same(a.own_rptr, b.own_rptr) && a.cd_sparse == b.cd_sparse;
 }
 template <class T>
 static int compare(const Sink<T> &A, const Sink<T> &B, const char *what) {
@@ -177,6 +190,67 @@ static int run_file(const char *path, const std::vector<unsigned char> &bytes, i
       std::fprintf(stderr, "%s: save_hierarchy does not reproduce the file\n", path);
       ++bad;
     }
+  }
+  // the analysis trailer (hifamd_save_ex): adopted -> the same derived arrays as analyzed; then hostile trailers whose
+  // CHECKSUM IS RIGHT (so that the size / range checks behind it are what refuses them): words of the trailer overwritten
+  // with nasty values -- a load must either ignore the trailer, adopt a still-consistent one, or refuse at the
+  // invariants of finalize; never read out of bounds
+  {
+    std::vector<unsigned char> out(bytes.size() * 6 + (1 << 20));
+    std::FILE *f = fmemopen(out.data(), out.size(), "wb");
+    if (std::fwrite(bytes.data(), 1, 16, f) != 16) throw std::runtime_error("fmemopen write failed");
+    save_hierarchy(f, A.host);
+    save_analysis(f, A.host, A.opt);
+    const long len = std::ftell(f);
+    std::fclose(f);
+    out.resize((size_t)len);
+    Sink<T> K;
+    K.opt = A.opt;
+    load_bytes(out, K, true);
+    if (K.adopted != (int)A.host.levels.size()) {
+      std::fprintf(stderr, "%s: analysis trailer adopted for %d of %zu levels\n", path, K.adopted, A.host.levels.size());
+      ++bad;
+    }
+    bad += finalize_host(K);
+    bad += compare(A, K, "adopted analysis");
+    const size_t t0 = bytes.size(), t1 = out.size() - 24;  // the trailer's bytes
+    auto reseal = [&](std::vector<unsigned char> &b) {
+      HashIo h{nullptr};
+      h.mix(b.data() + t0, t1 - t0);
+      const int64_t hv = (int64_t)h.value();
+      std::memcpy(&b[b.size() - 8], &hv, 8);
+    };
+    {  // (the footer's checksum is the one reseal computes)
+      std::vector<unsigned char> chk = out;
+      reseal(chk);
+      if (chk != out) ++bad, std::fprintf(stderr, "%s: trailer checksum not reproduced\n", path);
+    }
+    int t_adopted = 0, t_ignored = 0, t_refused = 0;
+    uint64_t rs = 88172645463325252ull;
+    auto rnd = [&] { rs ^= rs << 13, rs ^= rs >> 7, rs ^= rs << 17; return rs; };
+    const int32_t nasty32[] = {-1, 0, 1, 255, 256, 1 << 30, 2147483647, 7};
+    std::vector<unsigned char> mut = out;
+    for (int trial = 0; trial < 1500; ++trial) {
+      const size_t off = t0 + (size_t)(rnd() % (t1 - t0 - 4)) & ~(size_t)3;
+      unsigned char keep[4];
+      std::memcpy(keep, &mut[off], 4);
+      const int32_t v = (trial & 7) == 7 ? (int32_t)(keep[0] + 1) : nasty32[rnd() % 8];
+      std::memcpy(&mut[off], &v, 4);
+      reseal(mut);
+      Sink<T> S;
+      S.opt = A.opt;
+      try {
+        load_bytes(mut, S, true);
+        for (size_t l = 0; l < S.host.levels.size(); ++l) check_level_invariants(S.host.levels[l], l);
+        (S.adopted ? t_adopted : t_ignored)++;
+      } catch (const Error &e) {
+        if (e.code < 1 || e.code > 4) ++bad;
+        ++t_refused;
+      }
+      std::memcpy(&mut[off], keep, 4);
+    }
+    std::fprintf(stderr, "%s: hostile trailers with a valid checksum: %d ignored, %d adopted, %d refused at the invariants\n", path,
+                 t_ignored, t_adopted, t_refused);
   }
   // hostile files: truncation at ~200 points, and every 8-byte word of the first 4 KB + a sample of the rest
   // overwritten with a few nasty values -- must throw Error (or load cleanly when the word is plain data)

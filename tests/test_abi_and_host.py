@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -157,6 +158,99 @@ def test_hierarchy_file_roundtrip(name, tmp_path):
     open(bad, "wb").write(b"garbage!" + raw[8:])
     with pytest.raises(hifir_amd.HifAmdError):
         hifir_amd.HIF.load(bad, max_nrhs=0)
+
+
+@pytest.mark.parametrize("name", ["p2d_64_deep", "young1c", "cd2d_48"])
+def test_analysis_trailer_of_a_hierarchy_file(name, tmp_path):
+    """hifamd_save_ex(HIFAMD_SAVE_ANALYSIS) / hifamd_load (host side only): the trailer is adopted when it fits, ignored
+    -- with the same hierarchy as result -- when it is damaged, truncated, made under other planner options or
+    switched off, and invisible to the records in front of it."""
+    import subprocess
+
+    levels, d = load_hier(name)
+    plain, ana = str(tmp_path / "plain.hifamd"), str(tmp_path / "ana.hifamd")
+    M = _save_fixture(name, plain)
+    M.save(ana, analysis=True)
+    raw_plain, raw = open(plain, "rb").read(), open(ana, "rb").read()
+    assert raw[:len(raw_plain)] == raw_plain and len(raw) > len(raw_plain) + 24 and raw[-24:-16] == b"HIFAMDAF"
+
+    def load(data, env=None):
+        p = str(tmp_path / "t.hifamd")
+        open(p, "wb").write(data)
+        if env:  # (the planner options are read when a handle is created: another process)
+            code = ("import sys; sys.path.insert(0, %r); import hifir_amd; M = hifir_amd.HIF.load(%r, max_nrhs=0); "
+                    "print(int(M.stats_ext()['analysis_cached_levels']), M.nnz(), M.levels())" % (ROOT, p))
+            out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env)).decode().split()
+            return int(out[0]), (int(out[1]), int(out[2]))
+        M2 = hifir_amd.HIF.load(p, max_nrhs=0)
+        for l in range(len(levels)):
+            for which in (0, 1):
+                o1, w1 = M.level_schedule(l, which)
+                o2, w2 = M2.level_schedule(l, which)
+                assert np.array_equal(o1, o2) and np.array_equal(w1, w2)
+        # what a loaded handle saves is what was loaded (plain records; with the analysis: the same trailer)
+        M2.save(p + ".again", analysis=True)
+        assert open(p + ".again", "rb").read() == raw
+        return int(M2.stats_ext()["analysis_cached_levels"]), (M2.nnz(), M2.levels())
+
+    same = (M.nnz(), M.levels())
+    assert load(raw) == (len(levels), same)
+    assert load(raw_plain) == (0, same)
+    assert load(raw, {"HIFIR_AMD_LOAD_ANALYSIS": "0"}) == (0, same)
+    assert load(raw, {"HIFIR_AMD_BAND_DEPTH": "24"})[0] == 0    # made under other planner options: ignored
+    assert load(raw, {"HIFIR_AMD_BAND_DEPTH": "32"})[0] == len(levels)
+    nt = len(raw) - len(raw_plain)
+    rng = np.random.default_rng(5)
+    for off in [len(raw_plain) + 3, len(raw_plain) + nt // 2, len(raw) - 30, len(raw) - 5] + \
+            [len(raw_plain) + int(k) for k in rng.integers(8, nt - 24, size=6)]:
+        bad = bytearray(raw)
+        bad[off] ^= 0x40
+        assert load(bytes(bad)) == (0, same), off                # one flipped bit anywhere in the trailer: ignored
+    for cut in (1, 8, 24, 25, nt // 2, nt - 1):
+        assert load(raw[:len(raw) - cut]) == (0, same), cut      # truncated trailer: ignored
+    # the trailer holds no matrix values: behind OTHER factors of the same pattern it is as good; of another pattern: ignored
+    if name == "p2d_64_deep":
+        lv2 = [dict(lv) for lv in levels]
+        lv2[0]["L_vals"] = np.asarray(lv2[0]["L_vals"]) * 1.5
+        M4 = hifir_amd.HIF(dtype=M.dtype)
+        for lv in lv2:
+            M4.add_level(lv)
+        if int(levels[-1].get("dense_n", 0)) > 0:
+            M4.set_dense(levels[-1]["dense"])
+        other = str(tmp_path / "other.hifamd")
+        M4.save(other)
+        raw_other = open(other, "rb").read()
+        assert len(raw_other) == len(raw_plain) and raw_other != raw_plain
+        p = str(tmp_path / "o.hifamd")
+        open(p, "wb").write(raw_other + raw[len(raw_plain):])
+        M5 = hifir_amd.HIF.load(p, max_nrhs=0)
+        assert int(M5.stats_ext()["analysis_cached_levels"]) == len(levels)
+        lv3 = [dict(lv) for lv in levels]
+        L0 = sp.csc_matrix((np.asarray(lv3[0]["L_vals"]), np.asarray(lv3[0]["L_rowind"]), np.asarray(lv3[0]["L_colptr"])),
+                           shape=(int(lv3[0]["m"]),) * 2).tolil()
+        i, j = [(int(a), int(b)) for a, b in zip(*L0.nonzero())][7]
+        L0[i, j] = 0.0          # one entry fewer ...
+        k = next(r for r in range(int(lv3[0]["m"]) - 1, j, -1) if L0[r, j] == 0 and r != i)
+        L0[k, j] = 0.25         # ... one more elsewhere: same counts, another pattern
+        L0 = sp.csc_matrix(L0)
+        L0.eliminate_zeros()
+        L0.sort_indices()
+        lv3[0]["L_colptr"], lv3[0]["L_rowind"], lv3[0]["L_vals"] = L0.indptr.astype(np.int64), L0.indices.astype(np.int32), L0.data
+        M6 = hifir_amd.HIF(dtype=M.dtype)
+        for lv in lv3:
+            M6.add_level(lv)
+        if int(levels[-1].get("dense_n", 0)) > 0:
+            M6.set_dense(levels[-1]["dense"])
+        M6.save(other)
+        raw3 = open(other, "rb").read()
+        assert len(raw3) == len(raw_plain)
+        open(p, "wb").write(raw3 + raw[len(raw_plain):])
+        M7 = hifir_amd.HIF.load(p, max_nrhs=0)
+        assert int(M7.stats_ext()["analysis_cached_levels"]) == len(levels) - 1  # (level 0 is analyzed afresh)
+        for which in (0, 1):
+            o1, w1 = M6.level_schedule(0, which)
+            o2, w2 = M7.level_schedule(0, which)
+            assert np.array_equal(o1, o2) and np.array_equal(w1, w2)
 
 
 def test_host_eigensolver(tmp_path):

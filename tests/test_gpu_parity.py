@@ -263,6 +263,26 @@ def test_saved_hierarchy_applies_identically(cache, name, tmp_path):
     assert np.array_equal(M2.mmultiply(d["x"]), M.mmultiply(d["x"]))
 
 
+@pytest.mark.parametrize("name", ["cd2d_48", "young1c", "p2d_64_deep"])
+def test_saved_analysis_is_adopted_and_changes_nothing(cache, name, tmp_path):
+    # hifamd_save_ex(HIFAMD_SAVE_ANALYSIS): a load adopts the schedules / band plans / slot-ordered triangles of the
+    # trailer instead of analyzing again -- every device-resident array and every result keeps its bits
+    levels, d, M, O = _get(cache, name)
+    path = str(tmp_path / "h_ana.hifamd")
+    M.save(path, analysis=True)
+    M2 = hifir_amd.HIF.load(path, max_nrhs=64)
+    assert M2.stats_ext()["analysis_cached_levels"] == len(levels)
+    ck = lambda H: (lambda o: o[:hifir_amd.lib().hifamd_debug_checksums(H._h, o.ctypes.data, 256)])(np.zeros(256, np.uint64))
+    assert np.array_equal(ck(M), ck(M2))
+    for tr in (False, True):
+        assert np.array_equal(M2.solve_mrhs(d["B4"], trans=tr), M.solve_mrhs(d["B4"], trans=tr))
+    assert np.array_equal(M2.mmultiply(d["x"]), M.mmultiply(d["x"]))
+    # a handle loaded from a file with a trailer writes a trailer again (the adopted analysis is complete)
+    path3 = str(tmp_path / "h_ana3.hifamd")
+    M2.save(path3, analysis=True)
+    assert open(path3, "rb").read() == open(path, "rb").read()
+
+
 def test_two_handles_from_two_threads(cache):
     # "distinct handles may be used from distinct threads" (hifir_amd.h conventions, like the reference):
     # two hierarchies applied concurrently from two host threads (ctypes releases the GIL) keep their results
