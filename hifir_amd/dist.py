@@ -67,9 +67,10 @@ def share_levels(levels, path):
 
 def share_hierarchy(M, path, max_nrhs=64, device=-1):
     """The product hand-off: rank 0 holds the imported hierarchy `M` (hifir_amd.HIF; None elsewhere), writes it in
-    the library's own on-disk format (hifamd_save -- exactly the add_level / set_dense arguments, any last-level
-    kind) and every other rank replays the file (hifamd_load + finalize on ITS device).  No collective carries
-    matrix data: the file lives on the node, ranks only meet at two barriers."""
+    the library's own on-disk format (hifamd_save_ex -- exactly the add_level / set_dense arguments, any last-level
+    kind, plus the host analysis of every level so that the other ranks do not repeat it) and every other rank replays
+    the file (hifamd_load + finalize on ITS device).  No collective carries matrix data: the file lives on the node,
+    ranks only meet at two barriers."""
     from .hif import HIF
 
     d = _dist()
@@ -77,7 +78,7 @@ def share_hierarchy(M, path, max_nrhs=64, device=-1):
         return M
     if d.get_rank() == 0:
         tmp = path + f".tmp{os.getpid()}"
-        M.save(tmp)
+        M.save(tmp, analysis=True)
         os.replace(tmp, path)
     d.barrier()
     if d.get_rank() != 0:

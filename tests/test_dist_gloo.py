@@ -77,8 +77,10 @@ def _worker(rank, world, port, tmpdir, q):
             M = hd.share_hierarchy(M0, path, max_nrhs=0)
             assert M.levels() == len(lv0) + 1 and M.schur_rank() == int(lv0[-1]["dense_rank"]), name
             again = path + f".again{rank}"
-            M.save(again)
+            M.save(again, analysis=True)  # (the hand-off carries the host analysis: the other rank adopted it)
             assert open(again, "rb").read() == open(path, "rb").read(), name
+            if rank != 0:
+                assert int(M.stats_ext()["analysis_cached_levels"]) == len(lv0), name
         t = hd.max_over_ranks(1.0 + rank)
         assert t == float(world)
         c = [hd.column_block(64, r, world) for r in range(world)]
