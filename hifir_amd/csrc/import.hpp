@@ -223,8 +223,14 @@ void analyze_level(HostLevel<T> &H, const BandOptions &band_opt, bool dump = fal
           lo = std::min(lo, A.rowid[(size_t)q]), hi = std::max(hi, A.rowid[(size_t)q]);
         if (hi >= lo) span_sum += hi - lo + 1;
       }
-      std::fprintf(stderr, "PLAN2 level=%zu tri=%c band=%ld comp_entries_max=%d chunk_entries_max=%d row_entries_max=%d id_runs=%ld id_span_sum=%ld\n", level_no,
-                   tri ? 'U' : 'L', (long)b, ne_max, ck16, rowmax, (long)runs, (long)span_sum);
+      int64_t lvl_sum = 0, lvl_max = 0, ncomp_sp = 0;  // sparse-own components: depth levels of the LDS substitution
+      if (P.band_cd[(size_t)b] && P.cd_sparse && !P.cd_desc.empty())
+        for (int32_t c = P.wg_grp_ptr[(size_t)g0]; c < P.wg_grp_ptr[(size_t)g1]; ++c) {
+          const int32_t nl = P.cd_desc[(size_t)c * kCdDescWords + 24];
+          lvl_sum += nl, lvl_max = std::max<int64_t>(lvl_max, nl), ++ncomp_sp;
+        }
+      std::fprintf(stderr, "PLAN2 level=%zu tri=%c band=%ld comp_entries_max=%d chunk_entries_max=%d row_entries_max=%d id_runs=%ld id_span_sum=%ld own_levels_mean=%.1f own_levels_max=%ld\n", level_no,
+                   tri ? 'U' : 'L', (long)b, ne_max, ck16, rowmax, (long)runs, (long)span_sum, ncomp_sp ? (double)lvl_sum / (double)ncomp_sp : 0.0, (long)lvl_max);
       int64_t own = 0, prevb = 0;  // nonzeros inside the rows' own component / gathered by the band kernel itself
       for (int32_t q = s0; q < s1; ++q) {
         own += A.ptr[(size_t)q + 1] - P.csplit[(size_t)q];

@@ -230,7 +230,7 @@ static int run_file(const char *path, const std::vector<unsigned char> &bytes, i
     auto rnd = [&] { rs ^= rs << 13, rs ^= rs >> 7, rs ^= rs << 17; return rs; };
     const int32_t nasty32[] = {-1, 0, 1, 255, 256, 1 << 30, 2147483647, 7};
     std::vector<unsigned char> mut = out;
-    for (int trial = 0; trial < 1500; ++trial) {
+    for (int trial = 0; trial < 800; ++trial) {
       const size_t off = t0 + (size_t)(rnd() % (t1 - t0 - 4)) & ~(size_t)3;
       unsigned char keep[4];
       std::memcpy(keep, &mut[off], 4);
@@ -239,9 +239,11 @@ static int run_file(const char *path, const std::vector<unsigned char> &bytes, i
       reseal(mut);
       Sink<T> S;
       S.opt = A.opt;
+      S.analyze = false;  // (a level whose trailer is refused stays unanalyzed here: analyze_level has its own runs above)
       try {
         load_bytes(mut, S, true);
-        for (size_t l = 0; l < S.host.levels.size(); ++l) check_level_invariants(S.host.levels[l], l);
+        if (S.adopted == (int)S.host.levels.size())
+          for (size_t l = 0; l < S.host.levels.size(); ++l) check_level_invariants(S.host.levels[l], l);
         (S.adopted ? t_adopted : t_ignored)++;
       } catch (const Error &e) {
         if (e.code < 1 || e.code > 4) ++bad;
