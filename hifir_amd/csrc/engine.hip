@@ -420,6 +420,7 @@ class Engine : public EngineBase {
   int cd_split_min = 0, cd_split_wgs = 600;
   int narrow_spmm = 1;   // HIFIR_AMD_NARROW_SPMM=0: batches of <= 32 columns keep the 64-lane Schur product kernel
   int cs_sparse = 0;     // HIFIR_AMD_CS_SPARSE=1: sparse-own bands (level 0) in column slices at full width too
+  int device_inverses = 1;  // HIFIR_AMD_DEVICE_INVERSES=0: the block inverses of finalize are formed by the host threads and uploaded
   int cs_max_wgs = 0;    // HIFIR_AMD_CS_MAX_WGS (full batches: measured equal to k_band_cd at every band width)
   int act_cols = 64;     // columns of the 64-column arena that the tile being enqueued actually uses (enqueue_apply)
   int band_pipe = 1;     // 1: k_trsv_band_p (next row's head behind the last gathers), 0: k_trsv_band at R = 64 too
@@ -474,6 +475,7 @@ class Engine : public EngineBase {
     cs_mode = env_int("HIFIR_AMD_CS", 1);
     cs_max_wgs = env_int("HIFIR_AMD_CS_MAX_WGS", 0);
     cs_sparse = env_int("HIFIR_AMD_CS_SPARSE", 0);
+    device_inverses = env_int("HIFIR_AMD_DEVICE_INVERSES", 1);
     narrow_spmm = env_int("HIFIR_AMD_NARROW_SPMM", 1);
     cd_split_min = env_int("HIFIR_AMD_CD_SPLIT_MIN", 0);
     cd_split_wgs = env_int("HIFIR_AMD_CD_SPLIT_WGS", 600);
@@ -828,7 +830,7 @@ class Engine : public EngineBase {
     int64_t biggest = dense_block_elems(std::max<int64_t>(band_opt.dense_block, 32), cplx);
     for (size_t q = 0; q < P.blk_slot0.size(); ++q) biggest = std::max(biggest, elems_of(q));
     const size_t cap = (size_t)biggest * sizeof(double);
-    if (!pin[0] || pin_cap < cap) {
+    if (!device_inverses && (!pin[0] || pin_cap < cap)) {
       for (int k = 0; k < 2; ++k) {
         if (pin[k]) (void)hipHostFree(pin[k]);
         HIP_OK(hipHostMalloc((void **)&pin[k], cap, hipHostMallocDefault));
@@ -838,7 +840,34 @@ class Engine : public EngineBase {
     }
     std::vector<uint8_t> bad(P.blk_slot0.size(), 0);
     const size_t nblk = P.blk_slot0.size();
-    for (size_t q0 = 0; q0 < nblk;) {
+    if (device_inverses && nblk) {
+      // on the device (kernels.hip.hpp k_block_inverse): the factors are there already, the operators never cross PCIe
+      DevBuf d0, d1, doff, dg;
+      std::vector<int64_t> off64(P.blk_inv_off.begin(), P.blk_inv_off.end());
+      d0.upload(P.blk_slot0), d1.upload(P.blk_slot1), doff.upload(off64);
+      dg.alloc(nblk * sizeof(unsigned long long));
+      HIP_OK(hipMemsetAsync(dg.p, 0, dg.bytes, stream));
+      HIP_OK(hipMemsetAsync(M.tinv.p, 0, M.tinv.bytes, stream));
+      int32_t rows_max = 1;
+      for (size_t q = 0; q < nblk; ++q) rows_max = std::max(rows_max, P.blk_slot1[q] - P.blk_slot0[q]);
+      const unsigned gy = (unsigned)((rows_max + 255) / 256);
+      for (size_t q0 = 0; q0 < nblk; q0 += 1u << 20) {  // (grid.x in slices of 2^20 blocks)
+        const unsigned gx = (unsigned)std::min<size_t>(nblk - q0, 1u << 20);
+        hipLaunchKernelGGL((k_block_inverse<D>), dim3(gx, gy), dim3(256), 0, stream, d0.as<int32_t>() + q0, d1.as<int32_t>() + q0,
+                           doff.as<int64_t>() + q0, M.ptr.as<int32_t>(), M.srcslot.as<int32_t>(), M.val.as<D>(), M.tinv.as<double>(),
+                           dg.as<unsigned long long>() + q0);
+      }
+      HIP_OK(hipGetLastError());
+      std::vector<unsigned long long> gbits(nblk);
+      HIP_OK(hipMemcpyAsync(gbits.data(), dg.p, dg.bytes, hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+      for (size_t q = 0; q < nblk; ++q) {
+        double g;
+        std::memcpy(&g, &gbits[q], 8);
+        if (!(g <= band_opt.dense_max_growth)) bad[q] = 1;
+      }
+    }
+    for (size_t q0 = device_inverses ? nblk : 0; q0 < nblk;) {
       size_t q1 = q0 + 1;
       int64_t batch = elems_of(q0);
       while (q1 < nblk && batch + elems_of(q1) <= biggest && P.blk_inv_off[q1] == P.blk_inv_off[q0] + batch) batch += elems_of(q1++);

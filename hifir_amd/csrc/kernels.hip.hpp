@@ -3282,4 +3282,61 @@ __global__ void __launch_bounds__(256) k_zcombine(int64_t nrows, const double *_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Set-up (hifamd_finalize): the explicit inverses of the diagonal blocks of the block-dense and component-dense bands,
+// formed ON THE DEVICE straight in operand layout -- host.hpp build_dense_block restated (forward substitution on the
+// identity; the host version computes 16 columns side by side, here a lane owns a column): the same operations per
+// column in the same order, the same bits (tests compare the two through hifamd_debug_checksums).  30 GB of operators
+// for the 16.8 M-row hierarchy took the host threads 21 s and the PCIe link; this takes the factors that are on the
+// device anyway.  Block q = rows [slot0, slot1) of the slot-ordered triangle; element (r, c) of its inverse lives at
+// ((r >> 4) * ldk + c) * 16 + (r & 15) (complex: imaginary parts one plane behind); a lane reads back what it wrote
+// (y_c of an earlier row c), everything above the diagonal stays the zero it was set to.  growth[q] = largest |entry|
+// (NaN when a nonzero of the block is not finite: the host arithmetic would have produced NaN from inf * 0).
+// grid (blocks, ceil(max rows / 256)), 256 threads.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double vabs(double a) { return fabs(a); }
+__device__ __forceinline__ double vabs(cplx a) { return hypot(a.x, a.y); }
+__device__ __forceinline__ bool vfinite(double a) { return isfinite(a); }
+__device__ __forceinline__ bool vfinite(cplx a) { return isfinite(a.x) && isfinite(a.y); }
+__device__ __forceinline__ double op_get(const double *ops, int64_t, int64_t idx, double) { return ops[idx]; }
+__device__ __forceinline__ cplx op_get(const double *ops, int64_t plane, int64_t idx, cplx) { return cplx{ops[idx], ops[plane + idx]}; }
+__device__ __forceinline__ void op_put(double *ops, int64_t, int64_t idx, double v) { ops[idx] = v; }
+__device__ __forceinline__ void op_put(double *ops, int64_t plane, int64_t idx, cplx v) { ops[idx] = v.x, ops[plane + idx] = v.y; }
+template <class T>
+__global__ void __launch_bounds__(256) k_block_inverse(const int32_t *__restrict__ blk_slot0, const int32_t *__restrict__ blk_slot1,
+                                                       const int64_t *__restrict__ blk_inv_off, const int32_t *__restrict__ ptr,
+                                                       const int32_t *__restrict__ srcslot, const T *__restrict__ val, double *tinv,
+                                                       unsigned long long *growth_bits) {
+  const int q = (int)blockIdx.x;
+  const int32_t r0 = blk_slot0[q], nb = blk_slot1[q] - r0;
+  if ((int32_t)blockIdx.y * 256 >= nb) return;
+  const int32_t j = (int32_t)blockIdx.y * 256 + (int32_t)threadIdx.x;  // this lane's column of the inverse
+  const bool live = j < nb;
+  if (__builtin_amdgcn_readfirstlane(j) >= nb) return;  // (a wave without a column)
+  const int32_t c0 = j & ~15;  // (the host works on chunks of 16 columns: a column's sum starts at its chunk's first row)
+  const int64_t ldk = ((int64_t)nb + 31) & ~(int64_t)31, plane = (((int64_t)nb + 15) / 16) * 16 * ldk;
+  double *ops = tinv + blk_inv_off[q];
+  double g = 1.0;
+  if (live) op_put(ops, plane, (((int64_t)(j >> 4)) * ldk + j) * 16 + (j & 15), vfromreal(1.0, T()));
+  const int32_t rbeg = __builtin_amdgcn_readfirstlane(c0) + 1;  // (the wave's first chunk; later chunks skip rows <= their c0)
+  for (int32_t r = rbeg; r < nb; ++r) {
+    const int32_t s = r0 + r;
+    T acc = vfromreal(r == j ? 1.0 : 0.0, T());
+    const bool mine = live && r > c0;
+    for (int32_t k = ptr[s]; k < ptr[s + 1]; ++k) {
+      const int32_t c = srcslot[k] - r0;
+      if (c < 0) continue;  // (a source outside the block: the band kernel's business)
+      const T a = val[k];
+      if (!vfinite(a)) g = __builtin_nan("");
+      if (mine && c >= c0) acc = vsub(acc, vmul(a, op_get(ops, plane, (((int64_t)(c >> 4)) * ldk + j) * 16 + (c & 15), T())));
+    }
+    if (mine && j <= r) {
+      if (j < r) op_put(ops, plane, (((int64_t)(r >> 4)) * ldk + j) * 16 + (r & 15), acc);
+      g = vfinite(acc) ? fmax(g, vabs(acc)) + (isnan(g) ? g : 0.0) : __builtin_nan("");
+    }
+  }
+  // largest entry of the block: positive doubles order like their bit patterns; NaN (all ones in the exponent) wins
+  if (live) atomicMax(&growth_bits[q], (unsigned long long)__double_as_longlong(isnan(g) ? __builtin_nan("") : g));
+}
+
 }  // namespace hifamd

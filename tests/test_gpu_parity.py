@@ -283,6 +283,22 @@ def test_saved_analysis_is_adopted_and_changes_nothing(cache, name, tmp_path):
     assert open(path3, "rb").read() == open(path, "rb").read()
 
 
+@pytest.mark.parametrize("name", ["cd2d_48", "young1c", "p2d_64_deep", "p2d_100_tuned"])
+def test_block_inverses_formed_on_the_device_are_the_hosts(cache, name, monkeypatch):
+    # hifamd_finalize forms the explicit inverses of the diagonal blocks on the device (k_block_inverse); the host version
+    # (host.hpp build_dense_block, HIFIR_AMD_DEVICE_INVERSES=0) is the same arithmetic in the same order: every resident
+    # array -- the operators included -- and every result has the same bits
+    levels, d, M, O = _get(cache, name)
+    monkeypatch.setenv("HIFIR_AMD_DEVICE_INVERSES", "0")
+    Mh = hifir_amd.HIF.from_levels(levels, max_nrhs=64)
+    monkeypatch.delenv("HIFIR_AMD_DEVICE_INVERSES")
+    ck = lambda H: (lambda o: o[:hifir_amd.lib().hifamd_debug_checksums(H._h, o.ctypes.data, 256)])(np.zeros(256, np.uint64))
+    assert np.array_equal(ck(M), ck(Mh))
+    for tr in (False, True):
+        assert np.array_equal(Mh.solve_mrhs(d["B4"], trans=tr), M.solve_mrhs(d["B4"], trans=tr))
+    Mh.close()
+
+
 def test_two_handles_from_two_threads(cache):
     # "distinct handles may be used from distinct threads" (hifir_amd.h conventions, like the reference):
     # two hierarchies applied concurrently from two host threads (ctypes releases the GIL) keep their results
