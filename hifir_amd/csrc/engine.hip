@@ -918,9 +918,23 @@ class Engine : public EngineBase {
     Rmax = std::max<int64_t>(Rmax, 1LL << min_logR);
     // every array the kernels index with is re-validated right before it is shipped (import.hpp): a host copy that
     // is not what the conversion must have produced is refused here instead of hanging or mis-solving on the device
+    // (development aid, HIFIR_AMD_FINALIZE_DUMP=1: seconds per piece of the set-up on stderr)
+    const bool fdump = env_int("HIFIR_AMD_FINALIZE_DUMP", 0) != 0;
+    auto fnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double ft = fnow();
+    auto tick = [&](const char *what, size_t level) {
+      if (!fdump) return;
+      (void)hipDeviceSynchronize();
+      const double t = fnow();
+      std::fprintf(stderr, "FINALIZE level=%zu %-28s %.3f s\n", level, what, t - ft);
+      ft = t;
+    };
     for (size_t l = 0; l < host.levels.size(); ++l) check_level_invariants(host.levels[l], l, adjoint);
+    tick("invariants (all levels)", 0);
     bind_device();
+    tick("bind device", 0);
     for (auto &H : host.levels) {
+      const size_t fl_ = lv.size();
       std::unique_ptr<DevLevel> Lp(new DevLevel());
       DevLevel &L = *Lp;
       L.m = H.m;
@@ -929,6 +943,7 @@ class Engine : public EngineBase {
       L.E_void = H.E_void;
       ship_block_inverses(H.Lp, H.Lr, H.Ltinv_elems, L.L);
       ship_block_inverses(H.Up, H.Ur, H.Utinv_elems, L.U);
+      tick("triangles + block inverses", fl_);
       if (H.top_n > 0 && H.Lp.band_dense[(size_t)H.top_bandL] && H.Up.band_dense[(size_t)H.top_bandU]) {
         // (a top band whose block inverses grew too much has lost its dense flag: then the bands run one by one)
         const int32_t r0L = H.Lp.grp_slot_ptr[(size_t)H.Lp.wg_grp_ptr[(size_t)H.Lp.band_wg_ptr[(size_t)H.top_bandL]]];
@@ -943,6 +958,7 @@ class Engine : public EngineBase {
           top_rows_max = std::max(top_rows_max, H.top_n);
         }
       }
+      tick("combined top operator", fl_);
       L.E.upload(H.Er, nullptr);
       L.F.upload(H.Fr, nullptr);
       if (spmm_tiles && sizeof(T) == sizeof(double) && band_opt.dense_block > 0)  // fast mode, real data
@@ -957,6 +973,7 @@ class Engine : public EngineBase {
           Md.tl_coef.upload(Tl.coef);
           Md.tl_nblk = Tl.nblk;
         }
+      tick("E / F + product tiles", fl_);
       // S5 fused into the second L solve (host.hpp build_cd_streams_fused): thin F rows only -- rows that share columns
       // are better served by the tiled product
       if constexpr (std::is_same<T, double>::value) {
@@ -999,6 +1016,7 @@ class Engine : public EngineBase {
       L.alloc_arena((size_t)H.n * Rmax * sizeof(T));
       zero_dev(L.w.p, L.w.bytes);
       zero_dev(L.v.p, L.v.bytes);
+      tick("fused streams, vectors, arena", fl_);
 
       lv.push_back(std::move(Lp));
     }
@@ -1087,8 +1105,10 @@ class Engine : public EngineBase {
     }
     // The tail operator is an optimisation: whatever goes wrong while it is formed (allocation, a device error of
     // its own applies) leaves the handle with the recursion -- and the handle is marked finalized only afterwards.
+    tick("dense block, buffers", lv.size());
     try {
       build_tail_operator();
+      tick("tail operator", lv.size());
     } catch (const std::exception &) {
       (void)hipGetLastError();
       tailG.release();
