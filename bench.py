@@ -408,6 +408,7 @@ def main():
                        "launches_per_apply": int(st["launches"]) if st["launches"] else None,
                        "parallelism": f"rhs-sharded x{world} (hierarchy replicated)",
                        # set-up cost (once per hierarchy) and what stays resident beside the factors
+                       "analysis_s": r["setup"].get("analysis_s"), "analysis_levels_from_file": r["setup"].get("analysis_cached_levels"),
                        "finalize_s": r["setup"].get("finalize_s"), "graph_capture_ms": r["setup"].get("graph_capture_ms"),
                        "operator_bytes": {"block_inverses": r["setup"].get("bytes_inverses"), "top_operators": r["setup"].get("bytes_top"),
                                           "tail_operator": r["setup"].get("bytes_tail")},
