@@ -152,6 +152,11 @@ struct DevCsr {
   DevBuf own_val, own_lsrc, own_rptr, own_lvl;                        // ... sparse-own plans (BandPlan::cd_sparse)
   DevBuf f_desc, f_col, f_val, f_lrow;  // L only: the streams with the level's F entries appended (host.hpp build_cd_streams_fused)
   bool f_fused = false;
+  // tile form of the dense-own component bands' walked entries (host.hpp build_ct_tiles, kernel k_band_ct)
+  DevBuf ct_desc, ct_sptr, ct_src, ct_coef;
+  bool ct_on = false;
+  int64_t ct_tiles = 0;
+  std::vector<int32_t> band_wave_tiles;  // per band: most tiles one wave of one component walks
   bool cd_sparse = false;
   std::vector<int32_t> band_chunk_max;  // component bands: most entries of one wave chunk of the band (the serial walk of its slowest wave)
   int32_t own_cap = kCdOwnCap;  // sparse-own plans: most own nonzeros of one component, rounded up to 64 (sizes the kernels' LDS)
@@ -194,6 +199,13 @@ struct DevCsr {
     f_val.alias(o.f_val);
     f_lrow.alias(o.f_lrow);
     f_fused = o.f_fused;
+    ct_desc.alias(o.ct_desc);
+    ct_sptr.alias(o.ct_sptr);
+    ct_src.alias(o.ct_src);
+    ct_coef.alias(o.ct_coef);
+    ct_on = o.ct_on;
+    ct_tiles = o.ct_tiles;
+    band_wave_tiles = o.band_wave_tiles;
     cd_sparse = o.cd_sparse;
     band_cd = o.band_cd;
     band_old = o.band_old;
@@ -422,6 +434,8 @@ class Engine : public EngineBase {
   int cs_sparse = 0;     // HIFIR_AMD_CS_SPARSE=1: sparse-own bands (level 0) in column slices at full width too
   int device_inverses = 1;  // HIFIR_AMD_DEVICE_INVERSES=0: the block inverses of finalize are formed by the host threads and uploaded
   int cs_max_wgs = 0;    // HIFIR_AMD_CS_MAX_WGS (full batches: measured equal to k_band_cd at every band width)
+  int ct_mode = 1;       // HIFIR_AMD_CT=0: dense-own component bands walk their entries one by one (k_band_cd / k_band_cs) instead of
+                         // multiplying 16 x 4 coefficient tiles on the matrix cores (k_band_ct)
   int act_cols = 64;     // columns of the 64-column arena that the tile being enqueued actually uses (enqueue_apply)
   int band_pipe = 1;     // 1: k_trsv_band_p (next row's head behind the last gathers), 0: k_trsv_band at R = 64 too
   BandOptions band_opt;  // how triangles are cut into bands (host.hpp)
@@ -474,6 +488,7 @@ class Engine : public EngineBase {
     cd_dbg = env_int("HIFIR_AMD_CD_DBG", 0);
     cs_mode = env_int("HIFIR_AMD_CS", 1);
     cs_max_wgs = env_int("HIFIR_AMD_CS_MAX_WGS", 0);
+    ct_mode = env_int("HIFIR_AMD_CT", 1);
     cs_sparse = env_int("HIFIR_AMD_CS_SPARSE", 0);
     device_inverses = env_int("HIFIR_AMD_DEVICE_INVERSES", 1);
     narrow_spmm = env_int("HIFIR_AMD_NARROW_SPMM", 1);
@@ -632,6 +647,7 @@ class Engine : public EngineBase {
       E->cd_dbg = cd_dbg;
       E->cs_mode = cs_mode;
       E->cs_max_wgs = cs_max_wgs;
+      E->ct_mode = ct_mode;
       E->cs_sparse = cs_sparse;
       E->narrow_spmm = narrow_spmm;
       E->cd_split_min = cd_split_min;
@@ -693,6 +709,7 @@ class Engine : public EngineBase {
       E->cd_dbg = cd_dbg;
       E->cs_mode = cs_mode;
       E->cs_max_wgs = cs_max_wgs;
+      E->ct_mode = ct_mode;
       E->cs_sparse = cs_sparse;
       E->narrow_spmm = narrow_spmm;
       E->cd_split_min = cd_split_min;
@@ -823,6 +840,20 @@ class Engine : public EngineBase {
   // A band whose inverses grow beyond dense_max_growth reverts to the sequential (flag) scheme.
   void ship_block_inverses(BandPlan &P, const Csr<T> &A, int64_t total_elems, DevCsr &M) {
     M.upload(A, &P);
+    if (ct_mode && sizeof(T) == sizeof(double) && band_opt.dense_block > 0 && !P.cd_sparse && !P.band_cd.empty()) {
+      // dense-own component bands: the entries a component reads from older rows as 16 x 4 coefficient tiles (k_band_ct)
+      CtTiles Tl;
+      build_ct_tiles(P, A, Tl);
+      if (Tl.ntiles > 0 || !Tl.desc.empty()) {
+        M.ct_desc.upload(Tl.desc);
+        M.ct_sptr.upload(Tl.sptr, 8);
+        M.ct_src.upload(Tl.src, 64);
+        M.ct_coef.upload(Tl.coef, 512);
+        M.ct_on = true;
+        M.ct_tiles = Tl.ntiles;
+        M.band_wave_tiles = Tl.band_wave_tiles;
+      }
+    }
     if (!total_elems) return;
     M.tinv.alloc((size_t)total_elems * sizeof(double));
     const bool cplx = sizeof(T) != sizeof(double);
@@ -1469,6 +1500,11 @@ class Engine : public EngineBase {
     if (sparse) b += (size_t)own_cap * (sizeof(double) + 1) + 260 * sizeof(uint16_t) + 264;
     return b + 16;
   }
+  // LDS of k_band_ct: right-hand sides [rows][16], per row two doubles and three int32, 17 strip offsets
+  size_t ct_lds_bytes() const {
+    const size_t rows = (size_t)cd_lds_rows(false);
+    return rows * 18 * sizeof(double) + rows * 3 * sizeof(int32_t) + 32 * sizeof(int32_t);
+  }
   // v_tail = G c_tail (build_tail_operator); the product reads up to 31 rows behind c_tail: they lie inside the level's
   // arena (v follows w) and meet zero columns of the operand
   bool launch_tail(hipStream_t st, const D *cin, D *zout, int64_t &count) {
@@ -1508,6 +1544,15 @@ class Engine : public EngineBase {
       // column slices (k_band_cs): narrow batches always, full batches where the band is narrow
       const int nsl = std::min(4, (act_cols + 15) / 16);
       const bool fits = (int64_t)(g1 - g0) * nsl + 4 * (int64_t)extra < (1LL << 30);
+      if (ct_mode && M.ct_on && !M.cd_sparse && !with_f && fits) {  // coefficient tiles on the matrix cores, every batch width
+        hipLaunchKernelGGL(k_band_ct<LOWER>, dim3((unsigned)((g1 - g0) * nsl) + 4 * extra), dim3(256), ct_lds_bytes(), st, g0,
+                           M.wg_grp_ptr.as<int32_t>(), M.ct_desc.as<int32_t>(), M.ptr.as<int32_t>(), M.split.as<int32_t>(),
+                           M.col.as<int32_t>(), M.val.as<double>(), M.rowid.as<int32_t>(), L.d.as<double>(), L.w.as<double>(),
+                           L.v.as<double>(), M.tinv.as<double>(), M.ct_sptr.as<int32_t>(), M.ct_src.as<int32_t>(),
+                           M.ct_coef.as<double>(), pre ? 0 : 1, (int32_t)(g1 - g0), (int32_t)nsl, ps0, ps1, single_c0, lds_rows,
+                           cd_dbg | (no_walk ? 1 : 0), fl, lu);
+        return;
+      }
       if (cs_mode && (nsl < 4 || g1 - g0 <= cs_max_wgs || (cs_sparse && M.cd_sparse)) && fits) {
         auto kcs = M.cd_sparse ? k_band_cs<LOWER, true> : k_band_cs<LOWER, false>;
         hipLaunchKernelGGL(kcs, dim3((unsigned)((g1 - g0) * nsl) + 4 * extra), dim3(256), cs_lds_bytes(M.cd_sparse, M.own_cap), st, g0,

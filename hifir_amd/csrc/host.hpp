@@ -941,6 +941,134 @@ inline void build_cd_streams(BandPlan &P, const std::vector<int32_t> &aptr /* ro
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tile form of what a dense-own component band walks (round 4; kernel k_band_ct).  The entries [split, csplit) of a
+// component's rows -- sources finished by earlier launches -- are a small sparse matrix (rows x distinct sources) whose
+// rows share most of their sources (measured on the reference's 1M-row hierarchies: a 16-row strip of a component
+// meets 11-13 entries per 4 distinct sources).  Per 16-row strip the distinct sources, oldest first, are cut into groups
+// of four; a group is ONE v_mfma_f64_16x16x4 step per 16-column slice: A = the 16 x 4 coefficient tile (zeros where a row
+// lacks the source), B = the four gathered source rows.  Every distinct source of a strip is gathered once, and the
+// entry walk of k_band_cd (a dozen vector / scalar instructions per entry and wave) becomes one matrix instruction per
+// dozen entries.  The summation order differs from the row loops' (tolerance-level; fast mode only).
+//   sptr  : per component S + 1 tile offsets (S = strips of the component), block of component c at desc word 20
+//   src   : 4 source ROW numbers per tile (a short last group repeats its last source with zero coefficients)
+//   coef  : 64 per tile, element (k << 4) | r = coefficient of row 16 s + r for source k
+//   desc words 22, 23: four uint16 masks -- the strips each of the kernel's four waves owns (balanced by tiles)
+// ---------------------------------------------------------------------------------------------
+struct CtTiles {
+  std::vector<int32_t> sptr, src;
+  std::vector<double> coef;
+  std::vector<int32_t> desc;  // copy of BandPlan::cd_desc with words 20, 22, 23 filled for the dense-own components
+  int64_t ntiles = 0;
+  int32_t max_wave_tiles = 0;  // most tiles one wave of one component walks (the serial part of a band)
+  std::vector<int32_t> band_wave_tiles;  // ... per band
+};
+
+inline void build_ct_tiles(const BandPlan &P, const Csr<double> &A /* slot order */, CtTiles &Tl) {
+  Tl = CtTiles();
+  if (P.band_cd.empty() || P.cd_sparse || P.cd_desc.empty()) return;
+  Tl.desc = P.cd_desc;
+  const int64_t ngrp = (int64_t)P.grp_slot_ptr.size() - 1;
+  // which components take part, their strips, and (pass 1) the tiles of every strip
+  std::vector<uint8_t> is_cd((size_t)ngrp, 0);
+  Tl.band_wave_tiles.assign((size_t)P.nbands(), 0);
+  std::vector<int32_t> band_of((size_t)ngrp, -1);
+  for (int64_t b = 0; b < P.nbands(); ++b) {
+    if (!P.band_cd[(size_t)b]) continue;
+    for (int32_t c = P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b]]; c < P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b + 1]]; ++c)
+      is_cd[(size_t)c] = 1, band_of[(size_t)c] = (int32_t)b;
+  }
+  std::vector<int64_t> sp0((size_t)ngrp + 1, 0);  // first sptr entry of every component
+  for (int64_t c = 0; c < ngrp; ++c) {
+    const int32_t nb = P.grp_slot_ptr[(size_t)c + 1] - P.grp_slot_ptr[(size_t)c];
+    sp0[(size_t)c + 1] = sp0[(size_t)c] + (is_cd[(size_t)c] ? (nb + 15) / 16 + 1 : 0);
+  }
+  if (sp0[(size_t)ngrp] > (int64_t)std::numeric_limits<int32_t>::max()) throw Error(4, "component tile index overflows int32");
+  std::vector<int32_t> cnt((size_t)sp0[(size_t)ngrp], 0);  // tiles per strip (slot s + 1 of the component's block)
+  auto strip_sources = [&](int32_t r0, int32_t r1, std::vector<int32_t> &u) {  // distinct source slots, ascending
+    u.clear();
+    for (int32_t s = r0; s < r1; ++s)
+      for (int32_t k = P.split[(size_t)s]; k < P.csplit[(size_t)s]; ++k) u.push_back(P.srcslot[(size_t)k]);
+    std::sort(u.begin(), u.end());
+    u.erase(std::unique(u.begin(), u.end()), u.end());
+  };
+  parallel_for(ngrp, 64, [&](int64_t c0, int64_t c1) {
+    std::vector<int32_t> u;
+    for (int64_t c = c0; c < c1; ++c) {
+      if (!is_cd[(size_t)c]) continue;
+      const int32_t a = P.grp_slot_ptr[(size_t)c], e = P.grp_slot_ptr[(size_t)c + 1];
+      for (int32_t r0 = a, s = 0; r0 < e; r0 += 16, ++s) {
+        strip_sources(r0, std::min(e, r0 + 16), u);
+        cnt[(size_t)(sp0[(size_t)c] + s + 1)] = (int32_t)((u.size() + 3) / 4);
+      }
+    }
+  });
+  // absolute tile offsets
+  Tl.sptr.assign(cnt.size(), 0);
+  int64_t total = 0;
+  for (int64_t c = 0; c < ngrp; ++c) {
+    if (!is_cd[(size_t)c]) continue;
+    const int64_t b0 = sp0[(size_t)c], b1 = sp0[(size_t)c + 1];
+    for (int64_t q = b0; q < b1; ++q) {
+      total += cnt[(size_t)q];  // (cnt[b0] == 0: the block's first entry is the component's first tile)
+      if (total > (int64_t)std::numeric_limits<int32_t>::max() / 64) throw Error(4, "component tile index overflows int32");
+      Tl.sptr[(size_t)q] = (int32_t)total;
+    }
+  }
+  Tl.ntiles = total;
+  Tl.src.assign((size_t)(4 * total), 0);
+  Tl.coef.assign((size_t)(64 * total), 0.0);
+  std::vector<int32_t> wave_max((size_t)ngrp, 0);
+  parallel_for(ngrp, 64, [&](int64_t c0, int64_t c1) {
+    std::vector<int32_t> u;
+    for (int64_t c = c0; c < c1; ++c) {
+      if (!is_cd[(size_t)c]) continue;
+      const int32_t a = P.grp_slot_ptr[(size_t)c], e = P.grp_slot_ptr[(size_t)c + 1];
+      const int32_t S = (e - a + 15) / 16;
+      for (int32_t r0 = a, s = 0; r0 < e; r0 += 16, ++s) {
+        const int32_t r1 = std::min(e, r0 + 16);
+        strip_sources(r0, r1, u);
+        const int64_t t0 = Tl.sptr[(size_t)(sp0[(size_t)c] + s)];
+        const int64_t nt = ((int64_t)u.size() + 3) / 4;
+        for (int64_t q = 0; q < 4 * nt; ++q)  // source ROW numbers (what the kernel gathers from), short group padded
+          Tl.src[(size_t)(4 * t0 + q)] = A.rowid[(size_t)u[(size_t)std::min<int64_t>(q, (int64_t)u.size() - 1)]];
+        for (int32_t sl = r0; sl < r1; ++sl)
+          for (int32_t k = P.split[(size_t)sl]; k < P.csplit[(size_t)sl]; ++k) {
+            const int64_t q = std::lower_bound(u.begin(), u.end(), P.srcslot[(size_t)k]) - u.begin();
+            Tl.coef[(size_t)(64 * (t0 + q / 4) + ((q & 3) << 4) + (sl - r0))] += A.val[(size_t)k];
+          }
+      }
+      // strips to waves: heaviest first onto the lightest of the four waves (a strip costs its tiles + its 4 row loads)
+      int32_t *dsc = &Tl.desc[(size_t)c * kCdDescWords];
+      dsc[20] = (int32_t)sp0[(size_t)c];
+      uint16_t mask[4] = {0, 0, 0, 0};
+      int64_t load[4] = {0, 0, 0, 0}, tiles_w[4] = {0, 0, 0, 0};
+      std::vector<int32_t> order((size_t)S);
+      for (int32_t s = 0; s < S; ++s) order[(size_t)s] = s;
+      auto tiles_of = [&](int32_t s) { return (int64_t)cnt[(size_t)(sp0[(size_t)c] + s + 1)]; };
+      std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return tiles_of(x) > tiles_of(y); });
+      for (int32_t s : order) {
+        int wmin = 0;
+        for (int w_ = 1; w_ < 4; ++w_)
+          if (load[w_] < load[wmin]) wmin = w_;
+        mask[wmin] = (uint16_t)(mask[wmin] | (1u << s));
+        load[wmin] += tiles_of(s) + 2;
+        tiles_w[wmin] += tiles_of(s);
+      }
+      dsc[22] = (int32_t)((uint32_t)mask[0] | ((uint32_t)mask[1] << 16));
+      dsc[23] = (int32_t)((uint32_t)mask[2] | ((uint32_t)mask[3] << 16));
+      wave_max[(size_t)c] = (int32_t)std::max(std::max(tiles_w[0], tiles_w[1]), std::max(tiles_w[2], tiles_w[3]));
+    }
+  });
+  for (int64_t c = 0; c < ngrp; ++c) {
+    if (!is_cd[(size_t)c]) continue;
+    Tl.max_wave_tiles = std::max(Tl.max_wave_tiles, wave_max[(size_t)c]);
+    int32_t &bw = Tl.band_wave_tiles[(size_t)band_of[(size_t)c]];
+    bw = std::max(bw, wave_max[(size_t)c]);
+  }
+}
+inline void build_ct_tiles(const BandPlan &, const Csr<zdouble> &, CtTiles &Tl) { Tl = CtTiles(); }  // (real data only)
+
 // Pass 1 (import time, cheap): cut every candidate band into blocks and lay their MFMA operands out back to
 // back; returns the total number of doubles.  blk_inv_off counts doubles; complex blocks hold two planes.
 template <class T>

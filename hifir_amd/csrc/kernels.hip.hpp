@@ -2888,6 +2888,226 @@ __global__ void __launch_bounds__(256) k_band_cs(int32_t wg0, const int32_t *__r
 }
 
 // ---------------------------------------------------------------------------------------------
+// Component band on coefficient TILES (round 4; host.hpp build_ct_tiles).  Same plan, same launch shape as k_band_cs
+// (blockIdx.x = component-workgroup * nsl + slice of 16 columns, four waves, carried-prefix workgroups behind), but the
+// entries a component reads from rows finished by earlier launches are not walked one by one: per 16-row strip of the
+// component the host has cut the strip's distinct sources into groups of four and written the 16 x 4 coefficient tile of
+// every group; a wave owns whole strips (descriptor words 22 / 23) and spends ONE v_mfma_f64_16x16x4 per tile,
+//     acc[16 rows][16 columns] += coef[16 x 4] * x[4 gathered source rows][16 columns],
+// -- a dozen entries per matrix instruction on the reference's 1M-row hierarchies instead of a dozen instructions per
+// entry -- with the tile's four source rows gathered once (a lane loads the 8 bytes of ITS source row k = lane / 16,
+// column lane % 16: the B operand needs no shuffle, no LDS).  The wave then forms t = rhs - acc for its strips (S1 /
+// the pivot division fused as in k_band_cd) straight into LDS; phase 2, the product with the component's explicit
+// inverse, is k_band_cs's.  Column-separable like every kernel here: a column's bits do not depend on the batch width,
+// so this kernel serves narrow batches (nsl < 4) and full ones alike.  Summation order: tile by tile (tolerance-level).
+// ---------------------------------------------------------------------------------------------
+template <bool LOWER>
+__global__ void __launch_bounds__(256) k_band_ct(int32_t wg0, const int32_t *__restrict__ wg_grp_ptr,
+                                                 const int32_t *__restrict__ ct_desc, const int32_t *__restrict__ ptr,
+                                                 const int32_t *__restrict__ split, const int32_t *__restrict__ col,
+                                                 const double *__restrict__ val, const int32_t *__restrict__ rowid,
+                                                 const double *__restrict__ d, double *w, double *v,
+                                                 const double *__restrict__ tinv, const int32_t *__restrict__ ct_sptr,
+                                                 const int32_t *__restrict__ ct_src, const double *__restrict__ ct_coef,
+                                                 int first_u, int32_t n_band, int32_t nsl, int32_t ps0, int32_t ps1,
+                                                 int32_t single_c0, int32_t lds_rows, int dbg, FirstL<double> fl,
+                                                 LastU<double> lu) {
+  extern __shared__ double cs_buf[];
+  HIFAMD_CSP_DECL
+  HIFAMD_CSP(0)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int32_t nbw = n_band * nsl;
+  if ((int32_t)blockIdx.x >= nbw) {  // carried prefix of the next band over the sources older than this band
+    const int32_t pw = __builtin_amdgcn_readfirstlane(((int32_t)blockIdx.x - nbw) * 4 + wave);
+    if (dbg & 4) return;
+    const double *pf_bin = (LOWER && fl.on()) ? fl.bin.get() : nullptr;
+    trsv_stream_r64<double, 0, LOWER, true>(ps0 + pw, ps1, ((int32_t)gridDim.x - nbw) * 4, ptr, split, col, val, nullptr,
+                                            rowid, d, LOWER ? w : v, w, lane, nullptr, 0, nullptr, true, nullptr, 0, 0, pf_bin, &fl);
+    HIFAMD_CSP(6)
+    HIFAMD_CSP_FLUSH(2 + (LOWER ? 0 : 4) + 32, n_band, nsl)
+    return;
+  }
+  const int32_t bw = (int32_t)blockIdx.x / nsl, slice = (int32_t)blockIdx.x - bw * nsl;
+  const int kq = lane >> 4, l16 = lane & 15;
+  const int cc = slice * 16 + l16;  // this lane's column of the 64-column arena
+  double *x = LOWER ? w : v;
+  const bool div_u = !LOWER && first_u;
+  const bool first_l = LOWER && first_u && fl.on();
+  const double *rhs = div_u ? (const double *)w : (first_l ? fl.bin.get() : (const double *)x);
+  const int64_t rstride = first_l ? fl.ldb : 64;
+  const int rcol = first_l ? min(cc, fl.nrhs - 1) : cc;
+  int32_t c_first, c_last;
+  if (single_c0 >= 0) {
+    c_first = single_c0 + bw;
+    c_last = c_first + 1;
+  } else {
+    c_first = wg_grp_ptr[wg0 + bw];
+    c_last = wg_grp_ptr[wg0 + bw + 1];
+  }
+  // LDS: right-hand sides [lds_rows][16], per row: pivot / scale, output scale, row id, input row, output row; the
+  // component's strip -> tile offsets
+  double *tb = cs_buf;
+  double *s_hd = tb + (size_t)lds_rows * 16;
+  double *s_ot = s_hd + lds_rows;
+  int32_t *s_rowid = reinterpret_cast<int32_t *>(s_ot + lds_rows);
+  int32_t *s_hp = s_rowid + lds_rows;
+  int32_t *s_oi = s_hp + lds_rows;
+  int32_t *s_sptr = s_oi + lds_rows;  // 17 entries (a component has at most 16 strips)
+  const bool last_u = !LOWER && lu.on();
+  double *yout = last_u ? lu.out.get() : nullptr;
+  constexpr int KU = 8;
+  for (int32_t c = c_first; c < c_last; ++c) {
+    const int32_t *dsc = ct_desc + (int64_t)c * 28;
+    const int32_t s0 = dsc[0], nb = dsc[1], sp0 = dsc[20];
+    const int64_t inv_off = ((int64_t)(uint32_t)dsc[5] << 32) | (uint32_t)dsc[4];
+    const uint32_t mword = (uint32_t)dsc[22 + (wave >> 1)];
+    const uint32_t mymask = (wave & 1) ? (mword >> 16) : (mword & 0xffffu);  // the strips this wave owns
+    const int lda = (nb + 31) & ~31;
+    const double *Ac = tinv + inv_off;
+    const int S = (nb + 15) >> 4;
+    double a0[KU], a1[KU];
+    // ---- phase 0: the component's row ids, per-row scalars and strip offsets (coalesced)
+    for (int32_t t = (int32_t)threadIdx.x; t < nb; t += 256) {
+      const int32_t i = rowid[s0 + t];
+      s_rowid[t] = i;
+      if (div_u) s_hd[t] = d[i];
+      if (first_l) {
+        const int32_t pp = fl.p[i];
+        s_hp[t] = pp;
+        s_hd[t] = fl.s[pp];
+      }
+      if (last_u) {
+        const int32_t oi = lu.q[i];
+        s_oi[t] = oi;
+        s_ot[t] = lu.t[oi];
+      }
+    }
+    if ((int32_t)threadIdx.x <= S) s_sptr[threadIdx.x] = ct_sptr[sp0 + (int32_t)threadIdx.x];
+    // phase 2's first operand set does not depend on anything computed here: requested now
+    if (wave < S) {
+      const double *ap_ = Ac + ((int64_t)(S - 1 - wave) * lda) * 16 + l16 + (int64_t)kq * 16;
+#pragma unroll
+      for (int u = 0; u < KU; ++u) a0[u] = ap_[u * 64];
+    }
+    HIFAMD_CSP(1)
+    __syncthreads();
+    HIFAMD_CSP(2)
+    // ---- phase 1: this wave's strips -- right-hand sides requested first, then the strip's tiles four at a time (the
+    // next four source ids and coefficient tiles are in flight while the current four are gathered and multiplied)
+    for (int s = 0; s < S; ++s) {
+      if (!((mymask >> s) & 1u)) continue;  // (wave-uniform)
+      double tr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = min(16 * s + kq + 4 * j, nb - 1);
+        const int32_t i = first_l ? s_hp[row] : s_rowid[row];
+        tr[j] = rhs[(int64_t)i * rstride + rcol];
+      }
+      const int32_t t0 = s_sptr[s], t1 = (dbg & 1) ? t0 : s_sptr[s + 1];
+      v4f64 acc = v4f64{0.0, 0.0, 0.0, 0.0};
+      if (t0 < t1) {
+        int32_t sv[4];
+        double cv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int32_t tt = min(t0 + u, t1 - 1);
+          sv[u] = ct_src[4 * (int64_t)tt + kq];
+          cv[u] = ct_coef[64 * (int64_t)tt + lane];
+          if (t0 + u >= t1) cv[u] = 0.0;
+        }
+        for (int32_t t = t0; t < t1; t += 4) {
+          double bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) bv[u] = x[((int64_t)sv[u] << 6) + cc];
+          int32_t sn[4];
+          double cn[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {  // (clamped: the loads past the strip's last tile read that tile again, weight zero)
+            const int32_t tt = min(t + 4 + u, t1 - 1);
+            sn[u] = ct_src[4 * (int64_t)tt + kq];
+            cn[u] = ct_coef[64 * (int64_t)tt + lane];
+            if (t + 4 + u >= t1) cn[u] = 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sv[u] = sn[u], cv[u] = cn[u];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = 16 * s + kq + 4 * j;
+        if (row < nb) {
+          const double hd = (div_u || first_l) ? s_hd[row] : 1.0;
+          const double t_ = div_u ? tr[j] / hd : (first_l ? (cc < fl.nrhs ? hd * tr[j] : 0.0) : tr[j]);
+          tb[(row << 4) + l16] = t_ - acc[j];
+        }
+      }
+    }
+    // (rows nb .. lda - 1 are zero for the inverse product; lds_rows is a multiple of 32)
+    for (int t = nb * 16 + (int)threadIdx.x; t < lda * 16; t += 256) tb[t] = 0.0;
+    HIFAMD_CSP(4)
+    __syncthreads();
+    HIFAMD_CSP(5)
+    // ---- phase 2: x = Tinv * t on the matrix cores, one 16-row strip x this slice's 16 columns per step; strips are
+    // dealt heaviest first in snake order over the four waves (k_band_cs)
+    for (int rnd = 0;; ++rnd) {
+      const int q = 4 * rnd + ((rnd & 1) ? 3 - wave : wave);
+      if (q >= ((dbg & 2) ? 0 : S)) {
+        if (4 * rnd >= S) break;
+        continue;
+      }
+      const int strip = S - 1 - q;
+      const int kend = min(nb, 16 * (strip + 1));
+      const int nsets = (kend + 31) >> 5;
+      const double *Ap = Ac + ((int64_t)strip * lda) * 16 + l16;
+      const double *Bp = tb + l16;
+      v4f64 acc0 = v4f64{0.0, 0.0, 0.0, 0.0};
+#define HIFAMD_CT_LOAD(aa, t_)                                          \
+  {                                                                     \
+    const double *ap_ = Ap + (int64_t)(32 * (t_) + kq) * 16;            \
+    _Pragma("unroll") for (int u = 0; u < KU; ++u) aa[u] = ap_[u * 64]; \
+  }
+#define HIFAMD_CT_MFMA(aa, t_)                                                \
+  {                                                                           \
+    const int kb_ = 32 * (t_) + kq;                                           \
+    _Pragma("unroll") for (int u = 0; u < KU; ++u) {                          \
+      const double b0_ = Bp[(kb_ + 4 * u) << 4];                              \
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[u], b0_, acc0, 0, 0, 0); \
+    }                                                                         \
+  }
+      int t = 0;
+      if (rnd != 0) HIFAMD_CT_LOAD(a0, 0)  // (the first strip's first set was requested before phase 1)
+      while (t < nsets) {
+        if (t + 1 < nsets) HIFAMD_CT_LOAD(a1, t + 1)
+        HIFAMD_CT_MFMA(a0, t)
+        if (t + 1 >= nsets) break;
+        if (t + 2 < nsets) HIFAMD_CT_LOAD(a0, t + 2)
+        HIFAMD_CT_MFMA(a1, t + 1)
+        t += 2;
+      }
+#undef HIFAMD_CT_LOAD
+#undef HIFAMD_CT_MFMA
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * strip + kq + 4 * r;
+        if (row < nb) {
+          if (last_u) {
+            if (cc < lu.nrhs) yout[(int64_t)s_oi[row] * lu.ldy + cc] = s_ot[row] * acc0[r];
+          } else {
+            x[((int64_t)s_rowid[row] << 6) + cc] = acc0[r];
+          }
+        }
+      }
+    }
+    __syncthreads();  // (the next component overwrites the LDS block)
+  }
+  HIFAMD_CSP(6)
+  HIFAMD_CSP_FLUSH(1 + (LOWER ? 0 : 4) + 32, n_band, nsl)
+}
+
+// ---------------------------------------------------------------------------------------------
 // Column-sliced component band for COMPLEX data (round 3): k_band_cd_z for ONE slice of 16 complex columns per
 // workgroup (blockIdx.x = component-workgroup * nsl + slice), the complex twin of k_band_cs.  A batch of at most 48
 // columns launches only the slices it has: BASELINE config 5 (nrhs = 16) moves a quarter of the vector bytes and
