@@ -56,7 +56,7 @@ for j in range(L_):
             gs.append((int(q["Start_Timestamp"]) - int(rows[a + j - 1]["End_Timestamp"])) / 1e3)
     q = rows[wins[0][0] + j]
     kn = q["Kernel_Name"].replace("void hifamd::", "").replace("hifamd::", "")
-    kn = kn.split("(")[0]
+    kn = kn.split("(")[0].replace(" ", "")
     wg = int(q["Workgroup_Size_X"])
     d = statistics.median(ds)
     g = statistics.median(gs) if gs else 0.0
