@@ -153,12 +153,10 @@ struct DevCsr {
   DevBuf f_desc, f_col, f_val, f_lrow;  // L only: the streams with the level's F entries appended (host.hpp build_cd_streams_fused)
   bool f_fused = false;
   // tile form of the dense-own component bands' walked entries (host.hpp build_ct_tiles, kernel k_band_ct)
-  DevBuf ct_desc, ct_src, ct_coef;  // walked entries [split, csplit)
-  DevBuf cc_desc, cc_src, cc_coef;  // carried entries [ptr, split) of the bands with a carried prefix
+  DevBuf ct_desc, ct_sptr, ct_src, ct_coef;
   bool ct_on = false;
   int64_t ct_tiles = 0;
-  std::vector<int32_t> band_wave_tiles;  // per band: most tiles one wave of one component multiplies
-  int64_t cc_tiles = 0;
+  std::vector<int32_t> band_wave_tiles;  // per band: most tiles one wave of one component walks
   bool cd_sparse = false;
   std::vector<int32_t> band_chunk_max;  // component bands: most entries of one wave chunk of the band (the serial walk of its slowest wave)
   int32_t own_cap = kCdOwnCap;  // sparse-own plans: most own nonzeros of one component, rounded up to 64 (sizes the kernels' LDS)
@@ -202,10 +200,7 @@ struct DevCsr {
     f_lrow.alias(o.f_lrow);
     f_fused = o.f_fused;
     ct_desc.alias(o.ct_desc);
-    cc_desc.alias(o.cc_desc);
-    cc_src.alias(o.cc_src);
-    cc_coef.alias(o.cc_coef);
-    cc_tiles = o.cc_tiles;
+    ct_sptr.alias(o.ct_sptr);
     ct_src.alias(o.ct_src);
     ct_coef.alias(o.ct_coef);
     ct_on = o.ct_on;
@@ -852,19 +847,15 @@ class Engine : public EngineBase {
     if (ct_mode && sizeof(T) == sizeof(double) && band_opt.dense_block > 0 && !P.cd_sparse && !P.band_cd.empty()) {
       // dense-own component bands: the entries a component reads from older rows as 16 x 4 coefficient tiles (k_band_ct)
       CtTiles Tl;
-      build_ct_tiles(P, A, false, Tl);
-      if (!Tl.desc.empty()) {
-        M.ct_desc.upload(Tl.desc, 32);
+      build_ct_tiles(P, A, Tl);
+      if (Tl.ntiles > 0 || !Tl.desc.empty()) {
+        M.ct_desc.upload(Tl.desc);
+        M.ct_sptr.upload(Tl.sptr, 8);
         M.ct_src.upload(Tl.src, 64);
         M.ct_coef.upload(Tl.coef, 512);
         M.ct_on = true;
         M.ct_tiles = Tl.ntiles;
         M.band_wave_tiles = Tl.band_wave_tiles;
-        build_ct_tiles(P, A, true, Tl);
-        M.cc_desc.upload(Tl.desc, 32);
-        M.cc_src.upload(Tl.src, 64);
-        M.cc_coef.upload(Tl.coef, 512);
-        M.cc_tiles = Tl.ntiles;
       }
     }
     if (!total_elems) return;
@@ -1516,7 +1507,7 @@ class Engine : public EngineBase {
   // LDS of k_band_ct: right-hand sides [rows][16], per row two doubles and three int32, 17 strip offsets
   size_t ct_lds_bytes(int nct) const {
     const size_t rows = (size_t)cd_lds_rows(false);
-    return rows * (16 * (size_t)nct + 2) * sizeof(double) + 64 * 16 * (size_t)nct * sizeof(double) + rows * 3 * sizeof(int32_t) + 64;
+    return rows * (16 * (size_t)nct + 2) * sizeof(double) + rows * 3 * sizeof(int32_t) + 32 * sizeof(int32_t);
   }
   // v_tail = G c_tail (build_tail_operator); the product reads up to 31 rows behind c_tail: they lie inside the level's
   // arena (v follows w) and meet zero columns of the operand
@@ -1563,19 +1554,13 @@ class Engine : public EngineBase {
         const int ncols = (act_cols + 15) / 16;  // column tiles in use
         const int nct = (ncols >= 2 && g1 - g0 > ct_wide_wgs) ? 2 : 1;
         const int nslc = (ncols + nct - 1) / nct;
-        // the carried prefix of the next band: its component workgroups x slices, behind this band's own
-        int32_t wg1 = 0, n_next = 0;
-        if (extra) {
-          wg1 = g1;
-          n_next = M.band_wg_ptr[band + 2] - g1;
-        }
-        const unsigned grid = (unsigned)(((g1 - g0 + 7) / 8) * 8 * nslc) + (unsigned)(n_next * nslc);
+        const unsigned grid = (unsigned)(((g1 - g0 + 7) / 8) * 8 * nslc) + 4 * extra;
         auto kct = nct == 2 ? k_band_ct<LOWER, 2> : k_band_ct<LOWER, 1>;
-        const CtSet own{M.ct_desc.as<int32_t>(), M.ct_src.as<int32_t>(), M.ct_coef.as<double>()};
-        const CtSet car{M.cc_desc.as<int32_t>(), M.cc_src.as<int32_t>(), M.cc_coef.as<double>()};
-        hipLaunchKernelGGL(kct, dim3(grid), dim3(256), ct_lds_bytes(nct), st, g0, M.wg_grp_ptr.as<int32_t>(), M.cd_desc.as<int32_t>(),
-                           M.rowid.as<int32_t>(), L.d.as<double>(), L.w.as<double>(), L.v.as<double>(), M.tinv.as<double>(), own, car,
-                           pre ? 0 : 1, (int32_t)(g1 - g0), (int32_t)nslc, wg1, n_next, single_c0, lds_rows,
+        hipLaunchKernelGGL(kct, dim3(grid), dim3(256), ct_lds_bytes(nct), st, g0,
+                           M.wg_grp_ptr.as<int32_t>(), M.ct_desc.as<int32_t>(), M.ptr.as<int32_t>(), M.split.as<int32_t>(),
+                           M.col.as<int32_t>(), M.val.as<double>(), M.rowid.as<int32_t>(), L.d.as<double>(), L.w.as<double>(),
+                           L.v.as<double>(), M.tinv.as<double>(), M.ct_sptr.as<int32_t>(), M.ct_src.as<int32_t>(),
+                           M.ct_coef.as<double>(), pre ? 0 : 1, (int32_t)(g1 - g0), (int32_t)nslc, ps0, ps1, single_c0, lds_rows,
                            cd_dbg | (no_walk ? 1 : 0), fl, lu);
         return;
       }

@@ -950,146 +950,124 @@ inline void build_cd_streams(BandPlan &P, const std::vector<int32_t> &aptr /* ro
 // lacks the source), B = the four gathered source rows.  Every distinct source of a strip is gathered once, and the
 // entry walk of k_band_cd (a dozen vector / scalar instructions per entry and wave) becomes one matrix instruction per
 // dozen entries.  The summation order differs from the row loops' (tolerance-level; fast mode only).
-// The tiles of a component lie strip by strip, every strip padded with zero tiles to whole BATCHES of kCtBatch tiles; the
-// batches are cut into four equal contiguous ranges, one per wave of the kernel, so that a wave runs ONE software-
-// pipelined stream; a strip that straddles a cut is finished by the wave that holds its FIRST part, the later parts
-// (always the first segment of their wave: "continuations") are added from LDS in wave order (deterministic).
-// Two tile sets exist per triangle: WALKED = the entries [split, csplit) a band's own launch reads (sources in the
-// previous band, or everything older when nothing was carried), CARRIED = the entries [ptr, split) of a band with a
-// carried prefix (sources older than the previous band), multiplied by extra workgroups of the PREVIOUS band's launch.
-//   desc  : kCtDescWords int32 per component: [0] first tile; [1..5] batch offsets of the four waves (+ end), relative;
-//           [6] segments per wave (4 bytes); [7] bit w: wave w's first segment continues a strip of the wave before;
-//           [8 + 4 w ..] wave w's segments, 8 x uint16 = strip << 12 | batches
+//   sptr  : per component S + 1 tile offsets (S = strips of the component), block of component c at desc word 20
 //   src   : 4 source ROW numbers per tile (a short last group repeats its last source with zero coefficients)
 //   coef  : 64 per tile, element (k << 4) | r = coefficient of row 16 s + r for source k
+//   desc words 22, 23: four uint16 masks -- the strips each of the kernel's four waves owns (balanced by tiles)
 // ---------------------------------------------------------------------------------------------
-constexpr int kCtDescWords = 24, kCtBatch = 4;
 struct CtTiles {
-  std::vector<int32_t> desc, src;
+  std::vector<int32_t> sptr, src;
   std::vector<double> coef;
+  std::vector<int32_t> desc;  // copy of BandPlan::cd_desc with words 20, 22, 23 filled for the dense-own components
   int64_t ntiles = 0;
-  std::vector<int32_t> band_wave_tiles;  // per band: most tiles one wave of one component multiplies
+  int32_t max_wave_tiles = 0;  // most tiles one wave of one component walks (the serial part of a band)
+  std::vector<int32_t> band_wave_tiles;  // ... per band
 };
 
-inline void build_ct_tiles(const BandPlan &P, const Csr<double> &A /* slot order */, bool carried, CtTiles &Tl) {
+inline void build_ct_tiles(const BandPlan &P, const Csr<double> &A /* slot order */, CtTiles &Tl) {
   Tl = CtTiles();
   if (P.band_cd.empty() || P.cd_sparse || P.cd_desc.empty()) return;
+  Tl.desc = P.cd_desc;
   const int64_t ngrp = (int64_t)P.grp_slot_ptr.size() - 1;
+  // which components take part, their strips, and (pass 1) the tiles of every strip
+  std::vector<uint8_t> is_cd((size_t)ngrp, 0);
+  Tl.band_wave_tiles.assign((size_t)P.nbands(), 0);
   std::vector<int32_t> band_of((size_t)ngrp, -1);
   for (int64_t b = 0; b < P.nbands(); ++b) {
     if (!P.band_cd[(size_t)b]) continue;
-    if (carried && (P.band_fused.empty() || !P.band_fused[(size_t)b])) continue;
-    for (int32_t c = P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b]]; c < P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b + 1]]; ++c) {
-      band_of[(size_t)c] = (int32_t)b;
-      if (P.grp_slot_ptr[(size_t)c + 1] - P.grp_slot_ptr[(size_t)c] > 256)
-        throw Error(4, "internal error: component with more than 16 strips");
-    }
+    for (int32_t c = P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b]]; c < P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b + 1]]; ++c)
+      is_cd[(size_t)c] = 1, band_of[(size_t)c] = (int32_t)b;
   }
-  auto k_lo = [&](int32_t sl) { return carried ? A.ptr[(size_t)sl] : P.split[(size_t)sl]; };
-  auto k_hi = [&](int32_t sl) { return carried ? P.split[(size_t)sl] : P.csplit[(size_t)sl]; };
+  std::vector<int64_t> sp0((size_t)ngrp + 1, 0);  // first sptr entry of every component
+  for (int64_t c = 0; c < ngrp; ++c) {
+    const int32_t nb = P.grp_slot_ptr[(size_t)c + 1] - P.grp_slot_ptr[(size_t)c];
+    sp0[(size_t)c + 1] = sp0[(size_t)c] + (is_cd[(size_t)c] ? (nb + 15) / 16 + 1 : 0);
+  }
+  if (sp0[(size_t)ngrp] > (int64_t)std::numeric_limits<int32_t>::max()) throw Error(4, "component tile index overflows int32");
+  std::vector<int32_t> cnt((size_t)sp0[(size_t)ngrp], 0);  // tiles per strip (slot s + 1 of the component's block)
   auto strip_sources = [&](int32_t r0, int32_t r1, std::vector<int32_t> &u) {  // distinct source slots, ascending
     u.clear();
     for (int32_t s = r0; s < r1; ++s)
-      for (int32_t k = k_lo(s); k < k_hi(s); ++k) u.push_back(P.srcslot[(size_t)k]);
+      for (int32_t k = P.split[(size_t)s]; k < P.csplit[(size_t)s]; ++k) u.push_back(P.srcslot[(size_t)k]);
     std::sort(u.begin(), u.end());
     u.erase(std::unique(u.begin(), u.end()), u.end());
   };
-  // pass 1: batches per strip, the four waves' ranges and segment lists
-  Tl.desc.assign((size_t)ngrp * kCtDescWords, 0);
-  std::vector<int32_t> sbat((size_t)ngrp * 17, 0);  // first batch of strip s (+ end), relative to the component
-  std::vector<int64_t> comp_bat((size_t)ngrp + 1, 0);
+  parallel_for(ngrp, 64, [&](int64_t c0, int64_t c1) {
+    std::vector<int32_t> u;
+    for (int64_t c = c0; c < c1; ++c) {
+      if (!is_cd[(size_t)c]) continue;
+      const int32_t a = P.grp_slot_ptr[(size_t)c], e = P.grp_slot_ptr[(size_t)c + 1];
+      for (int32_t r0 = a, s = 0; r0 < e; r0 += 16, ++s) {
+        strip_sources(r0, std::min(e, r0 + 16), u);
+        cnt[(size_t)(sp0[(size_t)c] + s + 1)] = (int32_t)((u.size() + 3) / 4);
+      }
+    }
+  });
+  // absolute tile offsets
+  Tl.sptr.assign(cnt.size(), 0);
+  int64_t total = 0;
+  for (int64_t c = 0; c < ngrp; ++c) {
+    if (!is_cd[(size_t)c]) continue;
+    const int64_t b0 = sp0[(size_t)c], b1 = sp0[(size_t)c + 1];
+    for (int64_t q = b0; q < b1; ++q) {
+      total += cnt[(size_t)q];  // (cnt[b0] == 0: the block's first entry is the component's first tile)
+      if (total > (int64_t)std::numeric_limits<int32_t>::max() / 64) throw Error(4, "component tile index overflows int32");
+      Tl.sptr[(size_t)q] = (int32_t)total;
+    }
+  }
+  Tl.ntiles = total;
+  Tl.src.assign((size_t)(4 * total), 0);
+  Tl.coef.assign((size_t)(64 * total), 0.0);
   std::vector<int32_t> wave_max((size_t)ngrp, 0);
   parallel_for(ngrp, 64, [&](int64_t c0, int64_t c1) {
     std::vector<int32_t> u;
     for (int64_t c = c0; c < c1; ++c) {
-      if (band_of[(size_t)c] < 0) continue;
+      if (!is_cd[(size_t)c]) continue;
       const int32_t a = P.grp_slot_ptr[(size_t)c], e = P.grp_slot_ptr[(size_t)c + 1];
       const int32_t S = (e - a + 15) / 16;
-      int32_t *sb = &sbat[(size_t)(17 * c)];
-      for (int32_t r0 = a, s = 0; r0 < e; r0 += 16, ++s) {
-        strip_sources(r0, std::min(e, r0 + 16), u);
-        sb[s + 1] = sb[s] + (int32_t)((u.size() + 4 * kCtBatch - 1) / (4 * kCtBatch));
-      }
-      const int32_t nbt = sb[S];
-      int32_t *dsc = &Tl.desc[(size_t)c * kCtDescWords];
-      // equal ranges; a cut is moved to a strip boundary when one lies within an eighth of a range (fewer continuations);
-      // a wave takes at most 8 segments
-      int32_t cut[5] = {0, 0, 0, 0, nbt};
-      for (int w_ = 1; w_ < 4; ++w_) {
-        int32_t ideal = (int32_t)(((int64_t)nbt * w_ + 2) / 4);
-        int32_t best = ideal;
-        for (int32_t s = 0; s <= S; ++s)
-          if (std::abs(sb[s] - ideal) * 8 <= std::max(1, nbt / 4) && (best == ideal || std::abs(sb[s] - ideal) < std::abs(best - ideal))) best = sb[s];
-        cut[w_] = std::max(cut[w_ - 1], std::min(best, nbt));
-      }
-      uint32_t nsegs = 0, contm = 0;
-      int32_t wmax = 0;
-      for (int w_ = 0; w_ < 4; ++w_) {
-        uint16_t *seg = reinterpret_cast<uint16_t *>(&dsc[8 + 4 * w_]);
-        int ns = 0;
-        int32_t at = cut[w_];
-        for (int32_t s = 0; s < S && at < cut[w_ + 1]; ++s) {
-          if (sb[s + 1] <= at) continue;
-          if (ns == 8) {  // (cannot take more strips: the range ends here, the next wave starts here)
-            for (int q = w_ + 1; q < 4; ++q) cut[q] = std::max(cut[q], at);
-            if (w_ == 3) throw Error(4, "internal error: tile stream with more than 32 segments");
-            cut[w_ + 1] = at;
-            break;
-          }
-          const int32_t hi = std::min(sb[s + 1], cut[w_ + 1]);
-          if (ns == 0 && at > sb[s]) contm |= 1u << w_;
-          seg[ns++] = (uint16_t)(((uint32_t)s << 12) | (uint32_t)(hi - at));
-          if (hi - at > 4095) throw Error(4, "internal error: strip with too many coefficient tiles");
-          at = hi;
-        }
-        dsc[1 + w_] = cut[w_];
-        nsegs |= (uint32_t)ns << (8 * w_);
-        wmax = std::max(wmax, cut[w_ + 1] - cut[w_]);
-      }
-      dsc[5] = nbt;
-      dsc[6] = (int32_t)nsegs;
-      dsc[7] = (int32_t)contm;
-      comp_bat[(size_t)c + 1] = nbt;
-      wave_max[(size_t)c] = wmax * kCtBatch;
-    }
-  });
-  for (int64_t c = 0; c < ngrp; ++c) comp_bat[(size_t)c + 1] += comp_bat[(size_t)c];
-  const int64_t total = comp_bat[(size_t)ngrp] * kCtBatch;
-  if (total > (int64_t)std::numeric_limits<int32_t>::max() / 64) throw Error(4, "component tile index overflows int32");
-  Tl.ntiles = total;
-  Tl.src.assign((size_t)(4 * total), 0);
-  Tl.coef.assign((size_t)(64 * total), 0.0);
-  parallel_for(ngrp, 64, [&](int64_t c0, int64_t c1) {
-    std::vector<int32_t> u;
-    for (int64_t c = c0; c < c1; ++c) {
-      if (band_of[(size_t)c] < 0) continue;
-      const int32_t a = P.grp_slot_ptr[(size_t)c], e = P.grp_slot_ptr[(size_t)c + 1];
-      const int64_t tile0 = comp_bat[(size_t)c] * kCtBatch;
-      Tl.desc[(size_t)c * kCtDescWords] = (int32_t)tile0;
-      const int32_t *sb = &sbat[(size_t)(17 * c)];
       for (int32_t r0 = a, s = 0; r0 < e; r0 += 16, ++s) {
         const int32_t r1 = std::min(e, r0 + 16);
         strip_sources(r0, r1, u);
-        const int64_t t0 = tile0 + (int64_t)kCtBatch * sb[s];
-        const int64_t nt = (int64_t)kCtBatch * (sb[s + 1] - sb[s]);
-        for (int64_t q = 0; q < 4 * nt; ++q)  // source ROW numbers (what the kernel gathers from); padding repeats the last one
-          Tl.src[(size_t)(4 * t0 + q)] = u.empty() ? 0 : A.rowid[(size_t)u[(size_t)std::min<int64_t>(q, (int64_t)u.size() - 1)]];
+        const int64_t t0 = Tl.sptr[(size_t)(sp0[(size_t)c] + s)];
+        const int64_t nt = ((int64_t)u.size() + 3) / 4;
+        for (int64_t q = 0; q < 4 * nt; ++q)  // source ROW numbers (what the kernel gathers from), short group padded
+          Tl.src[(size_t)(4 * t0 + q)] = A.rowid[(size_t)u[(size_t)std::min<int64_t>(q, (int64_t)u.size() - 1)]];
         for (int32_t sl = r0; sl < r1; ++sl)
-          for (int32_t k = k_lo(sl); k < k_hi(sl); ++k) {
+          for (int32_t k = P.split[(size_t)sl]; k < P.csplit[(size_t)sl]; ++k) {
             const int64_t q = std::lower_bound(u.begin(), u.end(), P.srcslot[(size_t)k]) - u.begin();
             Tl.coef[(size_t)(64 * (t0 + q / 4) + ((q & 3) << 4) + (sl - r0))] += A.val[(size_t)k];
           }
       }
+      // strips to waves: heaviest first onto the lightest of the four waves (a strip costs its tiles + its 4 row loads)
+      int32_t *dsc = &Tl.desc[(size_t)c * kCdDescWords];
+      dsc[20] = (int32_t)sp0[(size_t)c];
+      uint16_t mask[4] = {0, 0, 0, 0};
+      int64_t load[4] = {0, 0, 0, 0}, tiles_w[4] = {0, 0, 0, 0};
+      std::vector<int32_t> order((size_t)S);
+      for (int32_t s = 0; s < S; ++s) order[(size_t)s] = s;
+      auto tiles_of = [&](int32_t s) { return (int64_t)cnt[(size_t)(sp0[(size_t)c] + s + 1)]; };
+      std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return tiles_of(x) > tiles_of(y); });
+      for (int32_t s : order) {
+        int wmin = 0;
+        for (int w_ = 1; w_ < 4; ++w_)
+          if (load[w_] < load[wmin]) wmin = w_;
+        mask[wmin] = (uint16_t)(mask[wmin] | (1u << s));
+        load[wmin] += tiles_of(s) + 2;
+        tiles_w[wmin] += tiles_of(s);
+      }
+      dsc[22] = (int32_t)((uint32_t)mask[0] | ((uint32_t)mask[1] << 16));
+      dsc[23] = (int32_t)((uint32_t)mask[2] | ((uint32_t)mask[3] << 16));
+      wave_max[(size_t)c] = (int32_t)std::max(std::max(tiles_w[0], tiles_w[1]), std::max(tiles_w[2], tiles_w[3]));
     }
   });
-  Tl.band_wave_tiles.assign((size_t)P.nbands(), 0);
-  for (int64_t c = 0; c < ngrp; ++c)
-    if (band_of[(size_t)c] >= 0) {
-      int32_t &bw = Tl.band_wave_tiles[(size_t)band_of[(size_t)c]];
-      bw = std::max(bw, wave_max[(size_t)c]);
-    }
+  for (int64_t c = 0; c < ngrp; ++c) {
+    if (!is_cd[(size_t)c]) continue;
+    Tl.max_wave_tiles = std::max(Tl.max_wave_tiles, wave_max[(size_t)c]);
+    int32_t &bw = Tl.band_wave_tiles[(size_t)band_of[(size_t)c]];
+    bw = std::max(bw, wave_max[(size_t)c]);
+  }
 }
-inline void build_ct_tiles(const BandPlan &, const Csr<zdouble> &, bool, CtTiles &Tl) { Tl = CtTiles(); }  // (real data only)
+inline void build_ct_tiles(const BandPlan &, const Csr<zdouble> &, CtTiles &Tl) { Tl = CtTiles(); }  // (real data only)
 
 // Pass 1 (import time, cheap): cut every candidate band into blocks and lay their MFMA operands out back to
 // back; returns the total number of doubles.  blk_inv_off counts doubles; complex blocks hold two planes.

@@ -2901,286 +2901,174 @@ __global__ void __launch_bounds__(256) k_band_cs(int32_t wg0, const int32_t *__r
 // inverse, is k_band_cs's.  Column-separable like every kernel here: a column's bits do not depend on the batch width,
 // so this kernel serves narrow batches (nsl < 4) and full ones alike.  Summation order: tile by tile (tolerance-level).
 // ---------------------------------------------------------------------------------------------
-// per-triangle arrays of one tile set (host.hpp CtTiles)
-struct CtSet {
-  const int32_t *desc;
-  const int32_t *src;
-  const double *coef;
-};
-
-// One wave's tile stream of one component (host.hpp build_ct_tiles: a contiguous range of the component's batches of four
-// tiles, strip by strip).  A ring of R batches: source ids and coefficient tiles travel R - 1 batches ahead of the matrix
-// instructions, the gathered source rows R - 2.  The loop body holds NO branch around a global access (loads past the
-// stream's end are clamped to its last tile and their batches not multiplied): hipcc then counts its s_waitcnt vmcnt
-// exactly and the ring really stays in flight -- with a load or store inside a conditional block it drains the ring
-// (vmcnt(0)) at every merge of paths, which is what a first version measured.  At the end of a strip's batches the
-// strip's 16 x 16 sums are subtracted from its right-hand sides in LDS (tb, filled by the caller) -- or, for a wave whose
-// first segment CONTINUES a strip of the wave before, stored to that wave's partial block pb (the caller adds the
-// partials in wave order behind a barrier); those branches touch LDS only.
-// ct_stream_begin issues the first loads (call it as early as possible), ct_stream_run does the rest.
-template <int NCT, int R>
-struct CtRing {
-  int32_t sv[2 * R][4];  // source ids: a ring twice as deep (they are needed when the GATHER is issued, not when it returns)
-  double cv[R][4], bv[R][NCT][4];
-  int32_t tbeg, nbt, tlast;
-  int touched;
-};
-#define HIFAMD_CT_SRC(slot, bi_)                                             \
-  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                            \
-    const int32_t tt = min(rg.tbeg + 4 * (bi_) + u, rg.tlast);               \
-    rg.sv[slot][u] = ct_src[4 * (int64_t)tt + kq];                           \
-  }
-#define HIFAMD_CT_GATHER(slot, slot2, bi_)                                   \
-  _Pragma("unroll") for (int u = 0; u < 4; ++u) {                            \
-    const int32_t tt = min(rg.tbeg + 4 * (bi_) + u, rg.tlast);               \
-    rg.cv[slot][u] = ct_coef[64 * (int64_t)tt + lane];                       \
-    _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct) rg.bv[slot][ct][u] = x[((int64_t)rg.sv[slot2][u] << 6) + cc + 16 * ct]; \
-  }
-template <int NCT, int R>
-__device__ __forceinline__ void ct_stream_begin(CtRing<NCT, R> &rg, const int32_t *__restrict__ ctd, int wave,
-                                                const int32_t *__restrict__ ct_src, const double *__restrict__ ct_coef,
-                                                int kq, int lane, bool no_tiles, bool touch) {
-  rg.tbeg = ctd[0] + 4 * ctd[1 + wave];
-  rg.nbt = no_tiles ? 0 : ctd[2 + wave] - ctd[1 + wave];  // batches of this wave
-  rg.tlast = rg.tbeg + max(4 * rg.nbt - 1, 0);
-  rg.touched = 0;
-  if (rg.nbt > 0) {
-    // every 128-byte line of this wave's coefficient tiles is touched once, now: the stream below then meets the L2
-    // instead of paying an HBM round trip per batch (one wave cannot hide that latency behind four matrix instructions)
-    if (touch) {
-      const char *tc = reinterpret_cast<const char *>(ct_coef + 64 * (int64_t)rg.tbeg);
-      const int32_t nl = rg.nbt * 16;
-      for (int32_t o = lane; o < nl; o += 64) rg.touched += *reinterpret_cast<const int *>(tc + (int64_t)o * 128);
-    }
-#pragma unroll
-    for (int q = 0; q < 2 * R - 2; ++q) HIFAMD_CT_SRC(q, q)
-  }
-}
-template <int NCT, int R>
-__device__ __forceinline__ void ct_stream_run(CtRing<NCT, R> &rg, const int32_t *__restrict__ ctd, int wave,
-                                              const int32_t *__restrict__ ct_src, const double *__restrict__ ct_coef,
-                                              const double *__restrict__ x, int cc, int kq, int lane, double *tb, double *pb) {
-  constexpr int W = 16 * NCT;
-  const int l16 = lane & 15;
-  const int32_t nbt = rg.nbt;
-  if (nbt <= 0) return;
-  const int nseg = (int)(((uint32_t)ctd[6] >> (8 * wave)) & 0xffu);
-  const uint32_t sw0 = (uint32_t)ctd[8 + 4 * wave], sw1 = (uint32_t)ctd[9 + 4 * wave], sw2 = (uint32_t)ctd[10 + 4 * wave],
-                 sw3 = (uint32_t)ctd[11 + 4 * wave];
-  bool cont = (((uint32_t)ctd[7] >> wave) & 1u) != 0;  // the first segment goes to pb
-  int seg = 0, strip = 0;
-  int32_t seg_end = 0;
-  v4f64 acc[NCT];
-#pragma unroll
-  for (int ct = 0; ct < NCT; ++ct) acc[ct] = v4f64{0.0, 0.0, 0.0, 0.0};
-#define HIFAMD_CT_OPEN()                                                                                        \
-  {                                                                                                             \
-    if (seg < nseg) {                                                                                           \
-      const uint32_t wsel = (seg >> 1) == 0 ? sw0 : ((seg >> 1) == 1 ? sw1 : ((seg >> 1) == 2 ? sw2 : sw3));   \
-      const uint32_t sg = (wsel >> (16 * (seg & 1))) & 0xffffu;                                                 \
-      strip = (int)(sg >> 12);                                                                                  \
-      seg_end += (int32_t)(sg & 0xfffu);                                                                        \
-    } else {                                                                                                    \
-      seg_end = 0x7fffffff;                                                                                     \
-    }                                                                                                           \
-  }
-  HIFAMD_CT_OPEN()
-#pragma unroll
-  for (int q = 0; q < R - 2; ++q) HIFAMD_CT_GATHER(q, q, q)
-#define HIFAMD_CT_STEP(i)                                                                                         \
-  {                                                                                                               \
-    const int32_t bi = b + (i);                                                                                   \
-    HIFAMD_CT_SRC(((i) + 2 * R - 2) % (2 * R), bi + 2 * R - 2)                                                    \
-    HIFAMD_CT_GATHER(((i) + R - 2) % R, ((i) + R - 2) % (2 * R), bi + R - 2)                                      \
-    if (bi < nbt) {                                                                                               \
-      _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                               \
-      _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct)                                                          \
-        acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(rg.cv[(i) % R][u], rg.bv[(i) % R][ct][u], acc[ct], 0, 0, 0); \
-    }                                                                                                             \
-    if (bi + 1 == seg_end) { /* the segment's last batch */                                                       \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                               \
-      _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct) {                                                        \
-        if (cont) {                                                                                               \
-          pb[(kq + 4 * j) * W + 16 * ct + l16] = acc[ct][j];                                                      \
-        } else {                                                                                                  \
-          double *tp = tb + (16 * strip + kq + 4 * j) * W + 16 * ct + l16;                                        \
-          *tp = *tp - acc[ct][j];                                                                                 \
-        }                                                                                                         \
-        acc[ct][j] = 0.0;                                                                                         \
-      }                                                                                                           \
-      cont = false;                                                                                               \
-      ++seg;                                                                                                      \
-      HIFAMD_CT_OPEN()                                                                                            \
-    }                                                                                                             \
-  }
-  for (int32_t b = 0; b < nbt; b += 2 * R) {  // (2 R steps per trip: the slots of both rings are compile-time constants)
-    HIFAMD_CT_STEP(0)
-    HIFAMD_CT_STEP(1)
-    HIFAMD_CT_STEP(2)
-    HIFAMD_CT_STEP(3)
-    HIFAMD_CT_STEP(4)
-    HIFAMD_CT_STEP(5)
-    if constexpr (R == 4) {
-      HIFAMD_CT_STEP(6)
-      HIFAMD_CT_STEP(7)
-    }
-  }
-#undef HIFAMD_CT_STEP
-#undef HIFAMD_CT_OPEN
-}
-#undef HIFAMD_CT_SRC
-#undef HIFAMD_CT_GATHER
-
 template <bool LOWER, int NCT>
-__global__ void __launch_bounds__(256, 2) k_band_ct(int32_t wg0, const int32_t *__restrict__ wg_grp_ptr,
-                                                    const int32_t *__restrict__ cd_desc, const int32_t *__restrict__ rowid,
-                                                    const double *__restrict__ d, double *w, double *v,
-                                                    const double *__restrict__ tinv, CtSet own, CtSet car, int first_u,
-                                                    int32_t n_band, int32_t nsl, int32_t wg1, int32_t n_next, int32_t single_c0,
-                                                    int32_t lds_rows, int dbg, FirstL<double> fl, LastU<double> lu) {
+__global__ void __launch_bounds__(256) k_band_ct(int32_t wg0, const int32_t *__restrict__ wg_grp_ptr,
+                                                 const int32_t *__restrict__ ct_desc, const int32_t *__restrict__ ptr,
+                                                 const int32_t *__restrict__ split, const int32_t *__restrict__ col,
+                                                 const double *__restrict__ val, const int32_t *__restrict__ rowid,
+                                                 const double *__restrict__ d, double *w, double *v,
+                                                 const double *__restrict__ tinv, const int32_t *__restrict__ ct_sptr,
+                                                 const int32_t *__restrict__ ct_src, const double *__restrict__ ct_coef,
+                                                 int first_u, int32_t n_band, int32_t nsl, int32_t ps0, int32_t ps1,
+                                                 int32_t single_c0, int32_t lds_rows, int dbg, FirstL<double> fl,
+                                                 LastU<double> lu) {
   extern __shared__ double cs_buf[];
   HIFAMD_CSP_DECL
   HIFAMD_CSP(0)
-  constexpr int W = 16 * NCT;  // columns of this workgroup's slice
-  constexpr int R = NCT == 1 ? 4 : 3;
+  constexpr int W = 16 * NCT;           // columns of this workgroup's slice
+  constexpr int BU = NCT == 1 ? 8 : 4;  // tiles per batch (one batch in flight ahead of the one being multiplied)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int kq = lane >> 4, l16 = lane & 15;
-  double *x = LOWER ? w : v;
   // blocks [0, nbp): component-workgroup x slice, laid out so that the slices of a component sit 8 blocks apart (blocks
   // are dealt round-robin over the eight XCDs: the slices then share one L2 -- the component's tiles and inverse are
-  // fetched from HBM once; placement is a speed matter only); blocks behind them: the CARRIED prefix of the next band --
-  // workgroup (component-workgroup of that band) x slice multiplies the tiles of the entries whose sources are older than
-  // THIS band and does the rows' first touch, x[row] = (S1: s[p] b[p] | U: w / d | x[row]) - tiles, exactly what the
-  // carried k_trsv_wide<PREFIX> rows of k_band_cd delivered; nothing there depends on this launch
+  // fetched from HBM once; placement is a speed matter only)
   const int32_t nbp = ((n_band + 7) >> 3) * 8 * nsl;
-  const bool carried = (int32_t)blockIdx.x >= nbp;
-  int32_t bw, slice;
-  if (carried) {
+  if ((int32_t)blockIdx.x >= nbp) {  // carried prefix of the next band over the sources older than this band
+    const int32_t pw = __builtin_amdgcn_readfirstlane(((int32_t)blockIdx.x - nbp) * 4 + wave);
     if (dbg & 4) return;
-    const int32_t idx = (int32_t)blockIdx.x - nbp;
-    bw = idx / nsl;
-    slice = idx - bw * nsl;
-    if (bw >= n_next) return;
-  } else {
-    const int32_t bgrp = (int32_t)blockIdx.x / (8 * nsl), brem = (int32_t)blockIdx.x - bgrp * 8 * nsl;
-    slice = brem >> 3;
-    bw = bgrp * 8 + (brem & 7);
-    if (bw >= n_band) return;
+    const double *pf_bin = (LOWER && fl.on()) ? fl.bin.get() : nullptr;
+    trsv_stream_r64<double, 0, LOWER, true>(ps0 + pw, ps1, ((int32_t)gridDim.x - nbp) * 4, ptr, split, col, val, nullptr,
+                                            rowid, d, LOWER ? w : v, w, lane, nullptr, 0, nullptr, true, nullptr, 0, 0, pf_bin, &fl);
+    HIFAMD_CSP(6)
+    HIFAMD_CSP_FLUSH(2 + (LOWER ? 0 : 4) + 32, n_band, nsl)
+    return;
   }
+  const int32_t bgrp = (int32_t)blockIdx.x / (8 * nsl), brem = (int32_t)blockIdx.x - bgrp * 8 * nsl;
+  const int32_t slice = brem >> 3, bw = bgrp * 8 + (brem & 7);
+  if (bw >= n_band) return;
+  const int kq = lane >> 4, l16 = lane & 15;
   const int cc = slice * W + l16;  // this lane's column of the 64-column arena (first column tile)
-  // the first touch of a row takes its right-hand side from the level's input (S1 fused, FirstL), from w / d (the first
-  // kernel of a U solve) or -- L without S1 -- from x itself; later touches from x (the carried prefix left it there)
-  const bool first = carried || first_u;
-  const bool div_u = !LOWER && first;
-  const bool first_l = LOWER && first && fl.on();
+  double *x = LOWER ? w : v;
+  const bool div_u = !LOWER && first_u;
+  const bool first_l = LOWER && first_u && fl.on();
   const double *rhs = div_u ? (const double *)w : (first_l ? fl.bin.get() : (const double *)x);
   const int64_t rstride = first_l ? fl.ldb : 64;
-  const int32_t *fl_p = fl.p, *lu_q = lu.q;
-  const double *fl_s = fl.s, *lu_t = lu.t;
-  const int fl_nrhs = fl.nrhs;
   int32_t c_first, c_last;
-  if (!carried && single_c0 >= 0) {
+  if (single_c0 >= 0) {
     c_first = single_c0 + bw;
     c_last = c_first + 1;
   } else {
-    const int32_t g = (carried ? wg1 : wg0) + bw;
-    c_first = wg_grp_ptr[g];
-    c_last = wg_grp_ptr[g + 1];
+    c_first = wg_grp_ptr[wg0 + bw];
+    c_last = wg_grp_ptr[wg0 + bw + 1];
   }
-  const CtSet ts = carried ? car : own;
-  // LDS: right-hand sides [lds_rows][W]; the waves' continuation partials [4][16][W]; per row: pivot / scale, output
-  // scale, row id, input row, output row
+  // LDS: right-hand sides [lds_rows][W], per row: pivot / scale, output scale, row id, input row, output row; the
+  // component's strip -> tile offsets
   double *tb = cs_buf;
-  double *pbase = tb + (size_t)lds_rows * W;
-  double *s_hd = pbase + 4 * 16 * W;
+  double *s_hd = tb + (size_t)lds_rows * W;
   double *s_ot = s_hd + lds_rows;
   int32_t *s_rowid = reinterpret_cast<int32_t *>(s_ot + lds_rows);
   int32_t *s_hp = s_rowid + lds_rows;
   int32_t *s_oi = s_hp + lds_rows;
-  const bool last_u = !carried && !LOWER && lu.on();
+  int32_t *s_sptr = s_oi + lds_rows;  // 17 entries (a component has at most 16 strips)
+  const bool last_u = !LOWER && lu.on();
   double *yout = last_u ? lu.out.get() : nullptr;
   constexpr int KU = 8;
   for (int32_t c = c_first; c < c_last; ++c) {
-    const int32_t *dsc = cd_desc + (int64_t)c * 28;
-    const int32_t *ctd = ts.desc + (int64_t)c * 24;
-    const int32_t s0 = dsc[0], nb = dsc[1];
+    const int32_t *dsc = ct_desc + (int64_t)c * 28;
+    const int32_t s0 = dsc[0], nb = dsc[1], sp0 = dsc[20];
     const int64_t inv_off = ((int64_t)(uint32_t)dsc[5] << 32) | (uint32_t)dsc[4];
+    const uint32_t mword = (uint32_t)dsc[22 + (wave >> 1)];
+    const uint32_t mymask = (wave & 1) ? (mword >> 16) : (mword & 0xffffu);  // the strips this wave owns
     const int lda = (nb + 31) & ~31;
     const double *Ac = tinv + inv_off;
     const int S = (nb + 15) >> 4;
-    // the stream's first source ids and coefficient tiles: requested before anything else
-    CtRing<NCT, R> rg;
-    ct_stream_begin<NCT, R>(rg, ctd, wave, ts.src, ts.coef, kq, lane, (dbg & 1) != 0, !(dbg & 64));
-    // ---- phase 0: the component's row ids and per-row scalars (one thread per row) ...
+    double a0[KU], a1[KU];
+    // ---- phase 0: the component's row ids, per-row scalars and strip offsets (coalesced)
     for (int32_t t = (int32_t)threadIdx.x; t < nb; t += 256) {
       const int32_t i = rowid[s0 + t];
       s_rowid[t] = i;
       if (div_u) s_hd[t] = d[i];
       if (first_l) {
-        const int32_t pp = fl_p[i];
+        const int32_t pp = fl.p[i];
         s_hp[t] = pp;
-        s_hd[t] = fl_s[pp];
+        s_hd[t] = fl.s[pp];
       }
       if (last_u) {
-        const int32_t oi = lu_q[i];
+        const int32_t oi = lu.q[i];
         s_oi[t] = oi;
-        s_ot[t] = lu_t[oi];
+        s_ot[t] = lu.t[oi];
       }
     }
+    if ((int32_t)threadIdx.x <= S) s_sptr[threadIdx.x] = ct_sptr[sp0 + (int32_t)threadIdx.x];
     HIFAMD_CSP(1)
     __syncthreads();
-    // ... then the rows' right-hand sides into LDS (a wave-instruction covers four rows x 16 columns; all of a thread's
-    // loads in flight at once); rows nb .. lda - 1 are zero (the inverse product reads whole operand sets of 32 rows;
-    // lds_rows is a multiple of 32)
-    for (int idx = (int)threadIdx.x; idx < lda * W; idx += 256) {
-      const int row = idx / W, colx = idx - row * W;
-      double val = 0.0;
-      if (row < nb) {
-        const int cx = slice * W + colx;
-        const int32_t i = first_l ? s_hp[row] : s_rowid[row];
-        const double r_ = rhs[(int64_t)i * rstride + (first_l ? min(cx, fl_nrhs - 1) : cx)];
-        val = div_u ? r_ / s_hd[row] : (first_l ? (cx < fl_nrhs ? s_hd[row] * r_ : 0.0) : r_);
-      }
-      tb[idx] = val;
-    }
     HIFAMD_CSP(2)
-    __syncthreads();
-    // ---- phase 1: this wave's tile stream, t -= tiles in LDS
-    ct_stream_run<NCT, R>(rg, ctd, wave, ts.src, ts.coef, x, cc, kq, lane, tb, pbase + wave * 16 * W);
-    if (rg.touched == 0x7fffffff && lds_rows < 0) tb[0] = 1.0;  // (never true: keeps the touch loads alive)
-    double a0[KU], a1[KU];
+    // ---- phase 1: this wave's strips -- right-hand sides requested first, then the strip's tiles BU at a time (the
+    // next BU source ids and coefficient tiles are in flight while the current ones are gathered and multiplied)
+    for (int s = 0; s < S; ++s) {
+      if (!((mymask >> s) & 1u)) continue;  // (wave-uniform)
+      double tr[NCT][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = min(16 * s + kq + 4 * j, nb - 1);
+        const int32_t i = first_l ? s_hp[row] : s_rowid[row];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const int cx = cc + 16 * ct;
+          tr[ct][j] = rhs[(int64_t)i * rstride + (first_l ? min(cx, fl.nrhs - 1) : cx)];
+        }
+      }
+      const int32_t t0 = s_sptr[s], t1 = (dbg & 1) ? t0 : s_sptr[s + 1];
+      v4f64 acc[NCT];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[ct] = v4f64{0.0, 0.0, 0.0, 0.0};
+      if (t0 < t1) {
+        int32_t sv[BU];
+        double cv[BU];
+#pragma unroll
+        for (int u = 0; u < BU; ++u) {
+          const int32_t tt = min(t0 + u, t1 - 1);
+          sv[u] = ct_src[4 * (int64_t)tt + kq];
+          cv[u] = ct_coef[64 * (int64_t)tt + lane];
+          if (t0 + u >= t1) cv[u] = 0.0;
+        }
+        for (int32_t t = t0; t < t1; t += BU) {
+          double bv[NCT][BU];
+#pragma unroll
+          for (int u = 0; u < BU; ++u)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) bv[ct][u] = x[((int64_t)sv[u] << 6) + cc + 16 * ct];
+          int32_t sn[BU];
+          double cn[BU];
+#pragma unroll
+          for (int u = 0; u < BU; ++u) {  // (clamped: the loads past the strip's last tile read that tile again, weight zero)
+            const int32_t tt = min(t + BU + u, t1 - 1);
+            sn[u] = ct_src[4 * (int64_t)tt + kq];
+            cn[u] = ct_coef[64 * (int64_t)tt + lane];
+            if (t + BU + u >= t1) cn[u] = 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < BU; ++u)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(cv[u], bv[ct][u], acc[ct], 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < BU; ++u) sv[u] = sn[u], cv[u] = cn[u];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = 16 * s + kq + 4 * j;
+        if (row < nb) {
+          const double hd = (div_u || first_l) ? s_hd[row] : 1.0;
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            const double t_ = div_u ? tr[ct][j] / hd : (first_l ? (cc + 16 * ct < fl.nrhs ? hd * tr[ct][j] : 0.0) : tr[ct][j]);
+            tb[row * W + 16 * ct + l16] = t_ - acc[ct][j];
+          }
+        }
+      }
+    }
     // phase 2's first operand set: requested before the barrier
-    if (!carried && wave < S) {
+    if (wave < S) {
       const double *ap_ = Ac + ((int64_t)(S - 1 - wave) * lda) * 16 + l16 + (int64_t)kq * 16;
 #pragma unroll
       for (int u = 0; u < KU; ++u) a0[u] = ap_[u * 64];
     }
+    // (rows nb .. lda - 1 are zero for the inverse product; lds_rows is a multiple of 32)
+    for (int t = nb * W + (int)threadIdx.x; t < lda * W; t += 256) tb[t] = 0.0;
     HIFAMD_CSP(4)
     __syncthreads();
-    {  // continuation partials, in wave order (a thread owns one element position: deterministic)
-      const uint32_t contm = (dbg & 1) ? 0u : (uint32_t)ctd[7];
-      if (contm) {
-        for (int e = (int)threadIdx.x; e < 16 * W; e += 256) {
-#pragma unroll
-          for (int w_ = 1; w_ < 4; ++w_)
-            if ((contm >> w_) & 1u) {
-              const int cs = (int)(((uint32_t)ctd[8 + 4 * w_] & 0xffffu) >> 12);  // strip of wave w_'s first segment
-              tb[16 * cs * W + e] -= pbase[w_ * 16 * W + e];
-            }
-        }
-        __syncthreads();
-      }
-    }
     HIFAMD_CSP(5)
-    if (carried) {  // the rows go back to x as they are: this band's own launch finishes them
-      for (int idx = (int)threadIdx.x; idx < nb * W; idx += 256) {
-        const int row = idx / W, colx = idx - row * W;
-        x[((int64_t)s_rowid[row] << 6) + slice * W + colx] = tb[idx];
-      }
-      __syncthreads();
-      continue;
-    }
     // ---- phase 2: x = Tinv * t on the matrix cores, one 16-row strip x this slice's columns per step; strips are dealt
     // heaviest first in snake order over the four waves (k_band_cs)
     for (int rnd = 0;; ++rnd) {
@@ -3243,8 +3131,7 @@ __global__ void __launch_bounds__(256, 2) k_band_ct(int32_t wg0, const int32_t *
     __syncthreads();  // (the next component overwrites the LDS block)
   }
   HIFAMD_CSP(6)
-  HIFAMD_CSP_FLUSH((carried ? 2 : 1) + (LOWER ? 0 : 4) + 32, n_band, nsl)
-  (void)0;
+  HIFAMD_CSP_FLUSH(1 + (LOWER ? 0 : 4) + 32, n_band, nsl)
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -38,9 +38,6 @@ struct Sink {
     for (int tri = 0; tri < 2; ++tri) {
       const BandPlan &P = tri ? H.Up : H.Lp;
       const Csr<double> &A = tri ? H.Ur : H.Lr;
-      CtTiles Tw, Tc;
-      build_ct_tiles(P, A, false, Tw);
-      build_ct_tiles(P, A, true, Tc);
       for (int64_t b = 0; b < P.nbands(); ++b) {
         const int32_t g0 = P.band_wg_ptr[(size_t)b], g1 = P.band_wg_ptr[(size_t)b + 1];
         const int32_t c0 = P.wg_grp_ptr[(size_t)g0], c1 = P.wg_grp_ptr[(size_t)g1];
@@ -54,15 +51,6 @@ struct Sink {
         if (!P.band_cd[(size_t)b]) {
           std::printf("}\n");
           continue;
-        }
-        if (!Tw.desc.empty()) {  // padded tiles of the walked / carried sets of this band, and the longest wave stream of each
-          int64_t tw = 0, tc = 0;
-          for (int32_t c = c0; c < c1; ++c) {
-            tw += (int64_t)kCtBatch * Tw.desc[(size_t)c * kCtDescWords + 5];
-            if (!Tc.desc.empty()) tc += (int64_t)kCtBatch * Tc.desc[(size_t)c * kCtDescWords + 5];
-          }
-          std::printf(", \"ct_tiles\": %ld, \"ct_wave_max\": %d, \"cc_tiles\": %ld, \"cc_wave_max\": %d", (long)tw,
-                      Tw.band_wave_tiles[(size_t)b], (long)tc, Tc.band_wave_tiles.empty() ? 0 : Tc.band_wave_tiles[(size_t)b]);
         }
         // per component: [rows, walked entries, distinct sources, tiles (16-row strips x 4 distinct sources), tiles of 32-row
         // strips, longest wave chunk, own nonzeros, depth levels (sparse plans)]
