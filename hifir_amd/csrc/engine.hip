@@ -414,7 +414,7 @@ class Engine : public EngineBase {
   double bytes_inverses = 0.0, bytes_top = 0.0, bytes_tail = 0.0;  // resident explicit operators (HBM)
   bool fuse_out = true;    // S7 fused into the last band of the final U solve (HIFIR_AMD_FUSE_S7=0: k_scatter_scale over all rows)
   bool spmm_split = true;  // tiled Schur products: one 16-row block per workgroup (k_spmm_tile4); HIFIR_AMD_SPMM_SPLIT=0: per wave
-  int carry_wgs = 256;   // workgroups a band's launch may add for the carried prefix of the next band (HIFIR_AMD_CARRY_WGS)
+  int carry_wgs = 512;   // workgroups a band's launch may add for the carried prefix of the next band (HIFIR_AMD_CARRY_WGS)
   bool fuse_f = true;    // S5 fused into the second L solve where the plan allows (HIFIR_AMD_FUSE_F=0: separate k_spmm_epi launch)
   int top_gemm = 4;      // top / tail operator product: 4 k_top_gemm (64-row tiles, panel through LDS, K splits); 1 k_strip_gemm_d<4>,
                          // 2 k_strip_gemm4_d<2>, 3 k_strip_gemm4_d<4> (HIFIR_AMD_TOP_GEMM)
@@ -498,7 +498,7 @@ class Engine : public EngineBase {
     cd_split_wgs = env_int("HIFIR_AMD_CD_SPLIT_WGS", 600);
     top_gemm = env_int("HIFIR_AMD_TOP_GEMM", 4);
     fuse_f = env_int("HIFIR_AMD_FUSE_F", 1) != 0;
-    carry_wgs = std::max(1, env_int("HIFIR_AMD_CARRY_WGS", 256));
+    carry_wgs = std::max(1, env_int("HIFIR_AMD_CARRY_WGS", 512));
     spmm_split = env_int("HIFIR_AMD_SPMM_SPLIT", 1) != 0;
     fuse_out = env_int("HIFIR_AMD_FUSE_S7", 1) != 0;
     tail_rows = env_int("HIFIR_AMD_TAIL_ROWS", 4096);

@@ -2923,17 +2923,21 @@ __global__ void __launch_bounds__(256) k_band_ct(int32_t wg0, const int32_t *__r
   // are dealt round-robin over the eight XCDs: the slices then share one L2 -- the component's tiles and inverse are
   // fetched from HBM once; placement is a speed matter only)
   const int32_t nbp = ((n_band + 7) >> 3) * 8 * nsl;
-  if ((int32_t)blockIdx.x >= nbp) {  // carried prefix of the next band over the sources older than this band
-    const int32_t pw = __builtin_amdgcn_readfirstlane(((int32_t)blockIdx.x - nbp) * 4 + wave);
+  // (dbg & 128: the carried workgroups take the FIRST block numbers instead of the last)
+  const int32_t ncar = (int32_t)gridDim.x - nbp;
+  const bool car_first = (dbg & 128) != 0;
+  const int32_t bx = car_first ? (int32_t)blockIdx.x - ncar : (int32_t)blockIdx.x;
+  if (car_first ? bx < 0 : bx >= nbp) {  // carried prefix of the next band over the sources older than this band
+    const int32_t pw = __builtin_amdgcn_readfirstlane((car_first ? (int32_t)blockIdx.x : bx - nbp) * 4 + wave);
     if (dbg & 4) return;
     const double *pf_bin = (LOWER && fl.on()) ? fl.bin.get() : nullptr;
-    trsv_stream_r64<double, 0, LOWER, true>(ps0 + pw, ps1, ((int32_t)gridDim.x - nbp) * 4, ptr, split, col, val, nullptr,
+    trsv_stream_r64<double, 0, LOWER, true>(ps0 + pw, ps1, ncar * 4, ptr, split, col, val, nullptr,
                                             rowid, d, LOWER ? w : v, w, lane, nullptr, 0, nullptr, true, nullptr, 0, 0, pf_bin, &fl);
     HIFAMD_CSP(6)
     HIFAMD_CSP_FLUSH(2 + (LOWER ? 0 : 4) + 32, n_band, nsl)
     return;
   }
-  const int32_t bgrp = (int32_t)blockIdx.x / (8 * nsl), brem = (int32_t)blockIdx.x - bgrp * 8 * nsl;
+  const int32_t bgrp = bx / (8 * nsl), brem = bx - bgrp * 8 * nsl;
   const int32_t slice = brem >> 3, bw = bgrp * 8 + (brem & 7);
   if (bw >= n_band) return;
   const int kq = lane >> 4, l16 = lane & 15;
@@ -2990,6 +2994,13 @@ __global__ void __launch_bounds__(256) k_band_ct(int32_t wg0, const int32_t *__r
       }
     }
     if ((int32_t)threadIdx.x <= S) s_sptr[threadIdx.x] = ct_sptr[sp0 + (int32_t)threadIdx.x];
+    // phase 2's first operand set does not depend on anything computed here: a narrow band (one 16-column slice per
+    // workgroup) requests it NOW -- its launch is a chain of round trips, and this one then hides behind phase 1
+    if (NCT == 1 && !(dbg & 256) && wave < S) {
+      const double *ap_ = Ac + ((int64_t)(S - 1 - wave) * lda) * 16 + l16 + (int64_t)kq * 16;
+#pragma unroll
+      for (int u = 0; u < KU; ++u) a0[u] = ap_[u * 64];
+    }
     HIFAMD_CSP(1)
     __syncthreads();
     HIFAMD_CSP(2)
@@ -3058,8 +3069,8 @@ __global__ void __launch_bounds__(256) k_band_ct(int32_t wg0, const int32_t *__r
         }
       }
     }
-    // phase 2's first operand set: requested before the barrier
-    if (wave < S) {
+    // (a wide band: requested behind phase 1, before the barrier -- there the registers buy more than the latency)
+    if ((NCT != 1 || (dbg & 256)) && wave < S) {
       const double *ap_ = Ac + ((int64_t)(S - 1 - wave) * lda) * 16 + l16 + (int64_t)kq * 16;
 #pragma unroll
       for (int u = 0; u < KU; ++u) a0[u] = ap_[u * 64];
