@@ -842,6 +842,10 @@ class Engine : public EngineBase {
   // buffers full) and streamed to HBM while the next batch is being inverted.  Consecutive small blocks share a
   // batch (built in parallel, one thread per block, ONE copy); a big block is a batch of its own (parallel inside).
   // A band whose inverses grow beyond dense_max_growth reverts to the sequential (flag) scheme.
+  // NOTE (analysis trailer): a band whose inverses grow beyond dense_max_growth loses its dense / component flag HERE, on the
+  // host plan, and save_analysis (which runs after finalize) writes those value-dependent verdicts into the trailer; a
+  // load with OTHER values of the same pattern keeps such a band on the flag scheme (still correct, never checked against
+  // growth again in the other direction: a band that is flagged and grows under the new values is demoted as usual).
   void ship_block_inverses(BandPlan &P, const Csr<T> &A, int64_t total_elems, DevCsr &M) {
     M.upload(A, &P);
     if (ct_mode && sizeof(T) == sizeof(double) && band_opt.dense_block > 0 && !P.cd_sparse && !P.band_cd.empty()) {
@@ -964,7 +968,7 @@ class Engine : public EngineBase {
       std::fprintf(stderr, "FINALIZE level=%zu %-28s %.3f s\n", level, what, t - ft);
       ft = t;
     };
-    for (size_t l = 0; l < host.levels.size(); ++l) check_level_invariants(host.levels[l], l, adjoint);
+    for (size_t l = 0; l < host.levels.size(); ++l) check_level_invariants(host.levels[l], l, adjoint, &band_opt);
     tick("invariants (all levels)", 0);
     bind_device();
     tick("bind device", 0);
@@ -2837,6 +2841,20 @@ static void do_copy_columns(E *e, size_t elem, const void *src, int64_t lds, int
   if (ncols < 1 || lds < ncols || col0 < 0 || ldd < col0 + ncols) throw Error(HIFAMD_MISMATCHED_SIZES, "column block does not fit");
   HIP_OK(hipSetDevice(e->device));
   const int64_t n = e->lv[0]->n;
+  // a destination on ANOTHER device: the copy is a peer copy and needs peer access from this handle's device (enabled
+  // once per pair; "already enabled" is fine); where the platform grants none the call fails loudly instead of a copy
+  // that the runtime would stage or refuse at its own discretion
+  hipPointerAttribute_t pa;
+  if (hipPointerGetAttributes(&pa, dst) == hipSuccess && pa.type == hipMemoryTypeDevice && pa.device != e->device) {
+    int can = 0;
+    HIP_OK(hipDeviceCanAccessPeer(&can, e->device, pa.device));
+    if (!can) throw Error(HIFAMD_HIFIR_ERROR, "no peer access between the two devices of a column-block copy");
+    const hipError_t pe = hipDeviceEnablePeerAccess(pa.device, 0);
+    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) HIP_OK(pe);
+    (void)hipGetLastError();
+  } else {
+    (void)hipGetLastError();  // (a host pointer: not an error here)
+  }
   HIP_OK(hipMemcpy2DAsync((char *)dst + (size_t)col0 * elem, (size_t)ldd * elem, src, (size_t)lds * elem, (size_t)ncols * elem,
                           (size_t)n, hipMemcpyDefault, e->stream));
 }

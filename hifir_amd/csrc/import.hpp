@@ -92,6 +92,15 @@ HostLevel<T> import_level(int64_t parent_nm, int64_t m, int64_t n, const int64_t
 // two independent pieces of host work side by side (an exception of either is rethrown after both have finished)
 template <class FA, class FB>
 void par2(FA &&fa, FB &&fb) {
+  {  // HIFIR_AMD_THREADS=1 (or a single hardware thread): strictly one after the other, on the calling thread
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("HIFIR_AMD_THREADS")) hw = (unsigned)std::max(1, std::atoi(e));
+    if (hw == 1) {
+      fa();
+      fb();
+      return;
+    }
+  }
   std::exception_ptr ea, eb;
   std::thread ta([&] {
     try {
@@ -325,7 +334,9 @@ void check_csr(const Csr<T> &A, int64_t nnz_expected, const char *what, size_t l
 }
 
 template <class T>
-void check_band_plan(const BandPlan &P, const Csr<T> &A, const char *what, size_t level_no, int64_t cd_rows_limit = 1 << 20) {
+void check_band_plan(const BandPlan &P, const Csr<T> &A, const char *what, size_t level_no, const BandOptions *opt = nullptr) {
+  // (components must fit the LDS block the kernels size from the planner options)
+  const int64_t cd_rows_limit = opt ? (P.cd_sparse ? opt->cd_sparse_rows : opt->cd_rows) : (int64_t)255;
   auto fail = [&](const char *why, int64_t at) {
     throw Error(kHifirError, std::string("internal error: band plan of ") + what + " of level " + std::to_string(level_no) +
                                  ": " + why + " at " + std::to_string(at));
@@ -368,7 +379,7 @@ void check_band_plan(const BandPlan &P, const Csr<T> &A, const char *what, size_
 }
 
 template <class T>
-void check_level_invariants(const HostLevel<T> &H, size_t level_no, bool adjoint = false) {
+void check_level_invariants(const HostLevel<T> &H, size_t level_no, bool adjoint = false, const BandOptions *opt = nullptr) {
   const int64_t m = H.m, n = H.n, nm = n - m;
   auto fail = [&](const char *why) {
     throw Error(kHifirError, std::string("internal error: level ") + std::to_string(level_no) + ": " + why +
@@ -383,8 +394,8 @@ void check_level_invariants(const HostLevel<T> &H, size_t level_no, bool adjoint
   check_csr(H.Ur, adjoint ? (int64_t)H.Ur.col.size() : H.U.nnz(), "U", level_no);
   check_csr(H.Er, adjoint ? (int64_t)H.Er.col.size() : H.E.nnz(), "E", level_no);
   check_csr(H.Fr, adjoint ? (int64_t)H.Fr.col.size() : H.F.nnz(), "F", level_no);
-  check_band_plan(H.Lp, H.Lr, "L", level_no);
-  check_band_plan(H.Up, H.Ur, "U", level_no);
+  check_band_plan(H.Lp, H.Lr, "L", level_no, opt);
+  check_band_plan(H.Up, H.Ur, "U", level_no, opt);
   if ((int64_t)H.d.size() != m || (int64_t)H.s.size() != n || (int64_t)H.t.size() != n) fail("vector lengths");
   if (!is_permutation(H.p, n) || !is_permutation(H.q_inv, n)) fail("p / q_inv are not permutations");
   if (!H.p_inv.empty() && !is_permutation(H.p_inv, n)) fail("p_inv is not a permutation");
@@ -742,11 +753,11 @@ bool cached_plan_ok(const BandPlan &P, const Csr<T> &A, int64_t m, int64_t nz, c
       !mono(P.band_wg_ptr, (int64_t)P.wg_grp_ptr.size() - 1))
     return false;
   const size_t nb = P.band_wg_ptr.size() - 1;
-  auto per_band = [&](const std::vector<uint8_t> &v, bool may_be_empty) { return v.size() == nb || (may_be_empty && v.empty()); };
-  if (!per_band(P.band_prefix, false) || !per_band(P.band_dense, false) || !per_band(P.band_fused, true) || !per_band(P.band_cd, true) ||
-      !per_band(P.band_old, true))
+  // (exactly the lengths check_band_plan demands at finalize: a plan that passes here must not fail there)
+  auto per_band = [&](const std::vector<uint8_t> &v) { return v.size() == nb; };
+  if (!per_band(P.band_prefix) || !per_band(P.band_dense) || !per_band(P.band_fused) || !per_band(P.band_cd) || !per_band(P.band_old))
     return false;
-  if ((int64_t)P.split.size() != m || (int64_t)P.srcslot.size() != nz || (!P.csplit.empty() && (int64_t)P.csplit.size() != m)) return false;
+  if ((int64_t)P.split.size() != m || (int64_t)P.srcslot.size() != nz || (int64_t)P.csplit.size() != m) return false;
   for (int64_t s = 0; s < m; ++s) {
     const int32_t a = A.ptr[(size_t)s], e = A.ptr[(size_t)s + 1], sp = P.split[(size_t)s];
     if (sp < a || sp > e) return false;
@@ -766,10 +777,12 @@ bool cached_plan_ok(const BandPlan &P, const Csr<T> &A, int64_t m, int64_t nz, c
     const bool cd = !P.band_cd.empty() && P.band_cd[b];
     if (cd) {  // (component streams index rows with a byte)
       if (P.csplit.empty() || opt.cd_rows <= 0 || opt.dense_block <= 0 || (P.cd_sparse && opt.cd_sparse_rows <= 0)) return false;
+      if (P.cd_sparse && sizeof(T) != sizeof(double)) return false;  // (sparse-own components exist for real data only)
       for (int32_t g = P.band_wg_ptr[b]; g < P.band_wg_ptr[b + 1]; ++g)
         for (int32_t c = P.wg_grp_ptr[(size_t)g]; c < P.wg_grp_ptr[(size_t)g + 1]; ++c) {
           const int32_t rows = P.grp_slot_ptr[(size_t)c + 1] - P.grp_slot_ptr[(size_t)c];
-          if (rows < 1 || rows > 255) return false;
+          // (the kernels size their LDS block from the planner OPTIONS: a cached component must fit what they allow)
+          if (rows < 1 || rows > 255 || rows > (P.cd_sparse ? opt.cd_sparse_rows : opt.cd_rows)) return false;
           if (!P.cd_sparse) inv_elems += (double)plane_elems(rows, round_up32(rows));
           // a component's own nonzeros [csplit, end) refer to EARLIER rows of the same component
           const int32_t s0 = P.grp_slot_ptr[(size_t)c];
@@ -872,20 +885,28 @@ bool adopt_analysis(HostLevel<T> &H, LevelAnalysis<T> &A, const BandOptions &opt
   } else if (A.top_n != 0 || A.top_bandL != -1 || A.top_bandU != -1) {
     return false;
   }
+  // the cheap rest (block cutting, component streams) is rebuilt on the CANDIDATE plans, before anything of H is
+  // replaced: an error there leaves H untouched and the caller analyzes as usual
+  int64_t lt = 0, ut = 0;
+  try {
+    par2(
+        [&] {
+          lt = plan_dense_blocks<T>(A.Lp, opt);
+          build_cd_streams(A.Lp, Lr.ptr);
+        },
+        [&] {
+          ut = plan_dense_blocks<T>(A.Up, opt);
+          build_cd_streams(A.Up, Ur.ptr);
+        });
+  } catch (const Error &) {
+    return false;
+  }
   H.Lr = std::move(Lr), H.Ur = std::move(Ur);
   H.Ls = std::move(A.Ls), H.Us = std::move(A.Us);
   H.Lp = std::move(A.Lp), H.Up = std::move(A.Up);
   H.top = std::move(A.top);
   H.top_n = A.top_n, H.top_bandL = A.top_bandL, H.top_bandU = A.top_bandU;
-  par2(
-      [&] {
-        H.Ltinv_elems = plan_dense_blocks<T>(H.Lp, opt);
-        build_cd_streams(H.Lp, H.Lr.ptr);
-      },
-      [&] {
-        H.Utinv_elems = plan_dense_blocks<T>(H.Up, opt);
-        build_cd_streams(H.Up, H.Ur.ptr);
-      });
+  H.Ltinv_elems = lt, H.Utinv_elems = ut;
   return true;
 }
 

@@ -213,6 +213,32 @@ static int run_file(const char *path, const std::vector<unsigned char> &bytes, i
     }
     bad += finalize_host(K);
     bad += compare(A, K, "adopted analysis");
+    // a cached component must fit the LDS block the kernels size from the planner OPTIONS (a re-sealed trailer with a
+    // larger one used to be adopted): the same plan is refused under options one row short of its largest component, and
+    // check_band_plan -- what finalize runs -- refuses it as well
+    for (size_t l = 0; l < K.host.levels.size(); ++l)
+      for (int tri = 0; tri < 2; ++tri) {
+        const HostLevel<T> &H = K.host.levels[l];
+        const BandPlan &P = tri ? H.Up : H.Lp;
+        const Csr<T> &M = tri ? H.Ur : H.Lr;
+        int32_t mx = 0;
+        for (size_t b = 0; b < P.band_cd.size(); ++b)
+          if (P.band_cd[b])
+            for (int32_t c = P.wg_grp_ptr[(size_t)P.band_wg_ptr[b]]; c < P.wg_grp_ptr[(size_t)P.band_wg_ptr[b + 1]]; ++c)
+              mx = std::max(mx, P.grp_slot_ptr[(size_t)c + 1] - P.grp_slot_ptr[(size_t)c]);
+        if (mx < 2) continue;
+        BandOptions small = A.opt;
+        (P.cd_sparse ? small.cd_sparse_rows : small.cd_rows) = mx - 1;
+        if (!cached_plan_ok(P, M, H.m, (int64_t)M.col.size(), A.opt)) ++bad, std::fprintf(stderr, "%s: a computed plan is not accepted as a cached one\n", path);
+        if (cached_plan_ok(P, M, H.m, (int64_t)M.col.size(), small)) ++bad, std::fprintf(stderr, "%s: oversized cached component accepted\n", path);
+        bool thrown = false;
+        try {
+          check_band_plan(P, M, "test", l, &small);
+        } catch (const Error &) {
+          thrown = true;
+        }
+        if (!thrown) ++bad, std::fprintf(stderr, "%s: check_band_plan accepts a component larger than the options allow\n", path);
+      }
     const size_t t0 = bytes.size(), t1 = out.size() - 24;  // the trailer's bytes
     auto reseal = [&](std::vector<unsigned char> &b) {
       HashIo h{nullptr};
