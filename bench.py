@@ -264,6 +264,11 @@ def main():
         launch_map = [16 * l + s_ for (l, s_) in M.launch_map()]
         level_bytes = {str(l): {str(k): v for k, v in d_.items()} for l, d_ in M.level_bytes(args.nrhs).items()}
         setup = M.stats_ext()
+        # (N > 1: how many levels each rank took from the analysis trailer of rank 0's hierarchy file)
+        ranks_cached = None
+        if world > 1:
+            ranks_cached = [None] * world
+            dist.all_gather_object(ranks_cached, int(setup.get("analysis_cached_levels", 0) or 0))
         # BASELINE configs[1]: the same hierarchy with ONE right-hand side (latency-bound; reported, not the metric)
         b1 = B[:, :1].contiguous()
         x1 = torch.empty_like(b1)
@@ -352,7 +357,7 @@ def main():
                          "first_tile_equals_64_column_result": bool(torch.equal(X2[:, :args.nrhs], X))}
             del B2, X2
         res = dict(ms_per_step=1e3 * el / steps, value=world * args.nrhs * steps / el, dev_ms=dev_ms, balg=balg, stage_bytes=stage_bytes, nrhs1_ms=nrhs1_ms, pipelined=pipelined,
-                   launch_map=launch_map, level_bytes=level_bytes, setup=setup, narrow=narrow,
+                   launch_map=launch_map, level_bytes=level_bytes, setup=setup, narrow=narrow, ranks_cached=ranks_cached,
                    stats=st, cpu=cpu, gather_ms=gather_ms, parity=parity, levels=levels, strong=strong, exact=exact)
         M.close()
         del B, X
@@ -418,7 +423,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_note": traffic_note,
-                         "kernel": "one whole batched apply (hipGraph of k_band_cd/k_top_gemm/k_top_reduce/k_trsv_wide/k_spmm_tile(4)/k_spmm_epi/k_scatter_scale_list; S1, S5 (level 0) and S7 fused into the component bands)",
+                         "kernel": "one whole batched apply (hipGraph of k_band_ct (levels >= 1) / k_band_cd (level 0) / k_top_gemm / k_top_reduce / k_trsv_wide / k_spmm_tile(4) / k_spmm_epi / k_scatter_scale_list; S1, S5 (level 0) and S7 fused into the component bands)",
                          "algorithmic_bytes": r["balg"], "apply_ms_hip_events": r["dev_ms"],
                          "algorithmic_bytes_by_stage": r["stage_bytes"], "algorithmic_bytes_by_level": r["level_bytes"],
                          "launch_map": r["launch_map"], "levels_from_profile": stages},
@@ -427,6 +432,8 @@ def main():
         }
         if r["gather_ms"] is not None:
             line["gather_ms"] = r["gather_ms"]
+        if r.get("ranks_cached") is not None:
+            line["config"]["analysis_levels_from_file_by_rank"] = r["ranks_cached"]
         if r["strong"] is not None:
             line["strong_scaling"] = r["strong"]
         if r["exact"] is not None:
