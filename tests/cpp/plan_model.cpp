@@ -38,6 +38,8 @@ struct Sink {
     for (int tri = 0; tri < 2; ++tri) {
       const BandPlan &P = tri ? H.Up : H.Lp;
       const Csr<double> &A = tri ? H.Ur : H.Lr;
+      CtTiles Tw;
+      build_ct_tiles(P, A, Tw);
       for (int64_t b = 0; b < P.nbands(); ++b) {
         const int32_t g0 = P.band_wg_ptr[(size_t)b], g1 = P.band_wg_ptr[(size_t)b + 1];
         const int32_t c0 = P.wg_grp_ptr[(size_t)g0], c1 = P.wg_grp_ptr[(size_t)g1];
@@ -48,9 +50,27 @@ struct Sink {
                     "\"prefix\": %d, \"fused\": %d, \"sparse\": %d, \"carried\": %ld",
                     level_no, tri ? 'U' : 'L', (long)b, s1 - s0, A.ptr[(size_t)s1] - A.ptr[(size_t)s0], g1 - g0, (int)P.band_cd[(size_t)b],
                     (int)P.band_dense[(size_t)b], (int)P.band_prefix[(size_t)b], (int)P.band_fused[(size_t)b], (int)P.cd_sparse, (long)carried);
+        {  // what the band's launch reads of explicit inverses: per component the lower strips of its strip-major operand
+          double inv_bytes = 0.0;
+          if (P.band_cd[(size_t)b] && !P.cd_sparse)
+            for (int32_t c = c0; c < c1; ++c) {
+              const int32_t nb = P.grp_slot_ptr[(size_t)c + 1] - P.grp_slot_ptr[(size_t)c];
+              for (int32_t st = 0; st * 16 < nb; ++st) inv_bytes += 16.0 * 8.0 * (double)(((std::min(nb, 16 * (st + 1)) + 31) / 32) * 32);
+            }
+          std::printf(", \"inv_bytes\": %.0f, \"top_band\": %d", inv_bytes, (int)((tri ? H.top_bandU : H.top_bandL) == (int32_t)b && H.top_n > 0));
+        }
         if (!P.band_cd[(size_t)b]) {
           std::printf("}\n");
           continue;
+        }
+        if (!Tw.sptr.empty()) {  // coefficient tiles of the band (what k_band_ct multiplies) and its longest wave
+          int64_t tw = 0;
+          for (int32_t c = c0; c < c1; ++c) {
+            const int32_t sp0 = Tw.desc[(size_t)c * kCdDescWords + 20];
+            const int32_t S = (P.grp_slot_ptr[(size_t)c + 1] - P.grp_slot_ptr[(size_t)c] + 15) / 16;
+            tw += Tw.sptr[(size_t)(sp0 + S)] - Tw.sptr[(size_t)sp0];
+          }
+          std::printf(", \"ct_tiles\": %ld, \"ct_wave_max\": %d", (long)tw, Tw.band_wave_tiles[(size_t)b]);
         }
         // per component: [rows, walked entries, distinct sources, tiles (16-row strips x 4 distinct sources), tiles of 32-row
         // strips, longest wave chunk, own nonzeros, depth levels (sparse plans)]
