@@ -1757,7 +1757,7 @@ class Engine : public EngineBase {
     c0 = count;
     if (fuse_s7) {
       if (L.s7_n > 0) {
-        hipLaunchKernelGGL((k_scatter_scale_list<D>), dim3(grid_for(L.s7_n, logR)), dim3(256), 0, st, v, L.qinv.as<int32_t>(),
+        hipLaunchKernelGGL((k_scatter_scale_list<D>), dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, (L.s7_n + 15) / 16))), dim3(256), 0, st, v, L.qinv.as<int32_t>(),
                            L.t.as<double>(), L.s7_list.as<int32_t>(), L.s7_n, yout, ldy, nrhs);
         ++count;
       }

@@ -198,9 +198,22 @@ __global__ void __launch_bounds__(256) k_scatter_scale_list(const T *__restrict_
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)xcd_block() * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t k = wave; k < cnt; k += nwaves) {
-    const int64_t i = list[k];
-    if (lane < nrhs) yout[i * ldy + lane] = vscale(t[i], v[((int64_t)qinv[i] << 6) + lane]);
+  // four rows per trip: the three dependent hops of a row (list -> q_inv, t -> v row) overlap across the four
+  constexpr int UR = 4;
+  for (int64_t k0 = wave * UR; k0 < cnt; k0 += nwaves * UR) {
+    int64_t i_[UR];
+    int32_t q_[UR];
+    double t_[UR];
+    T x_[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) i_[u] = list[min(k0 + u, cnt - 1)];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) q_[u] = qinv[i_[u]], t_[u] = t[i_[u]];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) x_[u] = v[((int64_t)q_[u] << 6) + lane];
+#pragma unroll
+    for (int u = 0; u < UR; ++u)
+      if (k0 + u < cnt && lane < nrhs) yout[i_[u] * ldy + lane] = vscale(t_[u], x_[u]);
   }
 }
 
@@ -2496,6 +2509,18 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
       // every own source sits in an earlier level (host.hpp build_cd_streams).  A wave takes a row at a time: the row's
       // (value, source) pairs come from LDS, so do the source rows -- no global access on the dependent path.
       const int nlvl = dsc[24];
+      if (dbg & 512) {  // (timing experiments: rows stored as they are, no substitution -- WRONG results)
+        for (int r = wave; r < nb; r += nw) {
+          const double a2 = cd_tbuf[(r << 6) + lane];
+          if (last_u) {
+            if (lane < lu.nrhs) yout[(int64_t)cd_oi[r] * lu.ldy + lane] = cd_ot[r] * a2;
+          } else {
+            x[((int64_t)cd_rowid[r] << 6) + lane] = a2;
+          }
+        }
+        __syncthreads();
+        continue;
+      }
       for (int lv = 0; lv < nlvl; ++lv) {
         const int r_lo = ow_lvl[lv], r_hi = ow_lvl[lv + 1];
         for (int r = r_lo + wave; r < r_hi; r += nw) {
