@@ -2522,9 +2522,21 @@ class Engine : public EngineBase {
   }
   // set-up / operator accounting beyond the 16 slots of hifamd_stats (hifir_amd.h hifamd_stats_ext)
   int stats_ext(double *o, int cap) const {
+    // resident bytes of this handle beside the explicit operators: the work arena of every level (w + v, Rmax columns),
+    // the coefficient tiles of the component bands, the factors with their plan arrays
+    double arena = 0.0, tiles = 0.0, factors = 0.0;
+    for (const auto &L : lv) {
+      arena += (double)L->arena.bytes;
+      for (const DevCsr *M : {&L->L, &L->U, &L->E, &L->F}) {
+        tiles += (double)(M->ct_sptr.bytes + M->ct_src.bytes + M->ct_coef.bytes + M->ct_desc.bytes);
+        factors += (double)(M->ptr.bytes + M->col.bytes + M->val.bytes + M->rowid.bytes + M->srcslot.bytes + M->split.bytes + M->csplit.bytes +
+                            M->cd_desc.bytes + M->mid_col.bytes + M->mid_val.bytes + M->mid_lrow.bytes + M->own_val.bytes + M->f_col.bytes +
+                            M->f_val.bytes + M->tl_ucol.bytes + M->tl_coef.bytes);
+      }
+    }
     const double v[] = {finalize_seconds, capture_ms,     bytes_inverses,  bytes_top,     bytes_tail,           (double)tail_n,
                         (double)tail_level, tail_probe_err, tail_max_abs, (double)tail_rejected, tail_probe_tol, tail_max_growth,
-                        (double)levels_from_cache, analysis_seconds};
+                        (double)levels_from_cache, analysis_seconds, arena, (double)Rmax, tiles, factors, (double)max_nrhs};
     const int nv = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < cap && i < nv; ++i) o[i] = v[i];
     return nv;

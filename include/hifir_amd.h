@@ -146,7 +146,10 @@ HifAmdStatus hifamd_stats(HifAmdHdl h, double *stats16);
  * was rejected (0 not, 1 not finite, 2 growth, 3 probe, 4 an error while it was formed), 10 / 11 the probe and growth
  * limits in force (HIFIR_AMD_TAIL_PROBE_TOL, HIFIR_AMD_TAIL_GROWTH), 12 levels whose analysis came from the trailer of the
  * file the handle was loaded from (hifamd_save_ex), 13 host seconds spent analyzing the levels (or adopting their
- * analysis).  -1 for a NULL handle. */
+ * analysis), 14 bytes of the work arena (w + v of every level), 15 its width in columns (this build: always 64 -- the
+ * fast kernels address a 64-column arena; max_nrhs bounds the batch width a call may pass, not the arena), 16 bytes of
+ * the component bands' coefficient tiles, 17 bytes of the factors with their plan arrays, 18 max_nrhs of hifamd_finalize.
+ * -1 for a NULL handle. */
 int hifamd_stats_ext(HifAmdHdl h, double *out, int cap);
 /* Per-level sizes (what the SURVEY 8(d) byte formula needs level by level): 0 m, 1 n, 2 nnz(L_B), 3 nnz(U_B), 4 nnz(E),
  * 5 nnz(F), 6 / 7 wavefronts of L / U, 8 / 9 launches ("bands") of the L / U plan, 10 rows of the combined top operator.

@@ -65,6 +65,15 @@ LhfStatus lhfzSaveHierarchy(const LhfzHifHdl hif, const char *path);
 LhfdHifHdl lhfdLoadHierarchy(const char *path);
 LhfzHifHdl lhfzLoadHierarchy(const char *path);
 
+/* What ONE replica of the handle keeps resident in HBM, in bytes (the sibling of lhf?GetStats, libhifir.h:700-716, for
+ * the device side): bytes[0] factors with their plan arrays, [1] explicit operators (block inverses, combined top
+ * operators, tail operator), [2] coefficient tiles of the component bands, [3] work arena, [4] columns of that arena,
+ * [5] the widest batch the handle was finalized for -- HIFIR_AMD_MAX_NRHS in the environment of lhf?Setup /
+ * lhf?LoadHierarchy (1 .. 64, default 64).  In this build the arena is 64 columns wide whatever was asked for (the
+ * fast kernels address a 64-column arena); a narrower request only bounds the tile width of lhf?ApplyBatch. */
+LhfStatus lhfdGetResidentBytes(const LhfdHifHdl hif, size_t bytes[6]);
+LhfStatus lhfzGetResidentBytes(const LhfzHifHdl hif, size_t bytes[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -213,6 +213,16 @@ LhfStatus upload_matrix(HifRec<V> *h) {
   return LHF_SUCCESS;
 }
 
+// HIFIR_AMD_MAX_NRHS (1 .. 64, default 64): the widest batch a handle of this process will be asked for -- what ship() and
+// hif_load() pass to hifamd_finalize.  A single-vector lhf?Solve user may say 1; lhf?ApplyBatch with more columns than
+// that is tiled.  (In this build the work arena stays 64 columns wide whatever is asked for: lhf?GetResidentBytes tells.)
+static int64_t shim_max_nrhs() {
+  const char *e = std::getenv("HIFIR_AMD_MAX_NRHS");
+  if (!e || !*e) return 64;
+  const long v = std::strtol(e, nullptr, 10);
+  return v < 1 ? 1 : (v > 64 ? 64 : v);
+}
+
 // M.precs() -> hifamd_add_level / hifamd_set_dense* -> hifamd_finalize, once per device
 template <class V>
 LhfStatus ship(HifRec<V> *h) {
@@ -249,7 +259,7 @@ LhfStatus ship(HifRec<V> *h) {
       }
       if (st != LHF_SUCCESS) return st;
     }
-    st = from_amd(hifamd_finalize(g, 64));
+    st = from_amd(hifamd_finalize(g, shim_max_nrhs()));
     if (st != LHF_SUCCESS) return st;
   }
   return upload_matrix(h);
@@ -430,6 +440,22 @@ void hif_stats(const HifRec<V> *h, std::size_t stats[]) {  // the nine slots of 
   }
 }
 
+// what one replica of the handle keeps in HBM (bytes): [0] factors + plan arrays, [1] explicit operators (block inverses,
+// combined tops, tail operator), [2] coefficient tiles of the component bands, [3] work arena, [4] arena columns,
+// [5] the batch width the handle was finalized for
+template <class V>
+LhfStatus hif_resident(const HifRec<V> *h, std::size_t out[6]) {
+  if (!h || !out) return fail("NULL argument");
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+  if (h->gpu.empty()) return fail("the handle has no hierarchy in HBM yet (lhf?Setup / lhf?LoadHierarchy)");
+  double v[19];
+  const int nv = hifamd_stats_ext(h->gpu[0], v, 19);
+  if (nv < 19) return fail("library too old for lhf?GetResidentBytes");
+  out[0] = (std::size_t)v[17], out[1] = (std::size_t)(v[2] + v[3] + v[4]), out[2] = (std::size_t)v[16], out[3] = (std::size_t)v[14];
+  out[4] = (std::size_t)v[15], out[5] = (std::size_t)v[18];
+  return LHF_SUCCESS;
+}
+
 template <class Hif, class V>
 Hif *hif_load(const char *path) {
   if (!path) {
@@ -451,7 +477,7 @@ Hif *hif_load(const char *path) {
         st = LHF_BAD_PREC;
       }
     }
-    if (st == LHF_SUCCESS) st = from_amd(hifamd_finalize(g, 64));
+    if (st == LHF_SUCCESS) st = from_amd(hifamd_finalize(g, shim_max_nrhs()));
     if (st != LHF_SUCCESS) {
       hif_destroy(h);
       return nullptr;
@@ -649,7 +675,11 @@ LHF_MATRIX_API(c, cflt, float _Complex)
     const char *ana = std::getenv("HIFIR_AMD_SAVE_ANALYSIS");                                                          \
     return from_amd(hifamd_save_ex(hif->gpu[0], path, (ana && ana[0] && ana[0] != '0') ? HIFAMD_SAVE_ANALYSIS : 0));   \
   }                                                                                                                   \
-  Lhf##T##HifHdl lhf##T##LoadHierarchy(const char *path) { return hif_load<Lhf##T##Hif, V>(path); }
+  Lhf##T##HifHdl lhf##T##LoadHierarchy(const char *path) { return hif_load<Lhf##T##Hif, V>(path); }                   \
+  LhfStatus lhf##T##GetResidentBytes(const Lhf##T##HifHdl hif, size_t bytes[6]) {                                     \
+    if (!hif) return LHF_NULL_OBJ;                                                                                    \
+    return hif_resident<V>(hif, bytes);                                                                               \
+  }
 
 LHF_HIF_API(d, double, double)
 LHF_HIF_API(z, zdbl, double _Complex)

@@ -170,6 +170,65 @@ static int run_cd(int64_t m, int fan, int64_t cd_rows, int64_t dense_block, bool
           if (e != mid0 + nmid) ++bad;
         }
     }
+    // the tile form of the same entries (build_ct_tiles, kernel k_band_ct), read the way the kernel reads it: the four
+    // waves' strip masks partition the component's strips, and per strip  sum over its tiles of coef[16 x 4] * x[4 sources]
+    // equals the rows' entry sums; every tile's sources are rows finished before the component
+    if (!sparse) {
+      if constexpr (std::is_same<T, double>::value) {
+        CtTiles Tl;
+        build_ct_tiles(P, Rs, Tl);
+        std::vector<double> xs((size_t)m);
+        std::mt19937_64 gt(313 + m);
+        for (auto &vv : xs) vv = u(gt);
+        int64_t ntile_seen = 0, ncomp_ct = 0;
+        for (int64_t bnd = 0; bnd < P.nbands(); ++bnd) {
+          if (!P.band_cd[(size_t)bnd]) continue;
+          for (int32_t gg = P.band_wg_ptr[(size_t)bnd]; gg < P.band_wg_ptr[(size_t)bnd + 1]; ++gg)
+            for (int32_t c = P.wg_grp_ptr[(size_t)gg]; c < P.wg_grp_ptr[(size_t)gg + 1]; ++c, ++ncomp_ct) {
+              const int32_t *dsc = &Tl.desc[(size_t)c * kCdDescWords];
+              const int32_t s0 = dsc[0], nb = dsc[1], sp0 = dsc[20], S = (nb + 15) / 16;
+              const uint32_t masks[4] = {(uint32_t)dsc[22] & 0xffffu, (uint32_t)dsc[22] >> 16, (uint32_t)dsc[23] & 0xffffu, (uint32_t)dsc[23] >> 16};
+              uint32_t seen = 0;
+              for (int w = 0; w < 4; ++w) {
+                if (seen & masks[w]) ++bad;  // (a strip owned twice)
+                seen |= masks[w];
+              }
+              if (seen != (S >= 32 ? 0xffffffffu : ((1u << S) - 1u))) ++bad;
+              for (int32_t st = 0; st < S; ++st) {
+                const int32_t t0 = Tl.sptr[(size_t)(sp0 + st)], t1 = Tl.sptr[(size_t)(sp0 + st + 1)];
+                if (t1 < t0 || (int64_t)t1 > Tl.ntiles) {
+                  ++bad;
+                  continue;
+                }
+                ntile_seen += t1 - t0;
+                double acc[16];
+                for (double &a : acc) a = 0.0;
+                for (int32_t t = t0; t < t1; ++t)
+                  for (int k = 0; k < 4; ++k) {
+                    const int32_t src = Tl.src[(size_t)(4 * t + k)];
+                    bool older = false;  // a source row: finished before this component (its slot lies in front of it)
+                    for (int32_t r = 16 * st; r < std::min(nb, 16 * st + 16) && !older; ++r)
+                      for (int32_t kk = P.split[(size_t)(s0 + r)]; kk < P.csplit[(size_t)(s0 + r)]; ++kk)
+                        if (Rs.col[(size_t)kk] == src) older = true;
+                    if (!older) {  // (a padding slot repeats the tile's last real source with zero coefficients)
+                      for (int r = 0; r < 16; ++r)
+                        if (Tl.coef[(size_t)(64 * t + (k << 4) + r)] != 0.0) ++bad;
+                    }
+                    for (int r = 0; r < 16; ++r) acc[r] += Tl.coef[(size_t)(64 * t + (k << 4) + r)] * xs[(size_t)src];
+                  }
+                for (int32_t r = 16 * st; r < std::min(nb, 16 * st + 16); ++r) {
+                  double ref = 0.0;
+                  for (int32_t kk = P.split[(size_t)(s0 + r)]; kk < P.csplit[(size_t)(s0 + r)]; ++kk) ref += Rs.val[(size_t)kk] * xs[(size_t)Rs.col[(size_t)kk]];
+                  if (std::fabs(ref - acc[r - 16 * st]) > 1e-12 * (1.0 + std::fabs(ref))) ++bad;
+                }
+                for (int32_t r = std::min(nb, 16 * st + 16); r < 16 * st + 16; ++r)
+                  if (acc[r - 16 * st] != 0.0) ++bad;  // (rows behind the component's end carry no coefficient)
+              }
+            }
+        }
+        if (ncomp_ct && ntile_seen != Tl.ntiles) ++bad;
+      }
+    }
     // S5 fused into the L streams (build_cd_streams_fused): every row's stream entries are its [split, csplit) L entries
     // followed by its F entries shifted to the child's rows, wave chunk by wave chunk with the plain streams' ownership;
     // checked numerically too: rhs - sum (stream entries) == rhs - L_old x - F y for random x, y

@@ -68,6 +68,7 @@ def lib():
             g("SaveHierarchy").argtypes = [_vp, C.c_char_p]
             g("LoadHierarchy").restype = _vp
             g("LoadHierarchy").argtypes = [C.c_char_p]
+            g("GetResidentBytes").argtypes = [_vp, C.POINTER(_sz)]
         for f in ("lhfsdUpdate", "lhfczUpdate"):
             getattr(L, f).argtypes = [_vp, _vp]
         for f in ("lhfsdApply", "lhfczApply"):

@@ -407,7 +407,7 @@ def test_integration_doc_matches_headers():
     norm = lambda t: re.sub(r"\s+", " ", t).strip()
     proto_re = r"^(?:LhfStatus|int|Lhf[dz]HifHdl)\s+lhf\w+\([^;]*\);"
     hdr_protos = [norm(p) for p in re.findall(proto_re, ext, flags=re.M)]
-    assert len(hdr_protos) == 14
+    assert len(hdr_protos) == 16
     blocks = re.findall(r"```c\n(.*?)```", doc, flags=re.S)
     doc_protos = [norm(p) for b in blocks for p in re.findall(proto_re, b, flags=re.M)]
     assert doc_protos == hdr_protos  # same prototypes, same order, same argument lists

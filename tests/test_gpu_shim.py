@@ -249,3 +249,30 @@ def test_single_precision_families_refuse(real_case):
     assert L.lhfsdApply(fake, su.LHF_S, su._ptr(b), 1, None, -2, su._ptr(b.copy()), None) == su.LHF_HIFIR_ERROR
     assert su.errmsg() and su.errmsg() is None
     As.close()
+
+
+def test_handle_finalized_for_a_narrow_batch_gives_the_same_bits(real_case, monkeypatch):
+    """HIFIR_AMD_MAX_NRHS (what a single-vector lhf?Solve user sets): a handle finalized for 16 columns solves to the very
+    bits of the default (64-column) handle, a wider lhf?ApplyBatch on it is tiled, and lhf?GetResidentBytes reports what
+    one replica keeps in HBM (libhifir.h:685-716 has no counterpart: additive, include/libhifir_amd_ext.h)."""
+    levels, d, A, M = real_case
+    st, x64 = M.solve(d["b"])
+    assert st == su.LHF_SUCCESS
+    res64 = (su._sz * 6)()
+    assert M._f("GetResidentBytes")(M.h, res64) == su.LHF_SUCCESS
+    assert res64[0] > 0 and res64[3] > 0 and res64[4] == 64 and res64[5] == 64
+    monkeypatch.setenv("HIFIR_AMD_MAX_NRHS", "16")
+    M16 = su.Hif("d", A, None, su.default_params())
+    assert M16.h, su.errmsg()
+    try:
+        res16 = (su._sz * 6)()
+        assert M16._f("GetResidentBytes")(M16.h, res16) == su.LHF_SUCCESS
+        assert res16[5] == 16 and res16[0] == res64[0] and res16[1] == res64[1]
+        st, x16 = M16.solve(d["b"])
+        assert st == su.LHF_SUCCESS and np.array_equal(x16, x64)
+        B = np.stack([d["b"] * (1.0 + 0.25 * k) for k in range(40)], axis=1)  # wider than the handle was finalized for
+        st, X16, _ = M16.apply_batch(su.LHF_S, B)
+        st2, X64, _ = M.apply_batch(su.LHF_S, B)
+        assert st == su.LHF_SUCCESS and st2 == su.LHF_SUCCESS and np.array_equal(X16, X64)
+    finally:
+        M16.close()

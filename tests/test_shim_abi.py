@@ -33,7 +33,7 @@ def test_exports_every_reference_symbol():
     assert not [s for s in req if s not in have]
     # the additive entry points of include/libhifir_amd_ext.h
     ext = re.findall(r"\b(lhf\w+)\s*\(", open(os.path.join(ROOT, "include", "libhifir_amd_ext.h")).read())
-    assert len(set(ext)) == 14 and not [s for s in ext if s not in have]
+    assert len(set(ext)) == 16 and not [s for s in ext if s not in have]
     # all four type families, incl. the mixed-precision ones
     for s in ("lhfsCreate", "lhfcApply", "lhfsdApply", "lhfczSolve", "lhfsdUpdate", "lhfEnableWarning"):
         assert s in have
