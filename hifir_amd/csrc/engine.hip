@@ -168,6 +168,7 @@ struct DevCsr {
   // tiled form of a coupling block (E, F) for k_spmm_tile (host.hpp SpmmTiles); nblk == 0: not built
   DevBuf tl_gptr, tl_ucol, tl_coef;
   int64_t tl_nblk = 0;
+  int tl_rb = 1;  // 16-row tiles per block (host.hpp SpmmTiles::rb)
 
   void alias(const DevCsr &o) {  // share the device arrays, copy the (small) host-side launch metadata
     nrows = o.nrows;
@@ -215,6 +216,7 @@ struct DevCsr {
     tl_ucol.alias(o.tl_ucol);
     tl_coef.alias(o.tl_coef);
     tl_nblk = o.tl_nblk;
+    tl_rb = o.tl_rb;
     band_wg_ptr = o.band_wg_ptr;
     band_slot_ptr = o.band_slot_ptr;
     band_prefix = o.band_prefix;
@@ -413,6 +415,8 @@ class Engine : public EngineBase {
   double finalize_seconds = 0.0, capture_ms = 0.0;  // set-up cost: hifamd_finalize, the last hipGraph capture + instantiate
   double bytes_inverses = 0.0, bytes_top = 0.0, bytes_tail = 0.0;  // resident explicit operators (HBM)
   bool fuse_out = true;    // S7 fused into the last band of the final U solve (HIFIR_AMD_FUSE_S7=0: k_scatter_scale over all rows)
+  int spmm_rb = 1;          // HIFIR_AMD_SPMM_RB: 16-row tiles per block of the tiled Schur products (1; 2 measured slower: fewer, longer chains)
+  int spmm_split_blocks = 4096;  // HIFIR_AMD_SPMM_SPLIT_BLOCKS: fewer blocks than this -> one block per workgroup (k_spmm_tile4)
   bool spmm_split = true;  // tiled Schur products: one 16-row block per workgroup (k_spmm_tile4); HIFIR_AMD_SPMM_SPLIT=0: per wave
   int carry_wgs = 512;   // workgroups a band's launch may add for the carried prefix of the next band (HIFIR_AMD_CARRY_WGS)
   bool fuse_f = true;    // S5 fused into the second L solve where the plan allows (HIFIR_AMD_FUSE_F=0: separate k_spmm_epi launch)
@@ -435,6 +439,7 @@ class Engine : public EngineBase {
   int device_inverses = 1;  // HIFIR_AMD_DEVICE_INVERSES=0: the block inverses of finalize are formed by the host threads and uploaded
   int cs_max_wgs = 0;    // HIFIR_AMD_CS_MAX_WGS (full batches: measured equal to k_band_cd at every band width)
   int ct_wide_wgs = 128; // HIFIR_AMD_CT_WIDE: a component band with more workgroups than this takes two column tiles per workgroup
+  int ct_wide4_wgs = 1 << 30;  // HIFIR_AMD_CT_WIDE4: ... and with more than this all four (one workgroup per component)
   int ct_mode = 1;       // HIFIR_AMD_CT=0: dense-own component bands walk their entries one by one (k_band_cd / k_band_cs) instead of
                          // multiplying 16 x 4 coefficient tiles on the matrix cores (k_band_ct)
   int act_cols = 64;     // columns of the 64-column arena that the tile being enqueued actually uses (enqueue_apply)
@@ -490,7 +495,10 @@ class Engine : public EngineBase {
     cs_mode = env_int("HIFIR_AMD_CS", 1);
     cs_max_wgs = env_int("HIFIR_AMD_CS_MAX_WGS", 0);
     ct_mode = env_int("HIFIR_AMD_CT", 1);
+    spmm_rb = env_int("HIFIR_AMD_SPMM_RB", 1) == 2 ? 2 : 1;
+    spmm_split_blocks = env_int("HIFIR_AMD_SPMM_SPLIT_BLOCKS", 4096);
     ct_wide_wgs = env_int("HIFIR_AMD_CT_WIDE", 128);
+    ct_wide4_wgs = env_int("HIFIR_AMD_CT_WIDE4", 1 << 30);
     cs_sparse = env_int("HIFIR_AMD_CS_SPARSE", 0);
     device_inverses = env_int("HIFIR_AMD_DEVICE_INVERSES", 1);
     narrow_spmm = env_int("HIFIR_AMD_NARROW_SPMM", 1);
@@ -541,6 +549,8 @@ class Engine : public EngineBase {
     HIP_OK(hipSetDevice(device));
     if (!stream) HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     if (sizeof(T) == sizeof(double) && band_opt.cd_rows > 0) {  // k_band_cd keeps a component in up to 128 KB of LDS
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_ct<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ct_lds_bytes(4)));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_ct<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ct_lds_bytes(4)));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(false)));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(false)));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(cd_lds_bytes(true), 160 * 1024)));
@@ -650,7 +660,10 @@ class Engine : public EngineBase {
       E->cs_mode = cs_mode;
       E->cs_max_wgs = cs_max_wgs;
       E->ct_mode = ct_mode;
+      E->spmm_rb = spmm_rb;
+      E->spmm_split_blocks = spmm_split_blocks;
       E->ct_wide_wgs = ct_wide_wgs;
+      E->ct_wide4_wgs = ct_wide4_wgs;
       E->cs_sparse = cs_sparse;
       E->narrow_spmm = narrow_spmm;
       E->cd_split_min = cd_split_min;
@@ -713,7 +726,10 @@ class Engine : public EngineBase {
       E->cs_mode = cs_mode;
       E->cs_max_wgs = cs_max_wgs;
       E->ct_mode = ct_mode;
+      E->spmm_rb = spmm_rb;
+      E->spmm_split_blocks = spmm_split_blocks;
       E->ct_wide_wgs = ct_wide_wgs;
+      E->ct_wide4_wgs = ct_wide4_wgs;
       E->cs_sparse = cs_sparse;
       E->narrow_spmm = narrow_spmm;
       E->cd_split_min = cd_split_min;
@@ -1005,8 +1021,9 @@ class Engine : public EngineBase {
           const Csr<T> &Ah = which ? H.Fr : H.Er;
           DevCsr &Md = which ? L.F : L.E;
           if (Ah.nrows < 64 || Ah.col.size() < 8 * (size_t)Ah.nrows) continue;  // (sparse rows share too little)
-          SpmmTiles Tl = build_spmm_tiles(Ah);
+          SpmmTiles Tl = build_spmm_tiles(Ah, spmm_rb);
           if (Tl.reuse < spmm_tile_reuse) continue;
+          Md.tl_rb = Tl.rb;
           Md.tl_gptr.upload(Tl.blk_gptr);
           Md.tl_ucol.upload(Tl.ucol);
           Md.tl_coef.upload(Tl.coef);
@@ -1556,10 +1573,10 @@ class Engine : public EngineBase {
         // a wide band takes two column tiles per workgroup (a coefficient tile is fetched for 32 columns at once); a narrow
         // one a workgroup per 16-column slice: its heaviest component then runs on four compute units
         const int ncols = (act_cols + 15) / 16;  // column tiles in use
-        const int nct = (ncols >= 2 && g1 - g0 > ct_wide_wgs) ? 2 : 1;
+        const int nct = (ncols == 4 && g1 - g0 > ct_wide4_wgs) ? 4 : ((ncols >= 2 && g1 - g0 > ct_wide_wgs) ? 2 : 1);
         const int nslc = (ncols + nct - 1) / nct;
         const unsigned grid = (unsigned)(((g1 - g0 + 7) / 8) * 8 * nslc) + 4 * extra;
-        auto kct = nct == 2 ? k_band_ct<LOWER, 2> : k_band_ct<LOWER, 1>;
+        auto kct = nct == 4 ? k_band_ct<LOWER, 4> : (nct == 2 ? k_band_ct<LOWER, 2> : k_band_ct<LOWER, 1>);
         hipLaunchKernelGGL(kct, dim3(grid), dim3(256), ct_lds_bytes(nct), st, g0,
                            M.wg_grp_ptr.as<int32_t>(), M.ct_desc.as<int32_t>(), M.ptr.as<int32_t>(), M.split.as<int32_t>(),
                            M.col.as<int32_t>(), M.val.as<double>(), M.rowid.as<int32_t>(), L.d.as<double>(), L.w.as<double>(),
@@ -1667,15 +1684,17 @@ class Engine : public EngineBase {
     if constexpr (std::is_same<T, double>::value) {
       // one block per workgroup, its groups dealt to the four waves: where the per-wave kernel would leave the chip short
       // of waves (with more blocks the product runs at the fabric's gather bandwidth either way: 95 vs 100 us, 101 vs 123 us)
-      if (A.tl_nblk > 0 && A.tl_nblk < 4096 && logR == 6 && spmm_split) {
-        hipLaunchKernelGGL(k_spmm_tile4, dim3((unsigned)A.tl_nblk), dim3(256), 0, st, nrows, A.tl_nblk, A.tl_gptr.as<int32_t>(),
+      if (A.tl_nblk > 0 && A.tl_nblk < spmm_split_blocks && logR == 6 && spmm_split) {
+        auto k4 = A.tl_rb == 2 ? k_spmm_tile4<2> : k_spmm_tile4<1>;
+        hipLaunchKernelGGL(k4, dim3((unsigned)A.tl_nblk), dim3(256), 0, st, nrows, A.tl_nblk, A.tl_gptr.as<int32_t>(),
                            A.tl_ucol.as<int32_t>(), A.tl_coef.as<double>(), (const double *)x, bin, ldb, nrhs, L.p.as<int32_t>(),
                            L.s.as<double>(), roff, out);
         return;
       }
       if (A.tl_nblk > 0 && logR == 6) {
         const unsigned grid = (unsigned)std::min<int64_t>((A.tl_nblk + 3) / 4, 256 * 16);
-        hipLaunchKernelGGL(k_spmm_tile, dim3(grid), dim3(256), 0, st, nrows, A.tl_nblk, A.tl_gptr.as<int32_t>(),
+        auto k1 = A.tl_rb == 2 ? k_spmm_tile<2> : k_spmm_tile<1>;
+        hipLaunchKernelGGL(k1, dim3(grid), dim3(256), 0, st, nrows, A.tl_nblk, A.tl_gptr.as<int32_t>(),
                            A.tl_ucol.as<int32_t>(), A.tl_coef.as<double>(), (const double *)x, bin, ldb, nrhs, L.p.as<int32_t>(),
                            L.s.as<double>(), roff, out);
         return;

@@ -1464,23 +1464,26 @@ Csr<T> permute_rows(const Csr<T> &A, const std::vector<int32_t> &order) {
 // ---------------------------------------------------------------------------------------------
 struct SpmmTiles {
   int64_t nrows = 0, nblk = 0;
+  int rb = 1;                     // 16-row tiles per block (a block's distinct columns are gathered once for all of them)
   std::vector<int32_t> blk_gptr;  // nblk + 1: the groups of block b
   std::vector<int32_t> ucol;      // 4 per group (padded with a repeated column whose coefficients are zero)
-  std::vector<double> coef;       // 64 per group: element l = (k << 4) | r  ->  A(16 b + r, ucol[4 g + k])
+  std::vector<double> coef;       // 64 rb per group: element rb_ * 64 + (k << 4) | r  ->  A(16 (rb b + rb_) + r, ucol[4 g + k])
   double reuse = 0.0;             // nonzeros per distinct (block, column) pair
 };
 
-inline SpmmTiles build_spmm_tiles(const Csr<double> &A) {
+inline SpmmTiles build_spmm_tiles(const Csr<double> &A, int rb = 1) {
   SpmmTiles Tl;
   Tl.nrows = A.nrows;
-  Tl.nblk = (A.nrows + 15) / 16;
+  Tl.rb = rb;
+  const int64_t brows = 16 * (int64_t)rb;
+  Tl.nblk = (A.nrows + brows - 1) / brows;
   Tl.blk_gptr.assign((size_t)Tl.nblk + 1, 0);
-  // pass 1: distinct columns per block (rows are sorted by column: a 16-way merge via sort of the block's columns)
+  // pass 1: distinct columns per block (rows are sorted by column: a merge via sort of the block's columns)
   std::vector<std::vector<int32_t>> ucols((size_t)Tl.nblk);
   int64_t distinct = 0;
   parallel_for(Tl.nblk, 256, [&](int64_t b0, int64_t b1) {
     for (int64_t b = b0; b < b1; ++b) {
-      const int64_t r0 = 16 * b, r1 = std::min<int64_t>(A.nrows, r0 + 16);
+      const int64_t r0 = brows * b, r1 = std::min<int64_t>(A.nrows, r0 + brows);
       std::vector<int32_t> &u = ucols[(size_t)b];
       u.assign(A.col.begin() + A.ptr[(size_t)r0], A.col.begin() + A.ptr[(size_t)r1]);
       std::sort(u.begin(), u.end());
@@ -1494,24 +1497,25 @@ inline SpmmTiles build_spmm_tiles(const Csr<double> &A) {
   Tl.reuse = distinct ? (double)A.col.size() / (double)distinct : 0.0;
   const int64_t ng = Tl.blk_gptr[(size_t)Tl.nblk];
   Tl.ucol.assign((size_t)(4 * ng), 0);
-  Tl.coef.assign((size_t)(64 * ng), 0.0);
+  Tl.coef.assign((size_t)(64 * rb * ng), 0.0);
   parallel_for(Tl.nblk, 256, [&](int64_t b0, int64_t b1) {
     for (int64_t b = b0; b < b1; ++b) {
       const std::vector<int32_t> &u = ucols[(size_t)b];
       const int64_t g0 = Tl.blk_gptr[(size_t)b], g1 = Tl.blk_gptr[(size_t)b + 1];
       for (int64_t q = 0; q < 4 * (g1 - g0); ++q)
         Tl.ucol[(size_t)(4 * g0 + q)] = u.empty() ? 0 : u[(size_t)std::min<int64_t>(q, (int64_t)u.size() - 1)];
-      const int64_t r0 = 16 * b, r1 = std::min<int64_t>(A.nrows, r0 + 16);
+      const int64_t r0 = brows * b, r1 = std::min<int64_t>(A.nrows, r0 + brows);
       for (int64_t i = r0; i < r1; ++i)
         for (int32_t k = A.ptr[(size_t)i]; k < A.ptr[(size_t)i + 1]; ++k) {
           const int64_t q = std::lower_bound(u.begin(), u.end(), A.col[(size_t)k]) - u.begin();  // position in the block's list
-          Tl.coef[(size_t)(64 * (g0 + q / 4) + ((q & 3) << 4) + (i - r0))] += A.val[(size_t)k];
+          const int64_t rl = i - r0;
+          Tl.coef[(size_t)(64 * rb * (g0 + q / 4) + 64 * (rl >> 4) + ((q & 3) << 4) + (rl & 15))] += A.val[(size_t)k];
         }
     }
   });
   return Tl;
 }
-inline SpmmTiles build_spmm_tiles(const Csr<zdouble> &) { return SpmmTiles(); }  // (real data only)
+inline SpmmTiles build_spmm_tiles(const Csr<zdouble> &, int = 1) { return SpmmTiles(); }  // (real data only)
 
 // ---------------------------------------------------------------------------------------------
 // one level + the whole hierarchy (host copy)

@@ -33,8 +33,24 @@ struct Sink {
   void set_dense_lup(int64_t nd, const double *) { std::printf("{\"dense_n\": %ld}\n", (long)nd); }
 
   void dump(const HostLevel<double> &H) {
-    std::printf("{\"level\": %zu, \"m\": %ld, \"n\": %ld, \"nnzE\": %zu, \"nnzF\": %zu, \"top_n\": %ld}\n", level_no, (long)H.m, (long)H.n,
-                H.Er.col.size(), H.Fr.col.size(), (long)H.top_n);
+    // distinct (row block, column) pairs of E and F for blocks of 16 / 32 / 64 rows: what a tiled Schur product gathers
+    long dist[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    for (int which = 0; which < 2; ++which) {
+      const Csr<double> &M = which ? H.Fr : H.Er;
+      for (int bi = 0; bi < 3; ++bi) {
+        const int64_t bs = 16 << bi;
+        std::vector<int32_t> u;
+        for (int64_t r0 = 0; r0 < M.nrows; r0 += bs) {
+          const int64_t r1 = std::min<int64_t>(M.nrows, r0 + bs);
+          u.assign(M.col.begin() + M.ptr[(size_t)r0], M.col.begin() + M.ptr[(size_t)r1]);
+          std::sort(u.begin(), u.end());
+          dist[which][bi] += (long)(std::unique(u.begin(), u.end()) - u.begin());
+        }
+      }
+    }
+    std::printf("{\"level\": %zu, \"m\": %ld, \"n\": %ld, \"nnzE\": %zu, \"nnzF\": %zu, \"top_n\": %ld, \"distinctE\": [%ld, %ld, %ld], "
+                "\"distinctF\": [%ld, %ld, %ld]}\n", level_no, (long)H.m, (long)H.n, H.Er.col.size(), H.Fr.col.size(), (long)H.top_n,
+                dist[0][0], dist[0][1], dist[0][2], dist[1][0], dist[1][1], dist[1][2]);
     for (int tri = 0; tri < 2; ++tri) {
       const BandPlan &P = tri ? H.Up : H.Lp;
       const Csr<double> &A = tri ? H.Ur : H.Lr;
