@@ -74,7 +74,13 @@ ms = M.time_apply(Bd, Xd, warmup=2, reps=reps)
 balg = M.algorithmic_bytes(nrhs)
 print(f"RESULT nx={nx} mode={mode} nrhs={nrhs}: {ms:.3f} ms/batch  {nrhs / ms * 1e3:.0f} RHS-applies/s  "
       f"B_alg={balg / 1e9:.3f} GB  {balg / ms / 1e6:.1f} GB/s  frac_of_8TB/s={balg / ms / 1e6 / 8000:.4f}", flush=True)
+import json  # noqa: E402
 import os  # noqa: E402
+
+# for tests/profile_config.sh: which level / stage every launch of the apply belongs to, and B_alg level by level
+print("LAUNCHMAP " + json.dumps({"map": [16 * l + s_ for (l, s_) in M.launch_map()],
+                                 "level_bytes": {str(l): {str(k): v for k, v in d_.items()} for l, d_ in M.level_bytes(nrhs).items()},
+                                 "level_rows": [int(M.level_stats(l)["n"]) for l in range(int(M.stats()["sparse_levels"]))]}), flush=True)
 
 if os.environ.get("GMRES"):  # GMRES(30) on all columns: time per inner step (apply + SpMM + Gram-Schmidt)
     M.set_matrix(A.indptr, A.indices, A.data)

@@ -17,6 +17,34 @@ timeout -k 10 1100 rocprofv3 --kernel-trace --stats -d $OUT --output-format csv 
   echo "# BASELINE secondary configuration: tests/perf_probe.py $NX $MODE $NRHS under rocprofv3 --kernel-trace --stats"
   echo "# git_head=$HEAD lib_sha256=$SHA"
   grep -E "reference factorize|import\+upload|first apply|relerr|RESULT" $OUT/probe.log
+  echo "# per level, from the LAST apply of the trace attributed with the library's launch map (microseconds; bytes: SURVEY 8(d))"
+  python3 - "$OUT" <<'PY'
+import csv, glob, json, sys
+out = sys.argv[1]
+lm = None
+for ln in open(out + "/probe.log"):
+    if ln.startswith("LAUNCHMAP "):
+        lm = json.loads(ln[10:])
+kt = glob.glob(out + "/*/*kernel_trace.csv")
+if lm and kt:
+    rows = sorted((r for r in csv.DictReader(open(kt[0])) if "hifamd" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+    mp = lm["map"]
+    last = rows[-len(mp):]
+    grp = {1: "in+LDU", 2: "in+LDU", 3: "E", 4: "dense/tail", 5: "F+LDU+out", 6: "F+LDU+out", 7: "F+LDU+out"}
+    t, cnt = {}, {}
+    for r, m in zip(last, mp):
+        key = (m // 16, grp.get(m % 16, "other"))
+        t[key] = t.get(key, 0.0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        cnt[key] = cnt.get(key, 0) + 1
+    tot = sum(t.values())
+    for lv in sorted({k[0] for k in t}):
+        lb = sum(float(v) for v in lm["level_bytes"].get(str(lv), {}).values())
+        us = sum(v for k, v in t.items() if k[0] == lv)
+        parts = "  ".join(f"{g} {t[(lv, g)]:.0f} us / {cnt[(lv, g)]} launches" for g in ("in+LDU", "E", "dense/tail", "F+LDU+out") if (lv, g) in t)
+        rows_ = lm["level_rows"][lv] if lv < len(lm["level_rows"]) else 0
+        print(f"level {lv} ({rows_} rows): {us:9.0f} us  {100 * us / tot:5.1f} %  {lb / 1e9:7.2f} GB  {lb / us / 1e6 if us else 0:6.2f} TB/s   {parts}")
+    print(f"one apply: {len(mp)} launches, {tot / 1e3:.3f} ms of kernel time")
+PY
   echo "# kernels (all applies of the run: warm-up, parity check and timed repetitions), by total time"
   python3 - "$OUT" <<'PY'
 import csv, glob, sys
