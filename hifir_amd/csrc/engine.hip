@@ -536,7 +536,12 @@ class Engine : public EngineBase {
     band_opt.cd_sparse_rows = std::min(240, env_int("HIFIR_AMD_CD_SPARSE_ROWS", 192));  // 0: thin triangles keep the flag bands
     band_opt.top_max = env_int("HIFIR_AMD_TOP_ROWS", 4096);      // combined top operator (host.hpp choose_top); 0 = off
     band_opt.top_few_wgs = env_int("HIFIR_AMD_TOP_WGS", 96);
-    if (sizeof(T) != sizeof(double)) band_opt.top_max = 0, band_opt.cd_sparse_rows = 0, band_opt.cd_max_nnz = env_int("HIFIR_AMD_CD_NNZ_Z", 0);
+    // complex handles: no combined top; sparse-own components for shallow thin triangles since round 4 (HIFIR_AMD_CD_SPARSE_ROWS_Z=0:
+    // those triangles keep the round-1 flag bands)
+    if (sizeof(T) != sizeof(double))
+      band_opt.top_max = 0, band_opt.cd_sparse_rows = std::min(240, env_int("HIFIR_AMD_CD_SPARSE_ROWS_Z", 192)),
+      band_opt.cd_max_nnz = env_int("HIFIR_AMD_CD_NNZ_Z", 0);
+    band_opt.cd_sparse_min_rows = env_int("HIFIR_AMD_CD_SPARSE_MIN_ROWS", 4096);
     if (band_opt.cd_rows > 240) band_opt.cd_rows = 240;  // (local row ids are bytes; 120 KB of the CU's 160 KB LDS)
   }
 
@@ -563,6 +568,8 @@ class Engine : public EngineBase {
     HIP_OK(hipFuncSetAttribute((const void *)k_top_gemm<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTopGemmLds));
     HIP_OK(hipFuncSetAttribute((const void *)k_top_gemm<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTopGemmLds));
     if (sizeof(T) != sizeof(double) && band_opt.cd_rows > 0) {
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cs_z<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(csz_lds_bytes(true, kCdOwnCap), 160 * 1024)));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_cs_z<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(csz_lds_bytes(true, kCdOwnCap), 160 * 1024)));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd_z<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes_z()));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd_z<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes_z()));
     }
@@ -1548,6 +1555,14 @@ class Engine : public EngineBase {
       return false;
     }
   }
+  // LDS of k_band_cs_z: two real planes [rows][16], per row two doubles and two int32; sparse-own plans add the own nonzeros
+  // (two doubles + a byte each), row offsets and depth levels
+  size_t csz_lds_bytes(bool sparse, int32_t own_cap) const {
+    const size_t rows = (size_t)(sparse ? band_opt.cd_sparse_rows : ((band_opt.cd_rows + 31) & ~(int64_t)31));
+    size_t b = rows * (2 * 16 + 2) * sizeof(double) + (((rows + 1) & ~(size_t)1) + rows) * sizeof(int32_t) + 16;
+    if (sparse) b += (size_t)own_cap * (2 * sizeof(double) + 2) + 260 * sizeof(uint16_t) + 264;
+    return b;
+  }
   size_t cd_lds_bytes_z() const {  // complex: two real planes of the component's right-hand sides + row ids
     const size_t rows = (size_t)band_opt.cd_rows;
     return rows * 128 * sizeof(double) + ((rows + 1) & ~(size_t)1) * sizeof(int32_t);
@@ -1608,15 +1623,24 @@ class Engine : public EngineBase {
                          M.own_lvl.as<uint8_t>(), lu);
     } else {
       (void)ps0, (void)ps1, (void)with_f, (void)lu;
-      if (extra || M.cd_sparse) throw Error(HIFAMD_HIFIR_ERROR, "internal error: carried prefix / sparse-own component band on a complex handle");
+      if (extra) throw Error(HIFAMD_HIFIR_ERROR, "internal error: carried prefix on a complex handle");
       const int nslz = std::min(4, (act_cols + 15) / 16);
+      if (M.cd_sparse) {  // sparse-own components (round 4): 16-column slices at every batch width
+        const int32_t rows = (int32_t)band_opt.cd_sparse_rows;
+        hipLaunchKernelGGL((k_band_cs_z<LOWER, true>), dim3((unsigned)((g1 - g0) * nslz)), dim3(256), csz_lds_bytes(true, M.own_cap), st, g0,
+                           M.wg_grp_ptr.as<int32_t>(), M.cd_desc.as<int32_t>(), M.rowid.as<int32_t>(), L.d.as<cplx>(), L.w.as<cplx>(),
+                           L.v.as<cplx>(), M.tinv.as<double>(), M.mid_col.as<int32_t>(), M.mid_val.as<cplx>(), M.mid_lrow.as<uint8_t>(),
+                           pre ? 0 : 1, (int32_t)nslz, rows, fl, M.own_cap, M.own_val.as<cplx>(), M.own_lsrc.as<uint8_t>(),
+                           M.own_rptr.as<uint16_t>(), M.own_lvl.as<uint8_t>());
+        return;
+      }
       if (cs_mode && nslz < 4 && (int64_t)(g1 - g0) * nslz < (1LL << 30)) {  // a narrow batch: only the slices it has
         const int32_t rows = (int32_t)((band_opt.cd_rows + 31) & ~(int64_t)31);
-        const size_t ldsz = (size_t)rows * (2 * 16 + 2) * sizeof(double) + (size_t)rows * 2 * sizeof(int32_t) + 16;
-        hipLaunchKernelGGL(k_band_cs_z<LOWER>, dim3((unsigned)((g1 - g0) * nslz)), dim3(256), ldsz, st, g0, M.wg_grp_ptr.as<int32_t>(),
-                           M.cd_desc.as<int32_t>(), M.rowid.as<int32_t>(), L.d.as<cplx>(), L.w.as<cplx>(), L.v.as<cplx>(),
-                           M.tinv.as<double>(), M.mid_col.as<int32_t>(), M.mid_val.as<cplx>(), M.mid_lrow.as<uint8_t>(), pre ? 0 : 1,
-                           (int32_t)nslz, rows, fl);
+        hipLaunchKernelGGL((k_band_cs_z<LOWER, false>), dim3((unsigned)((g1 - g0) * nslz)), dim3(256), csz_lds_bytes(false, 0), st, g0,
+                           M.wg_grp_ptr.as<int32_t>(), M.cd_desc.as<int32_t>(), M.rowid.as<int32_t>(), L.d.as<cplx>(), L.w.as<cplx>(),
+                           L.v.as<cplx>(), M.tinv.as<double>(), M.mid_col.as<int32_t>(), M.mid_val.as<cplx>(), M.mid_lrow.as<uint8_t>(),
+                           pre ? 0 : 1, (int32_t)nslz, rows, fl, 0, (const cplx *)nullptr, (const uint8_t *)nullptr,
+                           (const uint16_t *)nullptr, (const uint8_t *)nullptr);
         return;
       }
       hipLaunchKernelGGL(k_band_cd_z<LOWER>, dim3((unsigned)(g1 - g0)), dim3(1024), cd_lds_bytes_z(), st, g0, M.wg_grp_ptr.as<int32_t>(),

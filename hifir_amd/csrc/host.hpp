@@ -314,6 +314,7 @@ struct BandOptions {
   int64_t cd_fuse_max_wgs = 0;   // a component band with more workgroups than this is not carried by its predecessor (0: always)
   int64_t cd_max_nnz = 0;        // ... and nonzeros per component (0 = no limit): spreads heavy rows over more units
   int64_t cd_sparse_max_depth = 64;  // ... only for triangles with at most this many wavefronts
+  int64_t cd_sparse_min_rows = 4096;  // ... only for triangles of at least this many rows
   int64_t cd_sparse_rows = 192;  // sparse-own plans (BandPlan::cd_sparse) for the triangles below cd_min_row_nnz: rows per
                                  // component (0 = those triangles keep the depth-cut flag bands)
   int64_t top_max = 4096;        // combined top operator (choose_top): at most this many rows (0 = off)

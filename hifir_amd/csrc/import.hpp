@@ -160,7 +160,7 @@ void analyze_level(HostLevel<T> &H, const BandOptions &band_opt, bool dump = fal
     auto plan_one = [&](const Csr<T> &A, const Schedule &S, bool lower) {
       if (use_cd(A)) return plan_bands_cd(A, S, lower, band_opt);
       // (shallow triangles only: inside a component the sparse substitution pays a barrier per depth level)
-      if (band_opt.cd_rows > 0 && band_opt.cd_sparse_rows > 0 && band_opt.dense_block > 0 && A.nrows >= 4096 &&
+      if (band_opt.cd_rows > 0 && band_opt.cd_sparse_rows > 0 && band_opt.dense_block > 0 && A.nrows >= band_opt.cd_sparse_min_rows &&
           S.nwf() <= band_opt.cd_sparse_max_depth)
         return plan_bands_cd(A, S, lower, band_opt, nullptr, true);
       return plan_bands(A, S, lower, band_opt);
@@ -632,7 +632,7 @@ inline std::vector<double> band_option_words(const BandOptions &o, size_t sizeof
           (double)o.max_comp_weight, (double)o.max_wg_rows, (double)o.max_wgs, (double)o.dense_block, (double)o.fuse,
           (double)o.fuse_reorder, (double)o.fuse_max_wgs, (double)o.dense_min_rows, (double)o.cd_rows, o.cd_min_row_nnz,
           (double)o.cd_fuse_max_wgs, (double)o.cd_max_nnz, (double)o.cd_sparse_max_depth, (double)o.cd_sparse_rows,
-          (double)o.top_max, (double)o.top_few_wgs, o.dense_max_growth};
+          (double)o.top_max, (double)o.top_few_wgs, o.dense_max_growth, (double)o.cd_sparse_min_rows};
 }
 static const char kAnaMagic[8] = {'H', 'I', 'F', 'A', 'M', 'D', 'A', '1'};
 static const char kAnaFoot[8] = {'H', 'I', 'F', 'A', 'M', 'D', 'A', 'F'};
@@ -777,7 +777,6 @@ bool cached_plan_ok(const BandPlan &P, const Csr<T> &A, int64_t m, int64_t nz, c
     const bool cd = !P.band_cd.empty() && P.band_cd[b];
     if (cd) {  // (component streams index rows with a byte)
       if (P.csplit.empty() || opt.cd_rows <= 0 || opt.dense_block <= 0 || (P.cd_sparse && opt.cd_sparse_rows <= 0)) return false;
-      if (P.cd_sparse && sizeof(T) != sizeof(double)) return false;  // (sparse-own components exist for real data only)
       for (int32_t g = P.band_wg_ptr[b]; g < P.band_wg_ptr[b + 1]; ++g)
         for (int32_t c = P.wg_grp_ptr[(size_t)g]; c < P.wg_grp_ptr[(size_t)g + 1]; ++c) {
           const int32_t rows = P.grp_slot_ptr[(size_t)c + 1] - P.grp_slot_ptr[(size_t)c];

@@ -3201,18 +3201,30 @@ __global__ void __launch_bounds__(256) k_band_ct(int32_t wg0, const int32_t *__r
 // x_im = P_re t_im + P_im t_re), strips dealt heaviest first in snake order.  Per row and column the arithmetic and
 // its order are k_band_cd_z's: the same bits.  No carried prefixes, no sparse-own variant (complex plans have neither).
 // ---------------------------------------------------------------------------------------------
-template <bool LOWER>
+// SPARSE (round 4): sparse-own components of a complex triangle (level 0 of a PDE hierarchy: ~2 nonzeros per row) -- the
+// component's own nonzeros (two real LDS arrays), row offsets and depth levels are staged in LDS and the component is
+// solved level by level, a lane group per row, exactly as k_band_cs<*, true> does it for real data; no inverse exists.
+template <bool LOWER, bool SPARSE>
 __global__ void __launch_bounds__(256) k_band_cs_z(int32_t wg0, const int32_t *__restrict__ wg_grp_ptr,
                                                    const int32_t *__restrict__ cd_desc, const int32_t *__restrict__ rowid,
                                                    const cplx *__restrict__ d, cplx *w, cplx *v,
                                                    const double *__restrict__ tinv, const int32_t *__restrict__ mid_col,
                                                    const cplx *__restrict__ mid_val, const uint8_t *__restrict__ mid_lrow,
-                                                   int first_u, int32_t nsl, int32_t lds_rows, FirstL<cplx> fl) {
+                                                   int first_u, int32_t nsl, int32_t lds_rows, FirstL<cplx> fl,
+                                                   int32_t own_cap, const cplx *__restrict__ own_val,
+                                                   const uint8_t *__restrict__ own_lsrc, const uint16_t *__restrict__ own_rptr,
+                                                   const uint8_t *__restrict__ own_lvl) {
   extern __shared__ double cs_buf[];
   double *t_re = cs_buf, *t_im = cs_buf + (size_t)lds_rows * 16;
   double *s_hdx = t_im + (size_t)lds_rows * 16, *s_hdy = s_hdx + lds_rows;
   int32_t *s_rowid = reinterpret_cast<int32_t *>(s_hdy + lds_rows);
   int32_t *s_hp = s_rowid + lds_rows;
+  // SPARSE: own nonzeros (re, im), their local sources, row offsets, depth levels
+  double *ow_re = reinterpret_cast<double *>(s_hp + ((lds_rows + 1) & ~1));
+  double *ow_im = ow_re + (SPARSE ? own_cap : 0);
+  uint16_t *ow_rptr = reinterpret_cast<uint16_t *>(ow_im + (SPARSE ? own_cap : 0));
+  uint8_t *ow_src = reinterpret_cast<uint8_t *>(ow_rptr + 260);
+  uint8_t *ow_lvl = ow_src + (SPARSE ? own_cap : 0);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int32_t bw = (int32_t)blockIdx.x / nsl, slice = (int32_t)blockIdx.x - bw * nsl;
@@ -3248,6 +3260,16 @@ __global__ void __launch_bounds__(256) k_band_cs_z(int32_t wg0, const int32_t *_
         s_hp[t] = pp;
         s_hdx[t] = fl.s[pp];
       }
+    }
+    if (SPARSE) {
+      const int32_t own0 = dsc[20], nown = dsc[21], orp0 = dsc[22], lvl0 = dsc[23], nlvl = dsc[24];
+      for (int32_t t = (int32_t)threadIdx.x; t < nown; t += 256) {
+        const cplx ov = own_val[own0 + t];
+        ow_re[t] = ov.x, ow_im[t] = ov.y;
+        ow_src[t] = own_lsrc[own0 + t];
+      }
+      for (int32_t t = (int32_t)threadIdx.x; t <= nb; t += 256) ow_rptr[t] = own_rptr[orp0 + t];
+      for (int32_t t = (int32_t)threadIdx.x; t <= nlvl; t += 256) ow_lvl[t] = own_lvl[lvl0 + t];
     }
     int32_t colv = 0, lrv = 0;
     cplx valv = cplx{0.0, 0.0};
@@ -3329,6 +3351,26 @@ __global__ void __launch_bounds__(256) k_band_cs_z(int32_t wg0, const int32_t *_
     if (cur >= 0) {
       t_re[(cur << 4) + l16] = acc.x;
       t_im[(cur << 4) + l16] = acc.y;
+    }
+    if (SPARSE) {
+      __syncthreads();
+      // ---- phase 2, sparse: substitution inside LDS, depth level by depth level; a lane group takes a row at a time
+      const int nlvl = dsc[24];
+      for (int lv = 0; lv < nlvl; ++lv) {
+        const int r_lo = ow_lvl[lv], r_hi = ow_lvl[lv + 1];
+        for (int r = r_lo + gq; r < r_hi; r += 16) {
+          cplx a2 = cplx{t_re[(r << 4) + l16], t_im[(r << 4) + l16]};
+          const int eb = ow_rptr[r], ee = ow_rptr[r + 1];
+          for (int e = eb; e < ee; ++e) {
+            const int sr = (int)ow_src[e];
+            a2 = vsub(a2, vmul(cplx{ow_re[e], ow_im[e]}, cplx{t_re[(sr << 4) + l16], t_im[(sr << 4) + l16]}));
+          }
+          if (ee > eb) t_re[(r << 4) + l16] = a2.x, t_im[(r << 4) + l16] = a2.y;
+          x[((int64_t)s_rowid[r] << 6) + cc] = a2;
+        }
+        __syncthreads();
+      }
+      continue;
     }
     // (rows nb .. lda - 1 are zero for the inverse product; lds_rows is a multiple of 32)
     for (int t = nb * 16 + (int)threadIdx.x; t < lda * 16; t += 256) t_re[t] = 0.0, t_im[t] = 0.0;

@@ -22,6 +22,9 @@ MODES = {
     "R64-exact": (6, 0),    # default 64-wide arena, thin bands solved sequentially: reference summation order
     "narrow-exact": (0, 0), # narrow lane mappings (R = 1, 2, 4, ...): must give the same bits
     "R64-fast": (6, 2048),   # the DEFAULT configuration: thin bands through explicit block inverses (1e-12)
+    # ... with sparse-own components (k_band_cd / k_band_cs / k_band_cs_z <sparse>) on every shallow thin triangle, whatever
+    # its size: what level 0 of the 1M-row (real) and 2M-row (complex) hierarchies runs, here on the small fixtures
+    "R64-fast-sparse-own": (6, 2048, {"HIFIR_AMD_CD_SPARSE_MIN_ROWS": "0"}),
 }
 
 
@@ -29,12 +32,16 @@ MODES = {
 def cache(request):
     import os
 
-    logr, blk = MODES[request.param]
+    logr, blk = MODES[request.param][:2]
+    extra = MODES[request.param][2] if len(MODES[request.param]) > 2 else {}
     os.environ["HIFIR_AMD_MIN_LOGR"] = str(logr)
     os.environ["HIFIR_AMD_DENSE_BLOCK"] = str(blk)
+    os.environ.update(extra)
     yield {"exact": blk == 0}
     os.environ.pop("HIFIR_AMD_MIN_LOGR", None)
     os.environ.pop("HIFIR_AMD_DENSE_BLOCK", None)
+    for k in extra:
+        os.environ.pop(k, None)
 
 
 def _get(cache, name):
