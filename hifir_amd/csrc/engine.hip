@@ -415,6 +415,7 @@ class Engine : public EngineBase {
   double finalize_seconds = 0.0, capture_ms = 0.0;  // set-up cost: hifamd_finalize, the last hipGraph capture + instantiate
   double bytes_inverses = 0.0, bytes_top = 0.0, bytes_tail = 0.0;  // resident explicit operators (HBM)
   bool fuse_out = true;    // S7 fused into the last band of the final U solve (HIFIR_AMD_FUSE_S7=0: k_scatter_scale over all rows)
+  int spmm_tiles_z = 1;     // HIFIR_AMD_SPMM_TILES_Z=0: complex coupling blocks keep the row-gather products
   int spmm_rb = 1;          // HIFIR_AMD_SPMM_RB: 16-row tiles per block of the tiled Schur products (1; 2 measured slower: fewer, longer chains)
   int spmm_split_blocks = 4096;  // HIFIR_AMD_SPMM_SPLIT_BLOCKS: fewer blocks than this -> one block per workgroup (k_spmm_tile4)
   bool spmm_split = true;  // tiled Schur products: one 16-row block per workgroup (k_spmm_tile4); HIFIR_AMD_SPMM_SPLIT=0: per wave
@@ -496,6 +497,7 @@ class Engine : public EngineBase {
     cs_max_wgs = env_int("HIFIR_AMD_CS_MAX_WGS", 0);
     ct_mode = env_int("HIFIR_AMD_CT", 1);
     spmm_rb = env_int("HIFIR_AMD_SPMM_RB", 1) == 2 ? 2 : 1;
+    spmm_tiles_z = env_int("HIFIR_AMD_SPMM_TILES_Z", 1);
     spmm_split_blocks = env_int("HIFIR_AMD_SPMM_SPLIT_BLOCKS", 4096);
     ct_wide_wgs = env_int("HIFIR_AMD_CT_WIDE", 128);
     ct_wide4_wgs = env_int("HIFIR_AMD_CT_WIDE4", 1 << 30);
@@ -668,6 +670,7 @@ class Engine : public EngineBase {
       E->cs_max_wgs = cs_max_wgs;
       E->ct_mode = ct_mode;
       E->spmm_rb = spmm_rb;
+      E->spmm_tiles_z = spmm_tiles_z;
       E->spmm_split_blocks = spmm_split_blocks;
       E->ct_wide_wgs = ct_wide_wgs;
       E->ct_wide4_wgs = ct_wide4_wgs;
@@ -734,6 +737,7 @@ class Engine : public EngineBase {
       E->cs_max_wgs = cs_max_wgs;
       E->ct_mode = ct_mode;
       E->spmm_rb = spmm_rb;
+      E->spmm_tiles_z = spmm_tiles_z;
       E->spmm_split_blocks = spmm_split_blocks;
       E->ct_wide_wgs = ct_wide_wgs;
       E->ct_wide4_wgs = ct_wide4_wgs;
@@ -1023,7 +1027,7 @@ class Engine : public EngineBase {
       tick("combined top operator", fl_);
       L.E.upload(H.Er, nullptr);
       L.F.upload(H.Fr, nullptr);
-      if (spmm_tiles && sizeof(T) == sizeof(double) && band_opt.dense_block > 0)  // fast mode, real data
+      if (spmm_tiles && band_opt.dense_block > 0 && (sizeof(T) == sizeof(double) || spmm_tiles_z))  // fast mode
         for (int which = 0; which < 2; ++which) {
           const Csr<T> &Ah = which ? H.Fr : H.Er;
           DevCsr &Md = which ? L.F : L.E;
@@ -1721,6 +1725,16 @@ class Engine : public EngineBase {
         hipLaunchKernelGGL(k1, dim3(grid), dim3(256), 0, st, nrows, A.tl_nblk, A.tl_gptr.as<int32_t>(),
                            A.tl_ucol.as<int32_t>(), A.tl_coef.as<double>(), (const double *)x, bin, ldb, nrhs, L.p.as<int32_t>(),
                            L.s.as<double>(), roff, out);
+        return;
+      }
+    }
+    if constexpr (!std::is_same<T, double>::value) {
+      if (A.tl_nblk > 0 && logR == 6) {  // complex coupling block on coefficient tiles: one 16-column slice per grid row
+        const unsigned gx = (unsigned)std::min<int64_t>((A.tl_nblk + 3) / 4, 256 * 16);
+        const unsigned gy = (unsigned)std::min(4, (act_cols + 15) / 16);
+        hipLaunchKernelGGL(k_spmm_tile_z, dim3(gx, gy), dim3(256), 0, st, nrows, A.tl_nblk, A.tl_gptr.as<int32_t>(),
+                           A.tl_ucol.as<int32_t>(), A.tl_coef.as<double>(), (const cplx *)x, bin, ldb, nrhs, L.p.as<int32_t>(),
+                           L.s.as<double>(), roff, (cplx *)out);
         return;
       }
     }

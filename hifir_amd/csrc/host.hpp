@@ -1516,7 +1516,51 @@ inline SpmmTiles build_spmm_tiles(const Csr<double> &A, int rb = 1) {
   });
   return Tl;
 }
-inline SpmmTiles build_spmm_tiles(const Csr<zdouble> &, int = 1) { return SpmmTiles(); }  // (real data only)
+// complex coupling blocks (round 4): the same blocks and groups; a group's coefficients as TWO real tiles [re 64 | im 64]
+// (gfx950 has no complex MFMA: a complex tile product is four real ones, k_spmm_tile_z)
+inline SpmmTiles build_spmm_tiles(const Csr<zdouble> &A, int = 1) {
+  SpmmTiles Tl;
+  Tl.nrows = A.nrows;
+  Tl.rb = 1;
+  Tl.nblk = (A.nrows + 15) / 16;
+  Tl.blk_gptr.assign((size_t)Tl.nblk + 1, 0);
+  std::vector<std::vector<int32_t>> ucols((size_t)Tl.nblk);
+  int64_t distinct = 0;
+  parallel_for(Tl.nblk, 256, [&](int64_t b0, int64_t b1) {
+    for (int64_t b = b0; b < b1; ++b) {
+      const int64_t r0 = 16 * b, r1 = std::min<int64_t>(A.nrows, r0 + 16);
+      std::vector<int32_t> &u = ucols[(size_t)b];
+      u.assign(A.col.begin() + A.ptr[(size_t)r0], A.col.begin() + A.ptr[(size_t)r1]);
+      std::sort(u.begin(), u.end());
+      u.erase(std::unique(u.begin(), u.end()), u.end());
+    }
+  });
+  for (int64_t b = 0; b < Tl.nblk; ++b) {
+    distinct += (int64_t)ucols[(size_t)b].size();
+    Tl.blk_gptr[(size_t)b + 1] = Tl.blk_gptr[(size_t)b] + (int32_t)((ucols[(size_t)b].size() + 3) / 4);
+  }
+  Tl.reuse = distinct ? (double)A.col.size() / (double)distinct : 0.0;
+  const int64_t ng = Tl.blk_gptr[(size_t)Tl.nblk];
+  Tl.ucol.assign((size_t)(4 * ng), 0);
+  Tl.coef.assign((size_t)(128 * ng), 0.0);
+  parallel_for(Tl.nblk, 256, [&](int64_t b0, int64_t b1) {
+    for (int64_t b = b0; b < b1; ++b) {
+      const std::vector<int32_t> &u = ucols[(size_t)b];
+      const int64_t g0 = Tl.blk_gptr[(size_t)b], g1 = Tl.blk_gptr[(size_t)b + 1];
+      for (int64_t q = 0; q < 4 * (g1 - g0); ++q)
+        Tl.ucol[(size_t)(4 * g0 + q)] = u.empty() ? 0 : u[(size_t)std::min<int64_t>(q, (int64_t)u.size() - 1)];
+      const int64_t r0 = 16 * b, r1 = std::min<int64_t>(A.nrows, r0 + 16);
+      for (int64_t i = r0; i < r1; ++i)
+        for (int32_t k = A.ptr[(size_t)i]; k < A.ptr[(size_t)i + 1]; ++k) {
+          const int64_t q = std::lower_bound(u.begin(), u.end(), A.col[(size_t)k]) - u.begin();
+          const size_t at = (size_t)(128 * (g0 + q / 4) + ((q & 3) << 4) + (i - r0));
+          Tl.coef[at] += A.val[(size_t)k].real();
+          Tl.coef[at + 64] += A.val[(size_t)k].imag();
+        }
+    }
+  });
+  return Tl;
+}
 
 // ---------------------------------------------------------------------------------------------
 // one level + the whole hierarchy (host copy)

@@ -1299,6 +1299,68 @@ __global__ void __launch_bounds__(256) k_spmm_tile4(int64_t nrows, int64_t nblk,
   }
 }
 
+// The tiled product for COMPLEX coupling blocks (round 4; host.hpp build_spmm_tiles(Csr<zdouble>)): one wave per 16-row
+// block and 16-column slice of the (complex) batch -- blockIdx.y = slice --; a group's coefficients are two real tiles
+// [re | im], a lane gathers the 16 bytes (re, im) of ITS source row and column, and the complex tile product is four real
+// matrix instructions (rr, ii, ri, ir; out = (rr - ii) + i (ri + ir)).  Same software pipeline as k_spmm_tile: source-row
+// indices 7 groups ahead, coefficient tiles and gathered rows 3 groups ahead, every load unconditional.
+__global__ void __launch_bounds__(256) k_spmm_tile_z(int64_t nrows, int64_t nblk, const int32_t *__restrict__ blk_gptr,
+                                                     const int32_t *__restrict__ ucol, const double *__restrict__ coef,
+                                                     const cplx *__restrict__ x, IoPtr<const cplx> bin_, int64_t ldb, int nrhs,
+                                                     const int32_t *__restrict__ p, const double *__restrict__ s, int64_t roff,
+                                                     cplx *__restrict__ out) {
+  const cplx *__restrict__ bin = bin_.get();
+  const int lane = threadIdx.x & 63;
+  const int kq = lane >> 4, jc = lane & 15;
+  const int c = 16 * (int)blockIdx.y + jc;  // this lane's column of the 64-column (complex) arena
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t b = wave; b < nblk; b += nwaves) {
+    const int32_t g0 = rfl(blk_gptr[b]), g1 = rfl(blk_gptr[b + 1]);
+    v4f64 a_rr = v4f64{0.0, 0.0, 0.0, 0.0}, a_ii = a_rr, a_ri = a_rr, a_ir = a_rr;
+    if (g0 < g1) {
+      const int32_t gl = g1 - 1;
+      int32_t src[8];
+      double ar[4], ai[4];
+      cplx bv[4];
+#define HIFAMD_TLZ_SRC(slot, g) src[slot] = ucol[4 * (int64_t)min((g), gl) + kq];
+#define HIFAMD_TLZ_LOAD(slot, sslot, g)                              \
+  ar[slot] = coef[128 * (int64_t)min((g), gl) + lane];               \
+  ai[slot] = coef[128 * (int64_t)min((g), gl) + 64 + lane];          \
+  bv[slot] = x[((int64_t)src[sslot] << 6) + c];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) { HIFAMD_TLZ_SRC(q, g0 + q) }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { HIFAMD_TLZ_LOAD(q, q, g0 + q) }
+      for (int32_t g = g0; g < g1; g += 8) {
+#pragma unroll
+        for (int dd = 0; dd < 8; ++dd) {
+          const int32_t cur = g + dd;
+          HIFAMD_TLZ_LOAD((dd + 3) & 3, (dd + 3) & 7, cur + 3)
+          HIFAMD_TLZ_SRC((dd + 7) & 7, cur + 7)
+          const double mr = cur < g1 ? ar[dd & 3] : 0.0, mi = cur < g1 ? ai[dd & 3] : 0.0;
+          a_rr = __builtin_amdgcn_mfma_f64_16x16x4f64(mr, bv[dd & 3].x, a_rr, 0, 0, 0);
+          a_ii = __builtin_amdgcn_mfma_f64_16x16x4f64(mi, bv[dd & 3].y, a_ii, 0, 0, 0);
+          a_ri = __builtin_amdgcn_mfma_f64_16x16x4f64(mr, bv[dd & 3].y, a_ri, 0, 0, 0);
+          a_ir = __builtin_amdgcn_mfma_f64_16x16x4f64(mi, bv[dd & 3].x, a_ir, 0, 0, 0);
+        }
+      }
+#undef HIFAMD_TLZ_SRC
+#undef HIFAMD_TLZ_LOAD
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t i = 16 * b + kq + 4 * r;
+      if (i < nrows) {
+        const int32_t srow = p[roff + i];
+        cplx rhs = cplx{0.0, 0.0};
+        if (c < nrhs) rhs = vscale(s[srow], bin[(int64_t)srow * ldb + c]);
+        out[(i << 6) + c] = cplx{rhs.x - (a_rr[r] - a_ii[r]), rhs.y - (a_ri[r] + a_ir[r])};
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // outer CRS SpMM: y = A x (RESID = false) or r = b - A x (RESID = true), tmp = 0; tmp += a*x
 // ---------------------------------------------------------------------------------------------
