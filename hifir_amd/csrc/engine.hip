@@ -1056,9 +1056,10 @@ class Engine : public EngineBase {
           }
         }
       }
-      if constexpr (std::is_same<T, double>::value) {
+      {
         // S7 fused into the last U band (LastU): that band must be a component band (its kernel knows how) and the level
-        // must have come with q (hifamd_add_level: optional)
+        // must have come with q (hifamd_add_level: optional).  Complex handles (round 4): the slice kernel k_band_cs_z
+        // knows how -- enqueue_level asks s7_kernel_ok() whether this launch's last U band runs through it
         const BandPlan &Up = H.Up;
         const int64_t nbU = Up.nbands();
         if (fuse_out && Rmax == 64 && H.m > 0 && nbU > 0 && !Up.band_cd.empty() && Up.band_cd[(size_t)nbU - 1] &&
@@ -1564,8 +1565,17 @@ class Engine : public EngineBase {
   size_t csz_lds_bytes(bool sparse, int32_t own_cap) const {
     const size_t rows = (size_t)(sparse ? band_opt.cd_sparse_rows : ((band_opt.cd_rows + 31) & ~(int64_t)31));
     size_t b = rows * (2 * 16 + 2) * sizeof(double) + (((rows + 1) & ~(size_t)1) + rows) * sizeof(int32_t) + 16;
-    if (sparse) b += (size_t)own_cap * (2 * sizeof(double) + 2) + 260 * sizeof(uint16_t) + 264;
+    if (sparse) b += (size_t)own_cap * (2 * sizeof(double) + 2);
+    b += 260 * sizeof(uint16_t) + 264;  // (the kernel lays the row-offset / level arrays out in either variant)
+    b += rows * (sizeof(double) + sizeof(int32_t)) + 32;  // fused S7 (LastU): output scale and row of every row
     return b;
+  }
+  // does the last U band of this level run through a kernel that can write the level's output itself (LastU)?  real data:
+  // every component band kernel; complex data: the slice kernel k_band_cs_z (sparse-own bands, narrow batches)
+  bool s7_kernel_ok(const DevLevel &L) const {
+    if (sizeof(T) == sizeof(double)) return true;
+    const int nslz = std::min(4, (act_cols + 15) / 16);
+    return L.U.cd_sparse || (cs_mode && nslz < 4);
   }
   size_t cd_lds_bytes_z() const {  // complex: two real planes of the component's right-hand sides + row ids
     const size_t rows = (size_t)band_opt.cd_rows;
@@ -1626,7 +1636,7 @@ class Engine : public EngineBase {
                          lds_rows, M.own_cap, cd_dbg | (no_walk ? 1 : 0), fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
                          M.own_lvl.as<uint8_t>(), lu);
     } else {
-      (void)ps0, (void)ps1, (void)with_f, (void)lu;
+      (void)ps0, (void)ps1, (void)with_f;
       if (extra) throw Error(HIFAMD_HIFIR_ERROR, "internal error: carried prefix on a complex handle");
       const int nslz = std::min(4, (act_cols + 15) / 16);
       if (M.cd_sparse) {  // sparse-own components (round 4): 16-column slices at every batch width
@@ -1635,7 +1645,7 @@ class Engine : public EngineBase {
                            M.wg_grp_ptr.as<int32_t>(), M.cd_desc.as<int32_t>(), M.rowid.as<int32_t>(), L.d.as<cplx>(), L.w.as<cplx>(),
                            L.v.as<cplx>(), M.tinv.as<double>(), M.mid_col.as<int32_t>(), M.mid_val.as<cplx>(), M.mid_lrow.as<uint8_t>(),
                            pre ? 0 : 1, (int32_t)nslz, rows, fl, M.own_cap, M.own_val.as<cplx>(), M.own_lsrc.as<uint8_t>(),
-                           M.own_rptr.as<uint16_t>(), M.own_lvl.as<uint8_t>());
+                           M.own_rptr.as<uint16_t>(), M.own_lvl.as<uint8_t>(), lu);
         return;
       }
       if (cs_mode && nslz < 4 && (int64_t)(g1 - g0) * nslz < (1LL << 30)) {  // a narrow batch: only the slices it has
@@ -1644,7 +1654,7 @@ class Engine : public EngineBase {
                            M.wg_grp_ptr.as<int32_t>(), M.cd_desc.as<int32_t>(), M.rowid.as<int32_t>(), L.d.as<cplx>(), L.w.as<cplx>(),
                            L.v.as<cplx>(), M.tinv.as<double>(), M.mid_col.as<int32_t>(), M.mid_val.as<cplx>(), M.mid_lrow.as<uint8_t>(),
                            pre ? 0 : 1, (int32_t)nslz, rows, fl, 0, (const cplx *)nullptr, (const uint8_t *)nullptr,
-                           (const uint16_t *)nullptr, (const uint8_t *)nullptr);
+                           (const uint16_t *)nullptr, (const uint8_t *)nullptr, lu);
         return;
       }
       hipLaunchKernelGGL(k_band_cd_z<LOWER>, dim3((unsigned)(g1 - g0)), dim3(1024), cd_lds_bytes_z(), st, g0, M.wg_grp_ptr.as<int32_t>(),
@@ -1805,7 +1815,7 @@ class Engine : public EngineBase {
     // S6  :406  (its right-hand side is w = s b[p] - F y from S5, or -- no F, or no Schur complement at all -- S1 again)
     // S7 (:411) fused into the last band of this U solve where the plan allows (kernels LastU; finalize built the list of
     // output rows that band does not write)
-    const bool fuse_s7 = fuse_out && logR == 6 && m > 0 && L.s7_n >= 0;
+    const bool fuse_s7 = fuse_out && logR == 6 && m > 0 && L.s7_n >= 0 && s7_kernel_ok(L);
     const LU lu{yout, ldy, nrhs, L.q_s7.as<int32_t>(), L.t.as<double>()};
     c0 = count;
     launch_ldu(st, L, logR, count, (fuse_s1 && (!(nm && L.F_ncols) || fuse_f_lv)) ? &fl : nullptr, fuse_f_lv && nm && L.F_ncols,

@@ -3275,7 +3275,7 @@ __global__ void __launch_bounds__(256) k_band_cs_z(int32_t wg0, const int32_t *_
                                                    int first_u, int32_t nsl, int32_t lds_rows, FirstL<cplx> fl,
                                                    int32_t own_cap, const cplx *__restrict__ own_val,
                                                    const uint8_t *__restrict__ own_lsrc, const uint16_t *__restrict__ own_rptr,
-                                                   const uint8_t *__restrict__ own_lvl) {
+                                                   const uint8_t *__restrict__ own_lvl, LastU<cplx> lu) {
   extern __shared__ double cs_buf[];
   double *t_re = cs_buf, *t_im = cs_buf + (size_t)lds_rows * 16;
   double *s_hdx = t_im + (size_t)lds_rows * 16, *s_hdy = s_hdx + lds_rows;
@@ -3287,6 +3287,12 @@ __global__ void __launch_bounds__(256) k_band_cs_z(int32_t wg0, const int32_t *_
   uint16_t *ow_rptr = reinterpret_cast<uint16_t *>(ow_im + (SPARSE ? own_cap : 0));
   uint8_t *ow_src = reinterpret_cast<uint8_t *>(ow_rptr + 260);
   uint8_t *ow_lvl = ow_src + (SPARSE ? own_cap : 0);
+  // fused S7 (LastU, round 4 for complex data): output row and scale of every row, behind everything else
+  double *s_ot = reinterpret_cast<double *>(ow_lvl + (SPARSE ? 264 : 0) + 8);
+  s_ot = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(s_ot) + 7) & ~(uintptr_t)7);
+  int32_t *s_oi = reinterpret_cast<int32_t *>(s_ot + lds_rows);
+  const bool last_u = !LOWER && lu.on();
+  cplx *yout = last_u ? lu.out.get() : nullptr;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int32_t bw = (int32_t)blockIdx.x / nsl, slice = (int32_t)blockIdx.x - bw * nsl;
@@ -3321,6 +3327,11 @@ __global__ void __launch_bounds__(256) k_band_cs_z(int32_t wg0, const int32_t *_
         const int32_t pp = fl.p[i];
         s_hp[t] = pp;
         s_hdx[t] = fl.s[pp];
+      }
+      if (last_u) {
+        const int32_t oi = lu.q[i];
+        s_oi[t] = oi;
+        s_ot[t] = lu.t[oi];
       }
     }
     if (SPARSE) {
@@ -3428,7 +3439,11 @@ __global__ void __launch_bounds__(256) k_band_cs_z(int32_t wg0, const int32_t *_
             a2 = vsub(a2, vmul(cplx{ow_re[e], ow_im[e]}, cplx{t_re[(sr << 4) + l16], t_im[(sr << 4) + l16]}));
           }
           if (ee > eb) t_re[(r << 4) + l16] = a2.x, t_im[(r << 4) + l16] = a2.y;
-          x[((int64_t)s_rowid[r] << 6) + cc] = a2;
+          if (last_u) {
+            if (cc < lu.nrhs) yout[(int64_t)s_oi[r] * lu.ldy + cc] = vscale(s_ot[r], a2);
+          } else {
+            x[((int64_t)s_rowid[r] << 6) + cc] = a2;
+          }
         }
         __syncthreads();
       }
@@ -3484,7 +3499,14 @@ __global__ void __launch_bounds__(256) k_band_cs_z(int32_t wg0, const int32_t *_
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * strip + kq + 4 * r;
-        if (row < nb) x[((int64_t)s_rowid[row] << 6) + cc] = cplx{a_rr[r] - a_ii[r], a_ri[r] + a_ir[r]};
+        if (row < nb) {
+          const cplx res = cplx{a_rr[r] - a_ii[r], a_ri[r] + a_ir[r]};
+          if (last_u) {
+            if (cc < lu.nrhs) yout[(int64_t)s_oi[row] * lu.ldy + cc] = vscale(s_ot[row], res);
+          } else {
+            x[((int64_t)s_rowid[row] << 6) + cc] = res;
+          }
+        }
       }
     }
     __syncthreads();  // (the next component overwrites the LDS planes)
