@@ -441,6 +441,8 @@ class Engine : public EngineBase {
   int cs_max_wgs = 0;    // HIFIR_AMD_CS_MAX_WGS (full batches: measured equal to k_band_cd at every band width)
   int ct_wide_wgs = 128; // HIFIR_AMD_CT_WIDE: a component band with more workgroups than this takes two column tiles per workgroup
   int ct_wide4_wgs = 1 << 30;  // HIFIR_AMD_CT_WIDE4: ... and with more than this all four (one workgroup per component)
+  int ct_mode_z = 0;     // HIFIR_AMD_CT_Z=1: complex component bands on coefficient tiles too (k_band_ct_z; measured SLOWER than the
+                         // entry walk at every width on BASELINE config 5: 7.17 vs 7.00 ms at 16, 17.9 vs 16.1 ms at 64 columns)
   int ct_mode = 1;       // HIFIR_AMD_CT=0: dense-own component bands walk their entries one by one (k_band_cd / k_band_cs) instead of
                          // multiplying 16 x 4 coefficient tiles on the matrix cores (k_band_ct)
   int act_cols = 64;     // columns of the 64-column arena that the tile being enqueued actually uses (enqueue_apply)
@@ -496,6 +498,7 @@ class Engine : public EngineBase {
     cs_mode = env_int("HIFIR_AMD_CS", 1);
     cs_max_wgs = env_int("HIFIR_AMD_CS_MAX_WGS", 0);
     ct_mode = env_int("HIFIR_AMD_CT", 1);
+    ct_mode_z = env_int("HIFIR_AMD_CT_Z", 0);
     spmm_rb = env_int("HIFIR_AMD_SPMM_RB", 1) == 2 ? 2 : 1;
     spmm_tiles_z = env_int("HIFIR_AMD_SPMM_TILES_Z", 1);
     spmm_split_blocks = env_int("HIFIR_AMD_SPMM_SPLIT_BLOCKS", 4096);
@@ -669,6 +672,7 @@ class Engine : public EngineBase {
       E->cs_mode = cs_mode;
       E->cs_max_wgs = cs_max_wgs;
       E->ct_mode = ct_mode;
+      E->ct_mode_z = ct_mode_z;
       E->spmm_rb = spmm_rb;
       E->spmm_tiles_z = spmm_tiles_z;
       E->spmm_split_blocks = spmm_split_blocks;
@@ -736,6 +740,7 @@ class Engine : public EngineBase {
       E->cs_mode = cs_mode;
       E->cs_max_wgs = cs_max_wgs;
       E->ct_mode = ct_mode;
+      E->ct_mode_z = ct_mode_z;
       E->spmm_rb = spmm_rb;
       E->spmm_tiles_z = spmm_tiles_z;
       E->spmm_split_blocks = spmm_split_blocks;
@@ -875,7 +880,7 @@ class Engine : public EngineBase {
   // growth again in the other direction: a band that is flagged and grows under the new values is demoted as usual).
   void ship_block_inverses(BandPlan &P, const Csr<T> &A, int64_t total_elems, DevCsr &M) {
     M.upload(A, &P);
-    if (ct_mode && sizeof(T) == sizeof(double) && band_opt.dense_block > 0 && !P.cd_sparse && !P.band_cd.empty()) {
+    if (ct_mode && (sizeof(T) == sizeof(double) || ct_mode_z) && band_opt.dense_block > 0 && !P.cd_sparse && !P.band_cd.empty()) {
       // dense-own component bands: the entries a component reads from older rows as 16 x 4 coefficient tiles (k_band_ct)
       CtTiles Tl;
       build_ct_tiles(P, A, Tl);
@@ -1575,7 +1580,7 @@ class Engine : public EngineBase {
   bool s7_kernel_ok(const DevLevel &L) const {
     if (sizeof(T) == sizeof(double)) return true;
     const int nslz = std::min(4, (act_cols + 15) / 16);
-    return L.U.cd_sparse || (cs_mode && nslz < 4);
+    return L.U.cd_sparse || (ct_mode && L.U.ct_on) || (cs_mode && nslz < 4);
   }
   size_t cd_lds_bytes_z() const {  // complex: two real planes of the component's right-hand sides + row ids
     const size_t rows = (size_t)band_opt.cd_rows;
@@ -1639,6 +1644,15 @@ class Engine : public EngineBase {
       (void)ps0, (void)ps1, (void)with_f;
       if (extra) throw Error(HIFAMD_HIFIR_ERROR, "internal error: carried prefix on a complex handle");
       const int nslz = std::min(4, (act_cols + 15) / 16);
+      if (ct_mode && M.ct_on && !M.cd_sparse) {  // coefficient tiles (round 4): 16-column slices at every batch width
+        const size_t rows = (size_t)((band_opt.cd_rows + 31) & ~(int64_t)31);
+        const size_t ldsz = rows * (2 * 16 + 3) * sizeof(double) + rows * 3 * sizeof(int32_t) + 32 * sizeof(int32_t);
+        hipLaunchKernelGGL(k_band_ct_z<LOWER>, dim3((unsigned)((g1 - g0) * nslz)), dim3(256), ldsz, st, g0, M.wg_grp_ptr.as<int32_t>(),
+                           M.ct_desc.as<int32_t>(), M.rowid.as<int32_t>(), L.d.as<cplx>(), L.w.as<cplx>(), L.v.as<cplx>(),
+                           M.tinv.as<double>(), M.ct_sptr.as<int32_t>(), M.ct_src.as<int32_t>(), M.ct_coef.as<double>(), pre ? 0 : 1,
+                           (int32_t)nslz, (int32_t)rows, cd_dbg | (no_walk ? 1 : 0), fl, lu);
+        return;
+      }
       if (M.cd_sparse) {  // sparse-own components (round 4): 16-column slices at every batch width
         const int32_t rows = (int32_t)band_opt.cd_sparse_rows;
         hipLaunchKernelGGL((k_band_cs_z<LOWER, true>), dim3((unsigned)((g1 - g0) * nslz)), dim3(256), csz_lds_bytes(true, M.own_cap), st, g0,

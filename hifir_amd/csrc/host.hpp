@@ -965,7 +965,10 @@ struct CtTiles {
   std::vector<int32_t> band_wave_tiles;  // ... per band
 };
 
-inline void build_ct_tiles(const BandPlan &P, const Csr<double> &A /* slot order */, CtTiles &Tl) {
+// (complex data, round 4: a tile's coefficients are TWO real tiles [re 64 | im 64] -- four real matrix instructions per tile)
+template <class T>
+void build_ct_tiles(const BandPlan &P, const Csr<T> &A /* slot order */, CtTiles &Tl) {
+  constexpr int64_t kTile = sizeof(T) == sizeof(double) ? 64 : 128;  // doubles per tile
   Tl = CtTiles();
   if (P.band_cd.empty() || P.cd_sparse || P.cd_desc.empty()) return;
   Tl.desc = P.cd_desc;
@@ -1018,7 +1021,7 @@ inline void build_ct_tiles(const BandPlan &P, const Csr<double> &A /* slot order
   }
   Tl.ntiles = total;
   Tl.src.assign((size_t)(4 * total), 0);
-  Tl.coef.assign((size_t)(64 * total), 0.0);
+  Tl.coef.assign((size_t)(kTile * total), 0.0);
   std::vector<int32_t> wave_max((size_t)ngrp, 0);
   parallel_for(ngrp, 64, [&](int64_t c0, int64_t c1) {
     std::vector<int32_t> u;
@@ -1036,7 +1039,9 @@ inline void build_ct_tiles(const BandPlan &P, const Csr<double> &A /* slot order
         for (int32_t sl = r0; sl < r1; ++sl)
           for (int32_t k = P.split[(size_t)sl]; k < P.csplit[(size_t)sl]; ++k) {
             const int64_t q = std::lower_bound(u.begin(), u.end(), P.srcslot[(size_t)k]) - u.begin();
-            Tl.coef[(size_t)(64 * (t0 + q / 4) + ((q & 3) << 4) + (sl - r0))] += A.val[(size_t)k];
+            const size_t at = (size_t)(kTile * (t0 + q / 4) + ((q & 3) << 4) + (sl - r0));
+            Tl.coef[at] += real_(A.val[(size_t)k]);
+            if (kTile == 128) Tl.coef[at + 64] += reinterpret_cast<const double *>(&A.val[(size_t)k])[sizeof(T) / sizeof(double) - 1];
           }
       }
       // strips to waves: heaviest first onto the lightest of the four waves (a strip costs its tiles + its 4 row loads)
@@ -1068,7 +1073,6 @@ inline void build_ct_tiles(const BandPlan &P, const Csr<double> &A /* slot order
     bw = std::max(bw, wave_max[(size_t)c]);
   }
 }
-inline void build_ct_tiles(const BandPlan &, const Csr<zdouble> &, CtTiles &Tl) { Tl = CtTiles(); }  // (real data only)
 
 // Pass 1 (import time, cheap): cut every candidate band into blocks and lay their MFMA operands out back to
 // back; returns the total number of doubles.  blk_inv_off counts doubles; complex blocks hold two planes.

@@ -3514,6 +3514,197 @@ __global__ void __launch_bounds__(256) k_band_cs_z(int32_t wg0, const int32_t *_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Component band on coefficient tiles for COMPLEX data (round 4): k_band_ct's phase 1 (a wave owns whole strips; per tile
+// the four source rows are gathered once -- 16 bytes (re, im) per lane -- and multiplied with the tile's two real
+// coefficient planes by four real matrix instructions, rr / ii / ri / ir) in front of k_band_cs_z's phase 2 (the
+// component's explicit inverse as two real planes).  One workgroup per (component, slice of 16 complex columns) at every
+// batch width; column-separable: a column's bits do not depend on the batch it travels in.  LastU (fused S7) as in
+// k_band_cs_z.
+// ---------------------------------------------------------------------------------------------
+template <bool LOWER>
+__global__ void __launch_bounds__(256) k_band_ct_z(int32_t wg0, const int32_t *__restrict__ wg_grp_ptr,
+                                                   const int32_t *__restrict__ ct_desc, const int32_t *__restrict__ rowid,
+                                                   const cplx *__restrict__ d, cplx *w, cplx *v,
+                                                   const double *__restrict__ tinv, const int32_t *__restrict__ ct_sptr,
+                                                   const int32_t *__restrict__ ct_src, const double *__restrict__ ct_coef,
+                                                   int first_u, int32_t nsl, int32_t lds_rows, int dbg, FirstL<cplx> fl,
+                                                   LastU<cplx> lu) {
+  extern __shared__ double cs_buf[];
+  double *t_re = cs_buf, *t_im = cs_buf + (size_t)lds_rows * 16;
+  double *s_hdx = t_im + (size_t)lds_rows * 16, *s_hdy = s_hdx + lds_rows;
+  double *s_ot = s_hdy + lds_rows;
+  int32_t *s_rowid = reinterpret_cast<int32_t *>(s_ot + lds_rows);
+  int32_t *s_hp = s_rowid + lds_rows;
+  int32_t *s_oi = s_hp + lds_rows;
+  int32_t *s_sptr = s_oi + lds_rows;  // 17 entries
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int32_t bw = (int32_t)blockIdx.x / nsl, slice = (int32_t)blockIdx.x - bw * nsl;
+  const int kq = lane >> 4, l16 = lane & 15;
+  const int cc = slice * 16 + l16;
+  cplx *x = LOWER ? w : v;
+  const bool div_u = !LOWER && first_u;
+  const bool first_l = LOWER && first_u && fl.on();
+  const bool last_u = !LOWER && lu.on();
+  cplx *yout = last_u ? lu.out.get() : nullptr;
+  const cplx *rhs = div_u ? (const cplx *)w : (first_l ? fl.bin.get() : (const cplx *)x);
+  const int64_t rstride = first_l ? fl.ldb : 64;
+  const int rcol = first_l ? min(cc, fl.nrhs - 1) : cc;
+  const int32_t c_first = wg_grp_ptr[wg0 + bw], c_last = wg_grp_ptr[wg0 + bw + 1];
+  for (int32_t c = c_first; c < c_last; ++c) {
+    const int32_t *dsc = ct_desc + (int64_t)c * 28;
+    const int32_t s0 = dsc[0], nb = dsc[1], sp0 = dsc[20];
+    const int64_t inv_off = ((int64_t)(uint32_t)dsc[5] << 32) | (uint32_t)dsc[4];
+    const uint32_t mword = (uint32_t)dsc[22 + (wave >> 1)];
+    const uint32_t mymask = (wave & 1) ? (mword >> 16) : (mword & 0xffffu);  // the strips this wave owns
+    const int lda = (nb + 31) & ~31;
+    const int S = (nb + 15) >> 4;
+    // ---- phase 0: row ids, per-row scalars, strip offsets
+    for (int32_t t = (int32_t)threadIdx.x; t < nb; t += 256) {
+      const int32_t i = rowid[s0 + t];
+      s_rowid[t] = i;
+      if (div_u) {
+        const cplx dd = d[i];
+        s_hdx[t] = dd.x, s_hdy[t] = dd.y;
+      }
+      if (first_l) {
+        const int32_t pp = fl.p[i];
+        s_hp[t] = pp;
+        s_hdx[t] = fl.s[pp];
+      }
+      if (last_u) {
+        const int32_t oi = lu.q[i];
+        s_oi[t] = oi;
+        s_ot[t] = lu.t[oi];
+      }
+    }
+    if ((int32_t)threadIdx.x <= S) s_sptr[threadIdx.x] = ct_sptr[sp0 + (int32_t)threadIdx.x];
+    __syncthreads();
+    // ---- phase 1: this wave's strips -- right-hand sides requested first, then the strip's tiles four at a time
+    constexpr int BU = 4;
+    for (int s = 0; s < S; ++s) {
+      if (!((mymask >> s) & 1u)) continue;  // (wave-uniform)
+      cplx tr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = min(16 * s + kq + 4 * j, nb - 1);
+        const int32_t i = first_l ? s_hp[row] : s_rowid[row];
+        tr[j] = rhs[(int64_t)i * rstride + rcol];
+      }
+      const int32_t t0 = s_sptr[s], t1 = (dbg & 1) ? t0 : s_sptr[s + 1];
+      v4f64 a_rr = v4f64{0.0, 0.0, 0.0, 0.0}, a_ii = a_rr, a_ri = a_rr, a_ir = a_rr;
+      if (t0 < t1) {
+        int32_t sv[BU];
+        double cr[BU], ci[BU];
+#pragma unroll
+        for (int u = 0; u < BU; ++u) {
+          const int32_t tt = min(t0 + u, t1 - 1);
+          sv[u] = ct_src[4 * (int64_t)tt + kq];
+          cr[u] = ct_coef[128 * (int64_t)tt + lane];
+          ci[u] = ct_coef[128 * (int64_t)tt + 64 + lane];
+          if (t0 + u >= t1) cr[u] = 0.0, ci[u] = 0.0;
+        }
+        for (int32_t t = t0; t < t1; t += BU) {
+          cplx bv[BU];
+#pragma unroll
+          for (int u = 0; u < BU; ++u) bv[u] = x[((int64_t)sv[u] << 6) + cc];
+          int32_t sn[BU];
+          double crn[BU], cin[BU];
+#pragma unroll
+          for (int u = 0; u < BU; ++u) {  // (clamped: the loads past the strip's last tile read that tile again, weight zero)
+            const int32_t tt = min(t + BU + u, t1 - 1);
+            sn[u] = ct_src[4 * (int64_t)tt + kq];
+            crn[u] = ct_coef[128 * (int64_t)tt + lane];
+            cin[u] = ct_coef[128 * (int64_t)tt + 64 + lane];
+            if (t + BU + u >= t1) crn[u] = 0.0, cin[u] = 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < BU; ++u) {
+            a_rr = __builtin_amdgcn_mfma_f64_16x16x4f64(cr[u], bv[u].x, a_rr, 0, 0, 0);
+            a_ii = __builtin_amdgcn_mfma_f64_16x16x4f64(ci[u], bv[u].y, a_ii, 0, 0, 0);
+            a_ri = __builtin_amdgcn_mfma_f64_16x16x4f64(cr[u], bv[u].y, a_ri, 0, 0, 0);
+            a_ir = __builtin_amdgcn_mfma_f64_16x16x4f64(ci[u], bv[u].x, a_ir, 0, 0, 0);
+          }
+#pragma unroll
+          for (int u = 0; u < BU; ++u) sv[u] = sn[u], cr[u] = crn[u], ci[u] = cin[u];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = 16 * s + kq + 4 * j;
+        if (row < nb) {
+          cplx val = tr[j];
+          if (div_u)
+            val = vdiv(val, cplx{s_hdx[row], s_hdy[row]});
+          else if (first_l)
+            val = cc < fl.nrhs ? vscale(s_hdx[row], val) : cplx{0.0, 0.0};
+          t_re[(row << 4) + l16] = val.x - (a_rr[j] - a_ii[j]);
+          t_im[(row << 4) + l16] = val.y - (a_ri[j] + a_ir[j]);
+        }
+      }
+    }
+    // (rows nb .. lda - 1 are zero for the inverse product; lds_rows is a multiple of 32)
+    for (int t = nb * 16 + (int)threadIdx.x; t < lda * 16; t += 256) t_re[t] = 0.0, t_im[t] = 0.0;
+    __syncthreads();
+    // ---- phase 2: x = Tinv * t on the real matrix cores, four products per strip (k_band_cs_z)
+    const double *Are = tinv + inv_off, *Aim = Are + ((int64_t)((nb + 15) & ~15) * lda);  // plane_elems(nb, lda)
+    for (int rnd = 0; 4 * rnd < S; ++rnd) {
+      const int q = 4 * rnd + ((rnd & 1) ? 3 - wave : wave);
+      if (q >= S) continue;
+      const int strip = S - 1 - q;
+      const int kend = min(nb, 16 * (strip + 1));
+      const int nk = (kend + 3) >> 2;  // k-steps of four columns
+      const double *Apr = Are + ((int64_t)strip * lda) * 16 + l16 + (int64_t)kq * 16;
+      const double *Api = Aim + ((int64_t)strip * lda) * 16 + l16 + (int64_t)kq * 16;
+      const double *Bre = t_re + l16, *Bim = t_im + l16;
+      v4f64 a_rr = v4f64{0.0, 0.0, 0.0, 0.0}, a_ii = a_rr, a_ri = a_rr, a_ir = a_rr;
+      constexpr int KU = 4;
+      double pr0[KU], pi0[KU], pr1[KU], pi1[KU];
+#define HIFAMD_CTZ_LOAD(pr, pi, t_)                                                       \
+  _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                        \
+    pr[u] = Apr[(int64_t)(KU * (t_) + u) * 64];                                           \
+    pi[u] = Api[(int64_t)(KU * (t_) + u) * 64];                                           \
+  }
+#define HIFAMD_CTZ_MFMA(pr, pi, t_)                                                       \
+  _Pragma("unroll") for (int u = 0; u < KU; ++u) {                                        \
+    const int kb_ = 4 * (KU * (t_) + u) + kq;                                             \
+    const double br_ = Bre[kb_ << 4], bi_ = Bim[kb_ << 4];                                \
+    a_rr = __builtin_amdgcn_mfma_f64_16x16x4f64(pr[u], br_, a_rr, 0, 0, 0);               \
+    a_ii = __builtin_amdgcn_mfma_f64_16x16x4f64(pi[u], bi_, a_ii, 0, 0, 0);               \
+    a_ri = __builtin_amdgcn_mfma_f64_16x16x4f64(pr[u], bi_, a_ri, 0, 0, 0);               \
+    a_ir = __builtin_amdgcn_mfma_f64_16x16x4f64(pi[u], br_, a_ir, 0, 0, 0);               \
+  }
+      const int nsets = (nk + KU - 1) / KU;
+      int t = 0;
+      HIFAMD_CTZ_LOAD(pr0, pi0, 0)
+      while (t < nsets) {
+        if (t + 1 < nsets) HIFAMD_CTZ_LOAD(pr1, pi1, t + 1)
+        HIFAMD_CTZ_MFMA(pr0, pi0, t)
+        if (t + 1 >= nsets) break;
+        if (t + 2 < nsets) HIFAMD_CTZ_LOAD(pr0, pi0, t + 2)
+        HIFAMD_CTZ_MFMA(pr1, pi1, t + 1)
+        t += 2;
+      }
+#undef HIFAMD_CTZ_LOAD
+#undef HIFAMD_CTZ_MFMA
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * strip + kq + 4 * r;
+        if (row < nb) {
+          const cplx res = cplx{a_rr[r] - a_ii[r], a_ri[r] + a_ir[r]};
+          if (last_u) {
+            if (cc < lu.nrhs) yout[(int64_t)s_oi[row] * lu.ldy + cc] = vscale(s_ot[row], res);
+          } else {
+            x[((int64_t)s_rowid[row] << 6) + cc] = res;
+          }
+        }
+      }
+    }
+    __syncthreads();  // (the next component overwrites the LDS planes)
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Component-dense band for COMPLEX data (gfx950 has no complex MFMA): the same scheme as k_band_cd<LOWER, false> --
 // a dependency component per workgroup, LDS-resident, x_c = Tinv_c (rhs_c - older-source sums) -- with the component's
 // right-hand sides kept as TWO real planes in LDS (re[rows][64], im[rows][64]) and the explicit inverse as two real
