@@ -441,6 +441,7 @@ class Engine : public EngineBase {
   int cs_max_wgs = 0;    // HIFIR_AMD_CS_MAX_WGS (full batches: measured equal to k_band_cd at every band width)
   int ct_wide_wgs = 128; // HIFIR_AMD_CT_WIDE: a component band with more workgroups than this takes two column tiles per workgroup
   int ct_wide4_wgs = 1 << 30;  // HIFIR_AMD_CT_WIDE4: ... and with more than this all four (one workgroup per component)
+  int ct_mode_real = 1;  // HIFIR_AMD_CT_REAL=0: real handles keep the entry walk while HIFIR_AMD_CT_Z stays as set (tests)
   int ct_mode_z = 0;     // HIFIR_AMD_CT_Z=1: complex component bands on coefficient tiles too (k_band_ct_z; measured SLOWER than the
                          // entry walk at every width on BASELINE config 5: 7.17 vs 7.00 ms at 16, 17.9 vs 16.1 ms at 64 columns)
   int ct_mode = 1;       // HIFIR_AMD_CT=0: dense-own component bands walk their entries one by one (k_band_cd / k_band_cs) instead of
@@ -499,6 +500,7 @@ class Engine : public EngineBase {
     cs_max_wgs = env_int("HIFIR_AMD_CS_MAX_WGS", 0);
     ct_mode = env_int("HIFIR_AMD_CT", 1);
     ct_mode_z = env_int("HIFIR_AMD_CT_Z", 0);
+    ct_mode_real = env_int("HIFIR_AMD_CT_REAL", 1);
     spmm_rb = env_int("HIFIR_AMD_SPMM_RB", 1) == 2 ? 2 : 1;
     spmm_tiles_z = env_int("HIFIR_AMD_SPMM_TILES_Z", 1);
     spmm_split_blocks = env_int("HIFIR_AMD_SPMM_SPLIT_BLOCKS", 4096);
@@ -673,6 +675,7 @@ class Engine : public EngineBase {
       E->cs_max_wgs = cs_max_wgs;
       E->ct_mode = ct_mode;
       E->ct_mode_z = ct_mode_z;
+      E->ct_mode_real = ct_mode_real;
       E->spmm_rb = spmm_rb;
       E->spmm_tiles_z = spmm_tiles_z;
       E->spmm_split_blocks = spmm_split_blocks;
@@ -741,6 +744,7 @@ class Engine : public EngineBase {
       E->cs_max_wgs = cs_max_wgs;
       E->ct_mode = ct_mode;
       E->ct_mode_z = ct_mode_z;
+      E->ct_mode_real = ct_mode_real;
       E->spmm_rb = spmm_rb;
       E->spmm_tiles_z = spmm_tiles_z;
       E->spmm_split_blocks = spmm_split_blocks;
@@ -880,7 +884,7 @@ class Engine : public EngineBase {
   // growth again in the other direction: a band that is flagged and grows under the new values is demoted as usual).
   void ship_block_inverses(BandPlan &P, const Csr<T> &A, int64_t total_elems, DevCsr &M) {
     M.upload(A, &P);
-    if (ct_mode && (sizeof(T) == sizeof(double) || ct_mode_z) && band_opt.dense_block > 0 && !P.cd_sparse && !P.band_cd.empty()) {
+    if (ct_mode && (sizeof(T) == sizeof(double) ? ct_mode_real : ct_mode_z) && band_opt.dense_block > 0 && !P.cd_sparse && !P.band_cd.empty()) {
       // dense-own component bands: the entries a component reads from older rows as 16 x 4 coefficient tiles (k_band_ct)
       CtTiles Tl;
       build_ct_tiles(P, A, Tl);

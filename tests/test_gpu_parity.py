@@ -25,6 +25,9 @@ MODES = {
     # ... with sparse-own components (k_band_cd / k_band_cs / k_band_cs_z <sparse>) on every shallow thin triangle, whatever
     # its size: what level 0 of the 1M-row (real) and 2M-row (complex) hierarchies runs, here on the small fixtures
     "R64-fast-sparse-own": (6, 2048, {"HIFIR_AMD_CD_SPARSE_MIN_ROWS": "0"}),
+    # ... with the coefficient tiles off (real data: the entry walk of rounds 2-3, k_band_cd / k_band_cs, which still ships
+    # behind HIFIR_AMD_CT=0) and ON for complex data (k_band_ct_z, off by default: measured slower)
+    "R64-fast-walk-real-tiles-complex": (6, 2048, {"HIFIR_AMD_CT": "1", "HIFIR_AMD_CT_Z": "1", "HIFIR_AMD_CT_REAL": "0"}),
 }
 
 
