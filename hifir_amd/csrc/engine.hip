@@ -153,6 +153,7 @@ struct DevCsr {
   DevBuf f_desc, f_col, f_val, f_lrow;  // L only: the streams with the level's F entries appended (host.hpp build_cd_streams_fused)
   bool f_fused = false;
   // tile form of the dense-own component bands' walked entries (host.hpp build_ct_tiles, kernel k_band_ct)
+  DevBuf rowflag;  // sparse-own plans: per slot, what a level's FIRST solve may leave out (build_row_flags; kernels RowSkip)
   DevBuf ct_desc, ct_sptr, ct_src, ct_coef;
   bool ct_on = false;
   int64_t ct_tiles = 0;
@@ -200,6 +201,7 @@ struct DevCsr {
     f_val.alias(o.f_val);
     f_lrow.alias(o.f_lrow);
     f_fused = o.f_fused;
+    rowflag.alias(o.rowflag);
     ct_desc.alias(o.ct_desc);
     ct_sptr.alias(o.ct_sptr);
     ct_src.alias(o.ct_src);
@@ -307,6 +309,7 @@ struct DevLevel {
   // does not write itself (the other bands' rows and the child's)
   DevBuf q_s7, s7_list;
   int64_t s7_n = -1;  // -1: not fused
+  int64_t skip_w = 0, skip_v = 0;  // rows the first solve does not store (L.rowflag bit 0 / U.rowflag bit 0)
   void alloc_arena(size_t bytes_each) {
     arena.alloc(2 * bytes_each);
     w.view(arena, 0, bytes_each);
@@ -441,6 +444,7 @@ class Engine : public EngineBase {
   int cs_max_wgs = 0;    // HIFIR_AMD_CS_MAX_WGS (full batches: measured equal to k_band_cd at every band width)
   int ct_wide_wgs = 128; // HIFIR_AMD_CT_WIDE: a component band with more workgroups than this takes two column tiles per workgroup
   int ct_wide4_wgs = 1 << 30;  // HIFIR_AMD_CT_WIDE4: ... and with more than this all four (one workgroup per component)
+  int skip_rows = 3;  // HIFIR_AMD_SKIP_ROWS: bit 0 L rows / bit 1 U rows a level's first solve does not store (build_row_flags); 0: every row
   int ct_mode_real = 1;  // HIFIR_AMD_CT_REAL=0: real handles keep the entry walk while HIFIR_AMD_CT_Z stays as set (tests)
   int ct_mode_z = 0;     // HIFIR_AMD_CT_Z=1: complex component bands on coefficient tiles too (k_band_ct_z; measured SLOWER than the
                          // entry walk at every width on BASELINE config 5: 7.17 vs 7.00 ms at 16, 17.9 vs 16.1 ms at 64 columns)
@@ -501,6 +505,7 @@ class Engine : public EngineBase {
     ct_mode = env_int("HIFIR_AMD_CT", 1);
     ct_mode_z = env_int("HIFIR_AMD_CT_Z", 0);
     ct_mode_real = env_int("HIFIR_AMD_CT_REAL", 1);
+    skip_rows = env_int("HIFIR_AMD_SKIP_ROWS", 3);
     spmm_rb = env_int("HIFIR_AMD_SPMM_RB", 1) == 2 ? 2 : 1;
     spmm_tiles_z = env_int("HIFIR_AMD_SPMM_TILES_Z", 1);
     spmm_split_blocks = env_int("HIFIR_AMD_SPMM_SPLIT_BLOCKS", 4096);
@@ -676,6 +681,7 @@ class Engine : public EngineBase {
       E->ct_mode = ct_mode;
       E->ct_mode_z = ct_mode_z;
       E->ct_mode_real = ct_mode_real;
+      E->skip_rows = skip_rows;
       E->spmm_rb = spmm_rb;
       E->spmm_tiles_z = spmm_tiles_z;
       E->spmm_split_blocks = spmm_split_blocks;
@@ -745,6 +751,7 @@ class Engine : public EngineBase {
       E->ct_mode = ct_mode;
       E->ct_mode_z = ct_mode_z;
       E->ct_mode_real = ct_mode_real;
+      E->skip_rows = skip_rows;
       E->spmm_rb = spmm_rb;
       E->spmm_tiles_z = spmm_tiles_z;
       E->spmm_split_blocks = spmm_split_blocks;
@@ -873,6 +880,74 @@ class Engine : public EngineBase {
     host.has_dense = true;
   }
 
+  // What the FIRST solve of a level (S2, prec_solve.hpp:364) need not move (round 4).  Its result y_1 only feeds the Schur
+  // right-hand side b_2 - E y_1 (:366-368) -- the second solve starts again from b_1 -- and level 0 of a PDE hierarchy is
+  // two thirds rows WITHOUT any L entry (their L solve is the copy s[p] b[p]).  For the rows of a level (without a top
+  // operator) that sit in sparse-own component bands which touch them first, in BOTH triangles:
+  //   L slot, bit 0: the row has no entry and no row outside its own component reads it: the L band keeps it in LDS for its
+  //                  component and does not store it;
+  //   U slot, bit 1: that row: the U band takes its right-hand side from the level's input (same product, same bits);
+  //   U slot, bit 0: no column of E and no row outside the component refers to the row: its result is not stored.
+  // Rows of other kinds of bands (prefix passes, dense blocks) are never marked and count as outside readers.
+  // Used by enqueue_level for S2 only, and only with S1 fused (the flags' rows are never written otherwise).
+  // per slot: the component (group) it belongs to when its band is a sparse-own component band that touches its rows
+  // first (no prefix pass, no carried prefix, no dense blocks); -1 otherwise
+  static std::vector<int32_t> first_touch_component(const BandPlan &P, int64_t m) {
+    std::vector<int32_t> comp((size_t)m, -1);
+    if (!P.cd_sparse) return comp;
+    for (int64_t b = 0; b < P.nbands(); ++b) {
+      if (P.band_cd.empty() || !P.band_cd[(size_t)b]) continue;
+      if (!P.band_dense.empty() && P.band_dense[(size_t)b]) continue;
+      if (!P.band_prefix.empty() && P.band_prefix[(size_t)b]) continue;
+      if (!P.band_fused.empty() && P.band_fused[(size_t)b]) continue;
+      for (int32_t g = P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b]]; g < P.wg_grp_ptr[(size_t)P.band_wg_ptr[(size_t)b + 1]]; ++g)
+        for (int32_t sl = P.grp_slot_ptr[(size_t)g]; sl < P.grp_slot_ptr[(size_t)g + 1]; ++sl) comp[(size_t)sl] = g;
+    }
+    return comp;
+  }
+  void build_row_flags(const HostLevel<T> &H, DevLevel &L) {
+    const int64_t m = H.m;
+    if (m <= 0 || H.n <= m || L.top_n > 0 || !L.L.cd_sparse || !L.U.cd_sparse) return;
+    if ((int64_t)H.Lr.rowid.size() != m || (int64_t)H.Ur.rowid.size() != m || H.Lp.srcslot.size() != H.Lr.col.size() ||
+        H.Up.srcslot.size() != H.Ur.col.size())
+      return;
+    const std::vector<int32_t> compL = first_touch_component(H.Lp, m), compU = first_touch_component(H.Up, m);
+    // slots whose value a row OUTSIDE their own component reads from memory (rows of other kinds of bands: every entry)
+    auto outside_sources = [&](const Csr<T> &A, const BandPlan &P, const std::vector<int32_t> &comp) {
+      std::vector<uint8_t> used((size_t)m, 0);
+      for (int64_t t = 0; t < m; ++t)
+        for (int32_t k = A.ptr[(size_t)t]; k < A.ptr[(size_t)t + 1]; ++k) {
+          const int32_t src = P.srcslot[(size_t)k];
+          if (comp[(size_t)t] < 0 || comp[(size_t)src] != comp[(size_t)t]) used[(size_t)src] = 1;
+        }
+      return used;
+    };
+    const std::vector<uint8_t> usedL = outside_sources(H.Lr, H.Lp, compL), usedU = outside_sources(H.Ur, H.Up, compU);
+    std::vector<uint8_t> ecol((size_t)m, 0);
+    for (int32_t c : H.Er.col) ecol[(size_t)c] = 1;
+    std::vector<int32_t> uslot((size_t)m, -1);  // row -> U slot
+    for (int64_t sl = 0; sl < m; ++sl) uslot[(size_t)H.Ur.rowid[(size_t)sl]] = (int32_t)sl;
+    std::vector<uint8_t> fL((size_t)m, 0), fU((size_t)m, 0);
+    int64_t nred = 0, nskip = 0;
+    for (int64_t sl = 0; sl < m && (skip_rows & 1); ++sl) {
+      if (compL[(size_t)sl] < 0 || usedL[(size_t)sl] || H.Lr.ptr[(size_t)sl + 1] != H.Lr.ptr[(size_t)sl]) continue;
+      const int32_t us = uslot[(size_t)H.Lr.rowid[(size_t)sl]];
+      if (us < 0 || compU[(size_t)us] < 0) continue;  // (the U kernel that touches the row first must know where to look)
+      fL[(size_t)sl] = 1;
+      fU[(size_t)us] |= 2;
+      ++nred;
+    }
+    for (int64_t sl = 0; sl < m && (skip_rows & 2); ++sl)
+      if (compU[(size_t)sl] >= 0 && !usedU[(size_t)sl] && !ecol[(size_t)H.Ur.rowid[(size_t)sl]]) {
+        fU[(size_t)sl] |= 1;
+        ++nskip;
+      }
+    if (nred + nskip == 0) return;
+    L.L.rowflag.upload(fL, 8);
+    L.U.rowflag.upload(fU, 8);
+    L.skip_w = nred;
+    L.skip_v = nskip;
+  }
   // Block inverses of a triangle -- the 2,048-row blocks of its dense chains and the components of its
   // component-dense bands: built into two pinned staging buffers (reused, so the host never holds more than two
   // buffers full) and streamed to HBM while the next batch is being inverted.  Consecutive small blocks share a
@@ -1084,6 +1159,9 @@ class Engine : public EngineBase {
           L.s7_list.upload(list, 8);
           L.s7_n = (int64_t)list.size();
         }
+      }
+      if constexpr (std::is_same<T, double>::value) {
+        if (skip_rows && band_opt.dense_block > 0) build_row_flags(H, L);
       }
       L.d.upload(H.d);
       L.s.upload(H.s);
@@ -1364,7 +1442,7 @@ class Engine : public EngineBase {
   // flp != NULL: S1 is fused into this L solve -- whichever kernel touches a row first reads s[p] * b[p] (kernels FirstL)
   template <bool LOWER>
   void launch_trsv(hipStream_t st, const DevLevel &L, int logR, int64_t &count, const FL *flp = nullptr, bool with_f = false,
-                   const LU *lup = nullptr) {
+                   const LU *lup = nullptr, const FL *skip_fl = nullptr) {
     const DevCsr &M = LOWER ? L.L : L.U;
     if (M.nrows == 0) return;
     const FL fl = (LOWER && flp) ? *flp : no_fl();
@@ -1430,8 +1508,10 @@ class Engine : public EngineBase {
         }
         if (cdb) {
           // (the fused S7 -- LastU -- belongs to the LAST band of the final U solve only)
-          launch_band_cd<LOWER>(st, L, M, g0, g1, pre, ps0, ps1, extra, fl, LOWER && with_f,
-                                (!LOWER && lup && b + 1 == nb) ? *lup : no_lu(), b, cd_two);
+          // (skip_fl: the level's first solve; the U bands get the level's input for the rows the L bands did not store)
+          launch_band_cd<LOWER>(st, L, M, g0, g1, pre, ps0, ps1, extra, (!LOWER && skip_fl) ? *skip_fl : fl, LOWER && with_f,
+                                (!LOWER && lup && b + 1 == nb) ? *lup : no_lu(), b, cd_two,
+                                RowSkip{skip_fl ? M.rowflag.template as<uint8_t>() : (const uint8_t *)nullptr});
           ++count;
           continue;
         }
@@ -1593,7 +1673,7 @@ class Engine : public EngineBase {
   template <bool LOWER>
   void launch_band_cd(hipStream_t st, const DevLevel &L, const DevCsr &M, int32_t g0, int32_t g1, int pre, int32_t ps0,
                       int32_t ps1, unsigned extra, const FL &fl, bool with_f = false, const LU &lu = no_lu(), size_t band = 0,
-                      bool no_walk = false) {
+                      bool no_walk = false, RowSkip rs = RowSkip{nullptr}) {
     if constexpr (std::is_same<T, double>::value) {
       // LDS: the component's right-hand sides + its row ids (the attribute for > 64 KB is set in bind_device)
       const size_t lds = cd_lds_bytes(M.cd_sparse, M.own_cap);
@@ -1632,7 +1712,7 @@ class Engine : public EngineBase {
                            (with_f ? M.f_val : M.mid_val).template as<double>(), (with_f ? M.f_lrow : M.mid_lrow).template as<uint8_t>(),
                            pre ? 0 : 1, (int32_t)(g1 - g0), (int32_t)nsl, ps0, ps1, single_c0,
                            lds_rows, M.own_cap, cd_dbg | (no_walk ? 1 : 0), fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
-                           M.own_lvl.as<uint8_t>(), lu);
+                           M.own_lvl.as<uint8_t>(), lu, M.cd_sparse ? rs : RowSkip{nullptr});
         return;
       }
       auto kern = M.cd_sparse ? k_band_cd<LOWER, true> : k_band_cd<LOWER, false>;
@@ -1643,7 +1723,7 @@ class Engine : public EngineBase {
                          (with_f ? M.f_val : M.mid_val).template as<double>(), (with_f ? M.f_lrow : M.mid_lrow).template as<uint8_t>(),
                          pre ? 0 : 1, (int32_t)(g1 - g0), ps0, ps1, single_c0,
                          lds_rows, M.own_cap, cd_dbg | (no_walk ? 1 : 0), fl, M.own_val.as<double>(), M.own_lsrc.as<uint8_t>(), M.own_rptr.as<uint16_t>(),
-                         M.own_lvl.as<uint8_t>(), lu);
+                         M.own_lvl.as<uint8_t>(), lu, M.cd_sparse ? rs : RowSkip{nullptr});
     } else {
       (void)ps0, (void)ps1, (void)with_f;
       if (extra) throw Error(HIFAMD_HIFIR_ERROR, "internal error: carried prefix on a complex handle");
@@ -1682,11 +1762,13 @@ class Engine : public EngineBase {
     }
   }
 
+  // first: this is the level's FIRST solve with S1 fused -- the bands may leave out what build_row_flags marked
   void launch_ldu(hipStream_t st, DevLevel &L, int logR, int64_t &count, const FL *fl = nullptr, bool with_f = false,
-                  const LU *lu = nullptr) {
+                  const LU *lu = nullptr, bool first = false) {
     if (!L.m) return;
-    launch_trsv<true>(st, L, logR, count, fl, with_f);
-    launch_trsv<false>(st, L, logR, count, nullptr, false, lu);
+    const bool skip = first && fl && !with_f && !lu && logR == 6 && L.L.rowflag.p && L.U.rowflag.p;
+    launch_trsv<true>(st, L, logR, count, fl, with_f, nullptr, skip ? fl : nullptr);
+    launch_trsv<false>(st, L, logR, count, nullptr, false, lu, skip ? fl : nullptr);
   }
 
   // complex products on the real matrix cores (operands: two real planes, see host.hpp mfma_operand)
@@ -1798,7 +1880,7 @@ class Engine : public EngineBase {
     mark(l, 1, c0, count);
     if (nm) {
       c0 = count;
-      launch_ldu(st, L, logR, count, fuse_s1 ? &fl : nullptr);  // S2  :364
+      launch_ldu(st, L, logR, count, fuse_s1 ? &fl : nullptr, false, nullptr, /*first=*/fuse_s1);  // S2  :364
       mark(l, 2, c0, count);
       // S3  :366-368  -> w[m:n] (becomes the child's rhs, :386)
       c0 = count;
@@ -2609,9 +2691,11 @@ class Engine : public EngineBase {
   int stats_ext(double *o, int cap) const {
     // resident bytes of this handle beside the explicit operators: the work arena of every level (w + v, Rmax columns),
     // the coefficient tiles of the component bands, the factors with their plan arrays
-    double arena = 0.0, tiles = 0.0, factors = 0.0;
+    double arena = 0.0, tiles = 0.0, factors = 0.0, skip_w = 0.0, skip_v = 0.0;
     for (const auto &L : lv) {
       arena += (double)L->arena.bytes;
+      skip_w += (double)L->skip_w;
+      skip_v += (double)L->skip_v;
       for (const DevCsr *M : {&L->L, &L->U, &L->E, &L->F}) {
         tiles += (double)(M->ct_sptr.bytes + M->ct_src.bytes + M->ct_coef.bytes + M->ct_desc.bytes);
         factors += (double)(M->ptr.bytes + M->col.bytes + M->val.bytes + M->rowid.bytes + M->srcslot.bytes + M->split.bytes + M->csplit.bytes +
@@ -2621,7 +2705,8 @@ class Engine : public EngineBase {
     }
     const double v[] = {finalize_seconds, capture_ms,     bytes_inverses,  bytes_top,     bytes_tail,           (double)tail_n,
                         (double)tail_level, tail_probe_err, tail_max_abs, (double)tail_rejected, tail_probe_tol, tail_max_growth,
-                        (double)levels_from_cache, analysis_seconds, arena, (double)Rmax, tiles, factors, (double)max_nrhs};
+                        (double)levels_from_cache, analysis_seconds, arena, (double)Rmax, tiles, factors, (double)max_nrhs,
+                        skip_w, skip_v};
     const int nv = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < cap && i < nv; ++i) o[i] = v[i];
     return nv;

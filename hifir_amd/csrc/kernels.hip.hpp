@@ -124,6 +124,16 @@ __device__ __forceinline__ T first_l_rhs(const T *__restrict__ bin, const FirstL
 // S7 fused into the LAST band of a level's final U solve: y[i] = t[i] * v[q_inv[i]] (prec_solve.hpp:411) is, for a row
 // r that this band finishes, y[q[r]] = t[q[r]] * v_r -- the band writes the level's output itself and v[r], which
 // nothing reads any more, not at all; k_scatter_scale_list serves the rows of the other bands and of the child.
+// What a level's FIRST solve may leave out, per slot of a sparse-own triangle (engine.hip build_row_flags; NULL otherwise):
+//   bit 0  nobody reads this row's result from memory in this solve: it is not stored (L: a row without entries whose
+//          value only its own component uses; U: a row no other component and no column of E refers to);
+//   bit 1  (U) the L solve did not store the row: its right-hand side is s[p[i]] * b[p[i]] (FirstL), the product the L
+//          kernel would have stored.
+// (p[i] and s[p[i]] in slot order beside the flags -- no dependent gathers -- measured SLOWER: the U band 244 -> 316 us.)
+struct RowSkip {
+  const uint8_t *flag;
+};
+
 template <class T>
 struct LastU {
   IoPtr<T> out;
@@ -2422,7 +2432,7 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
                                                   int32_t lds_rows, int32_t own_cap, int dbg, FirstL<double> fl,
                                                   const double *__restrict__ own_val, const uint8_t *__restrict__ own_lsrc,
                                                   const uint16_t *__restrict__ own_rptr, const uint8_t *__restrict__ own_lvl,
-                                                  LastU<double> lu) {
+                                                  LastU<double> lu, RowSkip rs) {
   extern __shared__ double cd_tbuf[];  // [lds_rows][64] right-hand sides, then lds_rows row ids
   HIFAMD_CSP_DECL
   HIFAMD_CSP(0)
@@ -2499,12 +2509,20 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
       for (int u = 0; u < KU; ++u) a0[u] = ap_[u * 64];
     }
     // ---- phase 1a: right-hand sides of this wave's rows into LDS (row ids one per lane, eight loads in flight)
-    int32_t h_i = 0, h_p = 0;
+    int32_t h_i = 0, h_p = LOWER ? 0 : -1;
     double h_d = 1.0;  // (U: the pivot; fused S1: the row's scale)
+    double h_s = 0.0;  // (U, rowflag bit 1: the row's scale)
+    const bool from_b = !LOWER && SPARSE && div_u && rs.flag != nullptr;
+    const double *bsrc = from_b ? fl.bin.get() : nullptr;
     if (lane < nr) {
       h_i = rowid[s0 + r0 + lane];
-      cd_rowid[r0 + lane] = h_i;
+      const int hf = (SPARSE && rs.flag) ? (int)rs.flag[s0 + r0 + lane] : 0;
+      cd_rowid[r0 + lane] = (hf & 1) ? ~h_i : h_i;  // (negative: not stored)
       if (div_u) h_d = d[h_i];
+      if (from_b && (hf & 2)) {
+        h_p = fl.p[h_i];
+        h_s = fl.s[h_p];
+      }
       if (first_l) {
         h_p = fl.p[h_i];
         h_d = fl.s[h_p];
@@ -2528,14 +2546,20 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int32_t i = rl32(first_l ? h_p : h_i, min(j + q, 63));
-        t_[q] = (j + q < nr) ? rhs[(int64_t)i * rstride + rlane] : 0.0;
+        const double *src = rhs + (int64_t)i * rstride + rlane;
+        if (from_b) {
+          const int32_t pb = rl32(h_p, min(j + q, 63));  // (wave-uniform)
+          if (pb >= 0) src = bsrc + (int64_t)pb * fl.ldb + min(lane, fl.nrhs - 1);
+        }
+        t_[q] = (j + q < nr) ? *src : 0.0;
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q)
         if (j + q < nr) {
           const double hd = rl64(h_d, min(j + q, 63));
-          cd_tbuf[((r0 + j + q) << 6) + lane] =
-              div_u ? t_[q] / hd : (first_l ? (lane < fl.nrhs ? hd * t_[q] : 0.0) : t_[q]);
+          double tq = t_[q];
+          if (from_b && rl32(h_p, min(j + q, 63)) >= 0) tq = lane < fl.nrhs ? rl64(h_s, min(j + q, 63)) * tq : 0.0;
+          cd_tbuf[((r0 + j + q) << 6) + lane] = div_u ? tq / hd : (first_l ? (lane < fl.nrhs ? hd * tq : 0.0) : tq);
         }
     }
     HIFAMD_CSP(3)
@@ -2596,7 +2620,7 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
           const double a2 = cd_tbuf[(r << 6) + lane];
           if (last_u) {
             if (lane < lu.nrhs) yout[(int64_t)cd_oi[r] * lu.ldy + lane] = cd_ot[r] * a2;
-          } else {
+          } else if (cd_rowid[r] >= 0) {
             x[((int64_t)cd_rowid[r] << 6) + lane] = a2;
           }
         }
@@ -2613,7 +2637,8 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
           if (last_u) {
             if (lane < lu.nrhs) yout[(int64_t)cd_oi[r] * lu.ldy + lane] = cd_ot[r] * a2;
           } else {
-            x[((int64_t)cd_rowid[r] << 6) + lane] = a2;
+            const int32_t rid = cd_rowid[r];
+            if (rid >= 0) x[((int64_t)rid << 6) + lane] = a2;
           }
         }
         __syncthreads();
@@ -2768,7 +2793,7 @@ __global__ void __launch_bounds__(256) k_band_cs(int32_t wg0, const int32_t *__r
                                                  int32_t single_c0, int32_t lds_rows, int32_t own_cap, int dbg, FirstL<double> fl,
                                                  const double *__restrict__ own_val, const uint8_t *__restrict__ own_lsrc,
                                                  const uint16_t *__restrict__ own_rptr, const uint8_t *__restrict__ own_lvl,
-                                                 LastU<double> lu) {
+                                                 LastU<double> lu, RowSkip rs) {
   extern __shared__ double cs_buf[];
   HIFAMD_CSP_DECL
   HIFAMD_CSP(0)
@@ -2818,6 +2843,10 @@ __global__ void __launch_bounds__(256) k_band_cs(int32_t wg0, const int32_t *__r
   const bool last_u = !LOWER && lu.on();
   double *yout = last_u ? lu.out.get() : nullptr;
   const int kq = grp;
+  // (RowSkip: a row of the U solve whose right-hand side comes from the level's input keeps p[i] in s_hp -- -1 otherwise --
+  // and its scale in s_ot; the fused S7 never meets the flags: they belong to a level's first solve)
+  const bool from_b = !LOWER && SPARSE && div_u && rs.flag != nullptr;
+  const double *bsrc = from_b ? fl.bin.get() : nullptr;
   for (int32_t c = c_first; c < c_last; ++c) {
     const int32_t *dsc = cd_desc + (int64_t)c * 28;
     const int32_t s0 = dsc[0], nb = dsc[1], mid0 = dsc[2];
@@ -2834,8 +2863,17 @@ __global__ void __launch_bounds__(256) k_band_cs(int32_t wg0, const int32_t *__r
     // ---- phase 0: the component's row ids and per-row scalars (coalesced), sparse: its own nonzeros
     for (int32_t t = (int32_t)threadIdx.x; t < nb; t += 256) {
       const int32_t i = rowid[s0 + t];
-      s_rowid[t] = i;
+      const int hf = (SPARSE && rs.flag) ? (int)rs.flag[s0 + t] : 0;
+      s_rowid[t] = (hf & 1) ? ~i : i;  // (negative: not stored)
       if (div_u) s_hd[t] = d[i];
+      if (from_b) {
+        int32_t pp = -1;
+        if (hf & 2) {
+          pp = fl.p[i];
+          s_ot[t] = fl.s[pp];
+        }
+        s_hp[t] = pp;
+      }
       if (first_l) {
         const int32_t pp = fl.p[i];
         s_hp[t] = pp;
@@ -2880,14 +2918,22 @@ __global__ void __launch_bounds__(256) k_band_cs(int32_t wg0, const int32_t *__r
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int r = r0 + min(j + q, max(nr - 1, 0));
-        const int32_t i = first_l ? s_hp[r] : s_rowid[r];
-        t_[q] = (j + q < nr) ? rhs[(int64_t)i * rstride + rcol] : 0.0;
+        const int32_t rid = s_rowid[r];
+        const int32_t i = first_l ? s_hp[r] : (rid < 0 ? ~rid : rid);
+        const double *src = rhs + (int64_t)i * rstride + rcol;
+        if (from_b) {
+          const int32_t pb = s_hp[r];
+          if (pb >= 0) src = bsrc + (int64_t)pb * fl.ldb + min(cc, fl.nrhs - 1);
+        }
+        t_[q] = (j + q < nr) ? *src : 0.0;
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q)
         if (j + q < nr) {
           const double hd = s_hd[r0 + j + q];
-          tb[((r0 + j + q) << 4) + l16] = div_u ? t_[q] / hd : (first_l ? (cc < fl.nrhs ? hd * t_[q] : 0.0) : t_[q]);
+          double tq = t_[q];
+          if (from_b && s_hp[r0 + j + q] >= 0) tq = cc < fl.nrhs ? s_ot[r0 + j + q] * tq : 0.0;
+          tb[((r0 + j + q) << 4) + l16] = div_u ? tq / hd : (first_l ? (cc < fl.nrhs ? hd * tq : 0.0) : tq);
         }
     }
     HIFAMD_CSP(3)
@@ -2930,7 +2976,8 @@ __global__ void __launch_bounds__(256) k_band_cs(int32_t wg0, const int32_t *__r
           if (last_u) {
             if (cc < lu.nrhs) yout[(int64_t)s_oi[r] * lu.ldy + cc] = s_ot[r] * a2;
           } else {
-            x[((int64_t)s_rowid[r] << 6) + cc] = a2;
+            const int32_t rid = s_rowid[r];
+            if (rid >= 0) x[((int64_t)rid << 6) + cc] = a2;
           }
         }
         __syncthreads();

@@ -148,7 +148,9 @@ HifAmdStatus hifamd_stats(HifAmdHdl h, double *stats16);
  * file the handle was loaded from (hifamd_save_ex), 13 host seconds spent analyzing the levels (or adopting their
  * analysis), 14 bytes of the work arena (w + v of every level), 15 its width in columns (this build: always 64 -- the
  * fast kernels address a 64-column arena; max_nrhs bounds the batch width a call may pass, not the arena), 16 bytes of
- * the component bands' coefficient tiles, 17 bytes of the factors with their plan arrays, 18 max_nrhs of hifamd_finalize.
+ * the component bands' coefficient tiles, 17 bytes of the factors with their plan arrays, 18 max_nrhs of hifamd_finalize,
+ * 19 / 20 rows (all levels) whose L / U result the FIRST solve of a level does not store because nothing reads it from
+ * memory (real handles, sparse-own levels; HIFIR_AMD_SKIP_ROWS=0: none).
  * -1 for a NULL handle. */
 int hifamd_stats_ext(HifAmdHdl h, double *out, int cap);
 /* Per-level sizes (what the SURVEY 8(d) byte formula needs level by level): 0 m, 1 n, 2 nnz(L_B), 3 nnz(U_B), 4 nnz(E),

@@ -251,6 +251,54 @@ def test_column_bits_do_not_depend_on_the_batch_width(cache, name):
         assert np.array_equal(Xm, X[:, 40:48])
 
 
+def test_rows_the_first_solve_leaves_out_do_not_change_a_bit():
+    # Round 4: the FIRST solve of a sparse-own level (prec_solve.hpp:364; its result only feeds b_2 - E y_1, :366-368) does
+    # not store L rows without entries that only their own component reads, nor U rows no column of E refers to
+    # (engine.hip build_row_flags).  Same arithmetic on every row that is used: same bits as with every row stored, at
+    # the 64-column kernels (k_band_cd) and the 16-column slices (k_band_cs), forwards and transposed.
+    import os
+
+    keep = {k: os.environ.get(k) for k in ("HIFIR_AMD_CD_SPARSE_MIN_ROWS", "HIFIR_AMD_SKIP_ROWS", "HIFIR_AMD_DENSE_BLOCK",
+                                           "HIFIR_AMD_MIN_LOGR")}
+    skipped = 0
+    try:
+        os.environ["HIFIR_AMD_CD_SPARSE_MIN_ROWS"] = "0"
+        os.environ["HIFIR_AMD_DENSE_BLOCK"] = "2048"
+        os.environ["HIFIR_AMD_MIN_LOGR"] = "6"
+        for name in HIER_NAMES:
+            levels, d = load_hier(name)
+            if np.iscomplexobj(d["b"]):
+                continue
+            n = int(levels[0]["n"])
+            rng = np.random.default_rng(7)
+            B = rng.uniform(-1, 1, size=(n, 64))
+            out = []
+            for flag in ("3", "0"):
+                os.environ["HIFIR_AMD_SKIP_ROWS"] = flag
+                M = hifir_amd.HIF.from_levels(levels, max_nrhs=64)
+                se = M.stats_ext()
+                if flag == "3":
+                    skipped += int(se["rows_not_stored_L"]) + int(se["rows_not_stored_U"])
+                else:
+                    assert se["rows_not_stored_L"] == 0 and se["rows_not_stored_U"] == 0
+                out.append([M.solve_mrhs(B, trans=tr) for tr in (False, True)] +
+                           [M.solve_mrhs(np.ascontiguousarray(B[:, :9]), trans=tr) for tr in (False, True)])
+                # a second apply on the same handle: the rows left out hold what an earlier batch left there
+                B2 = np.full_like(B, np.nan)
+                M.solve_mrhs(B2)
+                again = M.solve_mrhs(B)
+                assert np.array_equal(again, out[-1][0]), name
+            for a, b in zip(*out):
+                assert np.array_equal(a, b), name
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert skipped > 0  # (the fixtures do have such rows: the test is not vacuous)
+
+
 @pytest.mark.parametrize("name", ["cd2d_48", "young1c"])
 def test_saved_hierarchy_applies_identically(cache, name, tmp_path):
     # hifamd_save -> hifamd_load -> finalize on a "GPU node without the reference": same bits as the original
