@@ -309,6 +309,7 @@ struct DevLevel {
   // does not write itself (the other bands' rows and the child's)
   DevBuf q_s7, s7_list;
   int64_t s7_n = -1;  // -1: not fused
+  int64_t s7_child = 0;  // the list's first s7_child rows are the CHILD's (nothing of this level's second solve feeds them)
   int64_t skip_w = 0, skip_v = 0;  // rows the first solve does not store (L.rowflag bit 0 / U.rowflag bit 0)
   void alloc_arena(size_t bytes_each) {
     arena.alloc(2 * bytes_each);
@@ -381,6 +382,12 @@ class Engine : public EngineBase {
   std::vector<std::unique_ptr<Engine<T>>> twins;
   hipEvent_t ev_fork = nullptr;
   std::vector<hipEvent_t> ev_join;
+  // S7 of the child's rows beside the level's second solve (enqueue_level): a side stream and one fork / join event per level
+  hipStream_t side_stream = nullptr;
+  std::vector<hipEvent_t> ev_side_fork, ev_side_join;
+  // HIFIR_AMD_LIST_EARLY=1 (round 4, measured, OFF): 3.66 -> 3.77 ms on the 1M default hierarchy -- the five fork / join pairs of
+  // the captured graph cost more than the 0.12 ms of list kernels they hide
+  int list_early = 0;
   std::vector<std::unique_ptr<DevLevel>> lv;
   DevDense dn;
   DevCsr A;
@@ -506,6 +513,7 @@ class Engine : public EngineBase {
     ct_mode_z = env_int("HIFIR_AMD_CT_Z", 0);
     ct_mode_real = env_int("HIFIR_AMD_CT_REAL", 1);
     skip_rows = env_int("HIFIR_AMD_SKIP_ROWS", 3);
+    list_early = env_int("HIFIR_AMD_LIST_EARLY", 0);
     spmm_rb = env_int("HIFIR_AMD_SPMM_RB", 1) == 2 ? 2 : 1;
     spmm_tiles_z = env_int("HIFIR_AMD_SPMM_TILES_Z", 1);
     spmm_split_blocks = env_int("HIFIR_AMD_SPMM_SPLIT_BLOCKS", 4096);
@@ -608,7 +616,10 @@ class Engine : public EngineBase {
     twins.clear();
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (auto e : ev_join) (void)hipEventDestroy(e);
+    for (auto e : ev_side_fork) (void)hipEventDestroy(e);
+    for (auto e : ev_side_join) (void)hipEventDestroy(e);
     clear_graphs();
+    if (side_stream) (void)hipStreamDestroy(side_stream);
     if (stream && owns_stream) (void)hipStreamDestroy(stream);
   }
 
@@ -682,6 +693,7 @@ class Engine : public EngineBase {
       E->ct_mode_z = ct_mode_z;
       E->ct_mode_real = ct_mode_real;
       E->skip_rows = skip_rows;
+      E->list_early = list_early;
       E->spmm_rb = spmm_rb;
       E->spmm_tiles_z = spmm_tiles_z;
       E->spmm_split_blocks = spmm_split_blocks;
@@ -752,6 +764,7 @@ class Engine : public EngineBase {
       E->ct_mode_z = ct_mode_z;
       E->ct_mode_real = ct_mode_real;
       E->skip_rows = skip_rows;
+      E->list_early = list_early;
       E->spmm_rb = spmm_rb;
       E->spmm_tiles_z = spmm_tiles_z;
       E->spmm_split_blocks = spmm_split_blocks;
@@ -788,6 +801,7 @@ class Engine : public EngineBase {
         L.q_s7.alias(Pl->q_s7);
         L.s7_list.alias(Pl->s7_list);
         L.s7_n = Pl->s7_n;
+        L.s7_child = Pl->s7_child;
         L.alloc_arena(Pl->w.bytes);
         if (L.w.bytes) zero_dev(L.w.p, L.w.bytes);
         if (L.v.bytes) zero_dev(L.v.p, L.v.bytes);
@@ -1152,9 +1166,12 @@ class Engine : public EngineBase {
           const int32_t s0 = Up.grp_slot_ptr[(size_t)Up.wg_grp_ptr[(size_t)Up.band_wg_ptr[(size_t)nbU - 1]]];
           const int32_t s1 = Up.grp_slot_ptr[(size_t)Up.wg_grp_ptr[(size_t)Up.band_wg_ptr[(size_t)nbU]]];
           for (int32_t sl = s0; sl < s1; ++sl) covered[(size_t)H.Ur.rowid[(size_t)sl]] = 1;
-          std::vector<int32_t> list;
+          std::vector<int32_t> list;  // (the child's rows first: they can go out while this level's second solve runs)
           for (int64_t i = 0; i < H.n; ++i)
-            if (!covered[(size_t)H.q_inv[(size_t)i]]) list.push_back((int32_t)i);
+            if (H.q_inv[(size_t)i] >= H.m) list.push_back((int32_t)i);
+          L.s7_child = (int64_t)list.size();
+          for (int64_t i = 0; i < H.n; ++i)
+            if (H.q_inv[(size_t)i] < H.m && !covered[(size_t)H.q_inv[(size_t)i]]) list.push_back((int32_t)i);
           L.q_s7.upload(H.q);
           L.s7_list.upload(list, 8);
           L.s7_n = (int64_t)list.size();
@@ -1860,6 +1877,27 @@ class Engine : public EngineBase {
                        logR);
   }
 
+  void launch_s7_list(hipStream_t st, const DevLevel &L, const D *v, int64_t first, int64_t cnt, OutP yout, int64_t ldy, int nrhs) {
+    hipLaunchKernelGGL((k_scatter_scale_list<D>), dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, (cnt + 15) / 16))), dim3(256), 0,
+                       st, v, L.qinv.as<int32_t>(), L.t.as<double>(), L.s7_list.as<int32_t>() + first, cnt, yout, ldy, nrhs);
+  }
+  // fork / join of the side stream around one level's early S7 list (inside a stream capture these become graph edges)
+  void side_fork(hipStream_t st, size_t l) {
+    if (!side_stream) HIP_OK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+    while (ev_side_fork.size() <= l) {
+      hipEvent_t a = nullptr, b = nullptr;
+      HIP_OK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+      ev_side_fork.push_back(a);
+      ev_side_join.push_back(b);
+    }
+    HIP_OK(hipEventRecord(ev_side_fork[l], st));
+    HIP_OK(hipStreamWaitEvent(side_stream, ev_side_fork[l], 0));
+  }
+  void side_join(hipStream_t st, size_t l) {
+    HIP_OK(hipEventRecord(ev_side_join[l], side_stream));
+    HIP_OK(hipStreamWaitEvent(st, ev_side_join[l], 0));
+  }
   void enqueue_level(hipStream_t st, size_t l, InP bin, int64_t ldb, OutP yout, int64_t ldy, int nrhs,
                      int logR, int64_t rank, int64_t &count) {
     DevLevel &L = *lv[l];
@@ -1871,6 +1909,8 @@ class Engine : public EngineBase {
     const bool fuse_s1 = fuse_gather && logR == 6 && band_pipe && m > 0;
     const FL fl{bin, ldb, nrhs, L.p.as<int32_t>(), L.s.as<double>()};
     const bool fuse_f_lv = fuse_s1 && L.L.f_fused;  // S5 fused as well (level with thin F rows, all-component L plan)
+    const bool fuse_s7_lv = fuse_out && logR == 6 && m > 0 && L.s7_n >= 0 && s7_kernel_ok(L);
+    int64_t early_rows = 0;  // rows of the S7 list already sent out on the side stream
     int64_t c0 = count;
     if (m && !fuse_s1) {  // S1  :359
       hipLaunchKernelGGL((k_gather_scale<D>), dim3(grid_for(m, logR)), dim3(256), 0, st, bin, ldb, nrhs,
@@ -1896,6 +1936,16 @@ class Engine : public EngineBase {
         mark(l + 1, 4, c0, count);  // (levels l+1 ... and the dense block as one product)
       } else
         enqueue_level(st, l + 1, in_direct(w + m * R), R, out_direct(v + m * R), R, (int)R, logR, rank, count);  // :383-388
+      // S7 of the child's rows (:411) needs nothing of this level's second solve: it leaves now, on the side stream, beside
+      // S5 / S6 (whose component bands are latency-bound and leave the memory system room); joined at the end of the level
+      if (fuse_s7_lv && list_early && L.s7_child > 0) {
+        c0 = count;
+        side_fork(st, l);
+        launch_s7_list(side_stream, L, v, 0, L.s7_child, yout, ldy, nrhs);
+        ++count;
+        mark(l, 7, c0, count);
+        early_rows = L.s7_child;
+      }
       // S5  :392-403   (v[m:n] already is "work[m:n] = y[m:n]")
       c0 = count;
       if (m) {
@@ -1915,7 +1965,7 @@ class Engine : public EngineBase {
     // S6  :406  (its right-hand side is w = s b[p] - F y from S5, or -- no F, or no Schur complement at all -- S1 again)
     // S7 (:411) fused into the last band of this U solve where the plan allows (kernels LastU; finalize built the list of
     // output rows that band does not write)
-    const bool fuse_s7 = fuse_out && logR == 6 && m > 0 && L.s7_n >= 0 && s7_kernel_ok(L);
+    const bool fuse_s7 = fuse_s7_lv;
     const LU lu{yout, ldy, nrhs, L.q_s7.as<int32_t>(), L.t.as<double>()};
     c0 = count;
     launch_ldu(st, L, logR, count, (fuse_s1 && (!(nm && L.F_ncols) || fuse_f_lv)) ? &fl : nullptr, fuse_f_lv && nm && L.F_ncols,
@@ -1923,11 +1973,11 @@ class Engine : public EngineBase {
     mark(l, 6, c0, count);
     c0 = count;
     if (fuse_s7) {
-      if (L.s7_n > 0) {
-        hipLaunchKernelGGL((k_scatter_scale_list<D>), dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, (L.s7_n + 15) / 16))), dim3(256), 0, st, v, L.qinv.as<int32_t>(),
-                           L.t.as<double>(), L.s7_list.as<int32_t>(), L.s7_n, yout, ldy, nrhs);
+      if (L.s7_n > early_rows) {
+        launch_s7_list(st, L, v, early_rows, L.s7_n - early_rows, yout, ldy, nrhs);
         ++count;
       }
+      if (early_rows) side_join(st, l);
     } else {
       hipLaunchKernelGGL((k_scatter_scale<D>), dim3(grid_for(n, logR)), dim3(256), 0, st, v, L.qinv.as<int32_t>(),
                          L.t.as<double>(), n, yout, ldy, nrhs, logR);

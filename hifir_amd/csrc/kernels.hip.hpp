@@ -121,9 +121,6 @@ __device__ __forceinline__ T first_l_rhs(const T *__restrict__ bin, const FirstL
   return lane < f.nrhs ? vscale(f.s[src], b) : vzero(T());
 }
 
-// S7 fused into the LAST band of a level's final U solve: y[i] = t[i] * v[q_inv[i]] (prec_solve.hpp:411) is, for a row
-// r that this band finishes, y[q[r]] = t[q[r]] * v_r -- the band writes the level's output itself and v[r], which
-// nothing reads any more, not at all; k_scatter_scale_list serves the rows of the other bands and of the child.
 // What a level's FIRST solve may leave out, per slot of a sparse-own triangle (engine.hip build_row_flags; NULL otherwise):
 //   bit 0  nobody reads this row's result from memory in this solve: it is not stored (L: a row without entries whose
 //          value only its own component uses; U: a row no other component and no column of E refers to);
@@ -134,6 +131,9 @@ struct RowSkip {
   const uint8_t *flag;
 };
 
+// S7 fused into the LAST band of a level's final U solve: y[i] = t[i] * v[q_inv[i]] (prec_solve.hpp:411) is, for a row
+// r that this band finishes, y[q[r]] = t[q[r]] * v_r -- the band writes the level's output itself and v[r], which
+// nothing reads any more, not at all; k_scatter_scale_list serves the rows of the other bands and of the child.
 template <class T>
 struct LastU {
   IoPtr<T> out;

@@ -28,6 +28,9 @@ MODES = {
     # ... with the coefficient tiles off (real data: the entry walk of rounds 2-3, k_band_cd / k_band_cs, which still ships
     # behind HIFIR_AMD_CT=0) and ON for complex data (k_band_ct_z, off by default: measured slower)
     "R64-fast-walk-real-tiles-complex": (6, 2048, {"HIFIR_AMD_CT": "1", "HIFIR_AMD_CT_Z": "1", "HIFIR_AMD_CT_REAL": "0"}),
+    # ... with S7 of the child's rows on a side stream beside the second solve (off by default: measured slower), sparse-own
+    # components everywhere so that the first solve's row flags are in force as well
+    "R64-fast-early-list": (6, 2048, {"HIFIR_AMD_LIST_EARLY": "1", "HIFIR_AMD_CD_SPARSE_MIN_ROWS": "0"}),
 }
 
 
