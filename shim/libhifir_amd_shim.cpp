@@ -10,9 +10,13 @@
 //   lhf?Update                       : the borrowed user matrix is (re)uploaded for iterative refinement
 //   lhf?ApplyBatch, lhfSetDevices,
 //   lhf?Save/LoadHierarchy           : additive (include/libhifir_amd_ext.h)
-//   s / c / sd / cz families         : exported; the matrix utilities work, every factorization / apply entry point
-//                                      returns LHF_HIFIR_ERROR with a message (the GPU path computes in fp64 /
-//                                      complex fp64 only, and there is no CPU fallback)
+//   s / c / sd / cz families         : the single-precision hierarchy is factorized on the host by the reference in single
+//                                      precision (its own templates), WIDENED exactly to fp64 / complex fp64 on the way to
+//                                      HBM and applied there by the same kernels: lhfsd* / lhfcz* (single hierarchy, double
+//                                      vectors, libhifir.cpp:1192-1284) run the reference's own mixed arithmetic in the
+//                                      sparse stages; lhfs* / lhfc* convert b on the way in and round x on the way out
+//                                      (the apply itself is carried out in the wider type: never less accurate than the
+//                                      reference's float loops; compared with the reference's results at float tolerance)
 //
 // This file includes the reference's OWN declaration header (-I$(REF)/libhifir/include), so a signature that
 // drifted from the reference's would not compile.  Nothing of libhifir.cpp is reproduced: the per-type blocks there
@@ -27,12 +31,15 @@
 #include "libhifir_amd_ext.h"
 #include "hifir_amd.h"
 
+#include <cfloat>
+#include <cmath>
 #include <complex>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -56,9 +63,44 @@ LhfStatus from_amd(HifAmdStatus st) {
 
 std::vector<int> g_devices;  // lhfSetDevices; empty = the current device
 
-const char *const kNoSingle =
-    "single-precision hierarchies are not supported by the MI355X apply path (fp64 / complex fp64 only, no CPU "
-    "fallback): use the d / z entry points";
+typedef std::complex<double> zdbl;
+typedef std::complex<float> cflt;
+
+// the type a value travels in on the device: single-precision data is widened (exactly) on the way to HBM
+template <class V>
+struct Wide {
+  typedef V type;
+  static const bool single = false;
+};
+template <>
+struct Wide<float> {
+  typedef double type;
+  static const bool single = true;
+};
+template <>
+struct Wide<cflt> {
+  typedef zdbl type;
+  static const bool single = true;
+};
+// -> pointer to n values of type W: the source itself when it already is W, a widened copy in buf otherwise
+template <class W>
+const W *widen(const W *src, std::size_t, std::vector<W> &) {
+  return src;
+}
+template <class N, class W>
+N narrow(const W &w) {
+  return N(w);
+}
+template <>
+cflt narrow<cflt, zdbl>(const zdbl &w) {
+  return cflt((float)w.real(), (float)w.imag());
+}
+template <class W, class S>
+const W *widen(const S *src, std::size_t n, std::vector<W> &buf) {
+  buf.resize(n);
+  for (std::size_t i = 0; i < n; ++i) buf[i] = W(src[i]);
+  return (n && src) ? buf.data() : nullptr;
+}
 
 template <class V>
 struct MatrixRec {  // never owns: aliases the caller's arrays (libhifir.cpp:316-321)
@@ -74,6 +116,8 @@ struct HifRec {
   typedef hif::HIF<V, LhfInt, LhfIndPtr> hif_t;
   hif_t *M;                    // the host factorization (NULL for a handle made by lhf?LoadHierarchy)
   MatrixRec<V> *A;             // borrowed (libhifir.cpp:413)
+  MatrixRec<typename Wide<V>::type> *Aw;  // single-precision handles: the double matrix of lhfsdUpdate / lhfczUpdate (Ad / Az)
+  const void *resident;        // which of the two the devices hold for iterative refinement
   std::vector<HifAmdHdl> gpu;  // one resident copy of the hierarchy per device of lhfSetDevices
   double rrqr_cond;
   std::size_t nrows;
@@ -87,6 +131,14 @@ struct ValueTag<double> {
 };
 template <>
 struct ValueTag<std::complex<double>> {
+  static const HifAmdValueType vt = HIFAMD_Z;
+};
+template <>
+struct ValueTag<float> {
+  static const HifAmdValueType vt = HIFAMD_D;
+};
+template <>
+struct ValueTag<std::complex<float>> {
   static const HifAmdValueType vt = HIFAMD_Z;
 };
 
@@ -180,17 +232,18 @@ const typename Arr::value_type *data_or_null(const Arr &a) {
 }
 
 // the user's matrix on every device, CRS (a column-major handle is transposed here; values are not conjugated)
-template <class V>
-LhfStatus upload_matrix(HifRec<V> *h) {
-  const MatrixRec<V> *A = h->A;
+template <class V, class MV>
+LhfStatus upload_matrix_of(HifRec<V> *h, const MatrixRec<MV> *A) {
+  typedef typename Wide<V>::type W;
   if (!A || !A->indptr || h->gpu.empty() || A->n != h->nrows) return LHF_SUCCESS;  // (checked again when refining)
   const std::size_t n = A->n;
   std::vector<int64_t> ip;
   std::vector<int32_t> ix;
-  std::vector<V> vv;
+  std::vector<MV> vv;
+  std::vector<W> wide;
   const int64_t *ipp = (const int64_t *)A->indptr;
   const int32_t *ixp = A->indices;
-  const V *vp = A->vals;
+  const MV *vp = A->vals;
   if (!A->rowmajor) {
     const LhfIndPtr base = A->indptr[0];
     const std::size_t nz = (std::size_t)(A->indptr[n] - base);
@@ -206,11 +259,19 @@ LhfStatus upload_matrix(HifRec<V> *h) {
       }
     ipp = ip.data(), ixp = ix.data(), vp = vv.data();
   }
+  const std::size_t nz = (std::size_t)(A->indptr[n] - A->indptr[0]);
+  const W *wp = widen<W>(vp, nz, wide);
   for (HifAmdHdl g : h->gpu) {
-    const LhfStatus st = from_amd(hifamd_set_matrix(g, (int64_t)n, ipp, ixp, vp));
+    const LhfStatus st = from_amd(hifamd_set_matrix(g, (int64_t)n, ipp, ixp, wp));
     if (st != LHF_SUCCESS) return st;
   }
+  h->resident = A;
   return LHF_SUCCESS;
+}
+template <class V>
+LhfStatus upload_matrix(HifRec<V> *h) {
+  h->resident = nullptr;
+  return upload_matrix_of(h, h->A);
 }
 
 // HIFIR_AMD_MAX_NRHS (1 .. 64, default 64): the widest batch a handle of this process will be asked for -- what ship() and
@@ -236,26 +297,37 @@ LhfStatus ship(HifRec<V> *h) {
     LhfStatus st = from_amd(hifamd_create(ValueTag<V>::vt, dev, &g));
     if (st != LHF_SUCCESS) return st;
     h->gpu.push_back(g);
+    typedef typename Wide<V>::type W;
     for (const auto &p : h->M->precs()) {
+      // (a single-precision hierarchy: every value widened exactly; the buffers live until the level is imported)
+      std::vector<W> bL, bU, bE, bF, bd, bm;
+      std::vector<double> bs, bt;
       st = from_amd(hifamd_add_level(
           g, (int64_t)p.m, (int64_t)p.n, (const int64_t *)data_or_null(p.L_B.col_start()), data_or_null(p.L_B.row_ind()),
-          data_or_null(p.L_B.vals()), (const int64_t *)data_or_null(p.U_B.col_start()), data_or_null(p.U_B.row_ind()),
-          data_or_null(p.U_B.vals()), (const int64_t *)data_or_null(p.E.col_start()), data_or_null(p.E.row_ind()),
-          data_or_null(p.E.vals()), (int64_t)(p.F.col_start().size() ? p.F.ncols() : 0),
-          (const int64_t *)data_or_null(p.F.col_start()), data_or_null(p.F.row_ind()), data_or_null(p.F.vals()),
-          data_or_null(p.d_B), data_or_null(p.s), data_or_null(p.t), data_or_null(p.p), data_or_null(p.p_inv),
-          data_or_null(p.q), data_or_null(p.q_inv)));
+          widen<W>(data_or_null(p.L_B.vals()), p.L_B.vals().size(), bL), (const int64_t *)data_or_null(p.U_B.col_start()),
+          data_or_null(p.U_B.row_ind()), widen<W>(data_or_null(p.U_B.vals()), p.U_B.vals().size(), bU),
+          (const int64_t *)data_or_null(p.E.col_start()), data_or_null(p.E.row_ind()),
+          widen<W>(data_or_null(p.E.vals()), p.E.vals().size(), bE), (int64_t)(p.F.col_start().size() ? p.F.ncols() : 0),
+          (const int64_t *)data_or_null(p.F.col_start()), data_or_null(p.F.row_ind()),
+          widen<W>(data_or_null(p.F.vals()), p.F.vals().size(), bF), widen<W>(data_or_null(p.d_B), p.d_B.size(), bd),
+          widen<double>(data_or_null(p.s), p.s.size(), bs), widen<double>(data_or_null(p.t), p.t.size(), bt), data_or_null(p.p),
+          data_or_null(p.p_inv), data_or_null(p.q), data_or_null(p.q_inv)));
       if (st != LHF_SUCCESS) return st;
       // the UNFACTORED Schur complement of the last level (Prec::inquire_or_export_dense, Prec.hpp:275-303)
       if (!p.dense_solver.empty()) {
         const auto &mat = p.dense_solver.mat_backup();
+        const W *mp = widen<W>(mat.array().data(), mat.array().size(), bm);
         if (std::strcmp(p.dense_solver.method(), "LUP") == 0)  // a reference built with HIF_DENSE_MODE=0
-          st = from_amd(hifamd_set_dense_lup(g, (int64_t)mat.nrows(), mat.array().data()));
-        else
-          st = from_amd(hifamd_set_dense(g, (int64_t)mat.nrows(), mat.array().data(), h->rrqr_cond));
+          st = from_amd(hifamd_set_dense_lup(g, (int64_t)mat.nrows(), mp));
+        else {
+          // (QRCP.hpp:110-118: without a user threshold the rank test uses eps^(-2/3) of the hierarchy's OWN scalar type)
+          double cond = h->rrqr_cond;
+          if (Wide<V>::single && cond <= 0.0) cond = (double)(float)(1.0 / std::pow((double)FLT_EPSILON, 2. / 3));
+          st = from_amd(hifamd_set_dense(g, (int64_t)mat.nrows(), mp, cond));
+        }
       } else if (!p.symm_dense_solver.empty()) {
         const auto &mat = p.symm_dense_solver.mat_backup();
-        st = from_amd(hifamd_set_dense_symm(g, (int64_t)mat.nrows(), mat.array().data(), 0));
+        st = from_amd(hifamd_set_dense_symm(g, (int64_t)mat.nrows(), widen<W>(mat.array().data(), mat.array().size(), bm), 0));
       }
       if (st != LHF_SUCCESS) return st;
     }
@@ -302,7 +374,7 @@ template <class Hif, class Mat, class V>
 Hif *hif_create(Mat *A, Mat *S, const double params[]) {
   Hif *h = new (std::nothrow) Hif();
   if (!h) return nullptr;
-  h->M = nullptr, h->A = nullptr, h->rrqr_cond = 0.0, h->nrows = 0;
+  h->M = nullptr, h->A = nullptr, h->Aw = nullptr, h->resident = nullptr, h->rrqr_cond = 0.0, h->nrows = 0;
   const LhfStatus st = hif_setup<Hif, Mat, V>(h, A, S, params);
   if (st == LHF_HIFIR_ERROR) {  // (a NULL matrix leaves an empty handle behind, as libhifir.cpp:383-396 does)
     release_gpu(h);
@@ -331,21 +403,11 @@ LhfStatus hif_update(Hif *h, Mat *A) {
   return upload_matrix(h);
 }
 
-// lhf?Apply for nrhs columns (nrhs = 1, ld = 1: the reference's entry point), libhifir.cpp:447-472
+// the device half of lhf?Apply: vectors already in the type the device computes in
 template <class V>
-LhfStatus hif_apply(HifRec<V> *h, LhfOperationType op, const V *B, std::size_t nrhs, std::size_t ldb, int nirs,
-                    const double *betas, int rank, V *X, std::size_t ldx, int *ir_status) {
-  if (!h) return LHF_NULL_OBJ;
-  if (h->gpu.empty()) return fail("MILU-Prec is empty!");
-  if (op != LHF_S && op != LHF_SH && op != LHF_M && op != LHF_MH) return fail("unknown operation tag");
-  const bool prod = (op == LHF_M || op == LHF_MH);
-  const bool refine = !prod && nirs > 1;
-  int64_t rnk = 0;  // the direct solve and the product never see `rank` (libhifir.cpp:459-461 pass no r: numerical rank)
-  if (refine) {
-    if (!h->A) return LHF_NULL_OBJ;
-    if (h->nrows != h->A->n) return LHF_MISMATCHED_SIZES;
-    rnk = rank == LHF_DEFAULT_RANK ? -1 : rank;  // :453-455
-  }
+LhfStatus run_apply(HifRec<V> *h, LhfOperationType op, const typename Wide<V>::type *B, std::size_t nrhs, std::size_t ldb,
+                    bool refine, int nirs, const double *betas, int64_t rnk, typename Wide<V>::type *X, std::size_t ldx,
+                    int *ir_status) {
   int *status = (refine && betas) ? ir_status : nullptr;  // only the bounded variant reports (libhifir.cpp:189-203)
   const std::size_t nd = std::min(h->gpu.size(), nrhs);
   if (nd <= 1)
@@ -374,6 +436,59 @@ LhfStatus hif_apply(HifRec<V> *h, LhfOperationType op, const V *B, std::size_t n
       return (LhfStatus)st[d];
     }
   return LHF_SUCCESS;
+}
+// (vectors of the device's type go straight through; single-precision ones are widened into a dense batch [n][nrhs] on the
+// way in and rounded on the way out)
+template <class V>
+LhfStatus run_apply_any(std::true_type, HifRec<V> *h, LhfOperationType op, const typename Wide<V>::type *B, std::size_t nrhs,
+                        std::size_t ldb, bool refine, int nirs, const double *betas, int64_t rnk, typename Wide<V>::type *X,
+                        std::size_t ldx, int *ir_status) {
+  return run_apply(h, op, B, nrhs, ldb, refine, nirs, betas, rnk, X, ldx, ir_status);
+}
+template <class V, class BV>
+LhfStatus run_apply_any(std::false_type, HifRec<V> *h, LhfOperationType op, const BV *B, std::size_t nrhs, std::size_t ldb,
+                        bool refine, int nirs, const double *betas, int64_t rnk, BV *X, std::size_t ldx, int *ir_status) {
+  typedef typename Wide<V>::type W;
+  const std::size_t n = h->nrows;
+  std::vector<W> Bw(n * nrhs), Xw(n * nrhs);
+  for (std::size_t i = 0; i < n; ++i)
+    for (std::size_t c = 0; c < nrhs; ++c) Bw[i * nrhs + c] = W(B[i * ldb + c]);
+  const LhfStatus st = run_apply(h, op, Bw.data(), nrhs, nrhs, refine, nirs, betas, rnk, Xw.data(), nrhs, ir_status);
+  if (st != LHF_SUCCESS) return st;
+  for (std::size_t i = 0; i < n; ++i)
+    for (std::size_t c = 0; c < nrhs; ++c) X[i * ldx + c] = narrow<BV>(Xw[i * nrhs + c]);
+  return LHF_SUCCESS;
+}
+
+// lhf?Apply for nrhs columns (nrhs = 1, ld = 1: the reference's entry point), libhifir.cpp:447-472
+// BV: the type of the caller's vectors -- V itself, or (lhfsd* / lhfcz*, :1192-1284) the wide type of a single-precision
+// hierarchy
+template <class V, class BV>
+LhfStatus hif_apply(HifRec<V> *h, LhfOperationType op, const BV *B, std::size_t nrhs, std::size_t ldb, int nirs,
+                    const double *betas, int rank, BV *X, std::size_t ldx, int *ir_status) {
+  if (!h) return LHF_NULL_OBJ;
+  if (h->gpu.empty()) return fail("MILU-Prec is empty!");
+  if (op != LHF_S && op != LHF_SH && op != LHF_M && op != LHF_MH) return fail("unknown operation tag");
+  const bool prod = (op == LHF_M || op == LHF_MH);
+  const bool refine = !prod && nirs > 1;
+  int64_t rnk = 0;  // the direct solve and the product never see `rank` (libhifir.cpp:459-461 pass no r: numerical rank)
+  if (Wide<V>::single && h->M && h->M->schur_size() && h->M->schur_rank() < h->M->schur_size())
+    rnk = (int64_t)h->M->schur_rank();  // (the numerical rank the reference's single-precision QRCP found, not the wide one's)
+  if (refine) {
+    // the matrix of the residual: A for vectors of the hierarchy's own type, Ad / Az for the mixed entry points
+    const bool own = std::is_same<BV, V>::value;
+    const std::size_t an = own ? (h->A ? h->A->n : 0) : (h->Aw ? h->Aw->n : 0);
+    const void *want = own ? (const void *)h->A : (const void *)h->Aw;
+    if (!want) return LHF_NULL_OBJ;
+    if (h->nrows != an) return LHF_MISMATCHED_SIZES;
+    if (h->resident != want) {
+      const LhfStatus su = own ? upload_matrix_of(h, h->A) : upload_matrix_of(h, h->Aw);
+      if (su != LHF_SUCCESS) return su;
+    }
+    rnk = rank == LHF_DEFAULT_RANK ? -1 : rank;  // :453-455
+  }
+  return run_apply_any<V>(typename std::is_same<BV, typename Wide<V>::type>::type(), h, op, B, nrhs, ldb, refine, nirs, betas, rnk, X,
+                          ldx, ir_status);
 }
 
 // lhf?ApplyBatchDev: the blocks of an RHS-sharded batch stay in the HBM of their devices (block d on replica d, i.e. on
@@ -464,7 +579,7 @@ Hif *hif_load(const char *path) {
   }
   Hif *h = new (std::nothrow) Hif();
   if (!h) return nullptr;
-  h->M = nullptr, h->A = nullptr, h->rrqr_cond = 0.0, h->nrows = 0;
+  h->M = nullptr, h->A = nullptr, h->Aw = nullptr, h->resident = nullptr, h->rrqr_cond = 0.0, h->nrows = 0;
   std::vector<int> devs = g_devices;
   if (devs.empty()) devs.push_back(-1);
   for (int dev : devs) {
@@ -496,15 +611,8 @@ struct LhfzMatrix : MatrixRec<std::complex<double>> {};
 struct LhfcMatrix : MatrixRec<std::complex<float>> {};
 struct LhfdHif : HifRec<double> {};
 struct LhfzHif : HifRec<std::complex<double>> {};
-struct LhfsHif {  // never instantiated: lhfsCreate / lhfcCreate refuse
-  int unused;
-};
-struct LhfcHif {
-  int unused;
-};
-
-typedef std::complex<double> zdbl;
-typedef std::complex<float> cflt;
+struct LhfsHif : HifRec<float> {};
+struct LhfcHif : HifRec<std::complex<float>> {};
 
 extern "C" {
 
@@ -623,16 +731,16 @@ LHF_MATRIX_API(c, cflt, float _Complex)
   }                                                                                                                   \
   LhfStatus lhf##T##Apply(const Lhf##T##HifHdl hif, const LhfOperationType op, const CV *b, const int nirs,           \
                           const double *betas, const int rank, CV *x, int *ir_status) {                               \
-    return hif_apply<V>(hif, op, (const V *)b, 1, 1, nirs, betas, rank, (V *)x, 1, ir_status);                        \
+    return hif_apply<V, V>(hif, op, (const V *)b, 1, 1, nirs, betas, rank, (V *)x, 1, ir_status);                           \
   }                                                                                                                   \
   LhfStatus lhf##T##Solve(const Lhf##T##HifHdl hif, const CV *b, CV *x) {                                             \
-    return hif_apply<V>(hif, LHF_S, (const V *)b, 1, 1, 1, nullptr, 0, (V *)x, 1, nullptr);                           \
+    return hif_apply<V, V>(hif, LHF_S, (const V *)b, 1, 1, 1, nullptr, 0, (V *)x, 1, nullptr);                              \
   }                                                                                                                   \
   LhfStatus lhf##T##ApplyBatch(const Lhf##T##HifHdl hif, const LhfOperationType op, const CV *B, const size_t nrhs,   \
                                const size_t ldb, const int nirs, const double *betas, const int rank, CV *X,          \
                                const size_t ldx, int *ir_status) {                                                    \
     if (!nrhs || ldb < nrhs || ldx < nrhs) return hif ? LHF_MISMATCHED_SIZES : LHF_NULL_OBJ;                          \
-    return hif_apply<V>(hif, op, (const V *)B, nrhs, ldb, nirs, betas, rank, (V *)X, ldx, ir_status);                 \
+    return hif_apply<V, V>(hif, op, (const V *)B, nrhs, ldb, nirs, betas, rank, (V *)X, ldx, ir_status);                    \
   }                                                                                                                   \
   LhfStatus lhf##T##ApplyBatchDev(const Lhf##T##HifHdl hif, const LhfOperationType op, const int nblocks,             \
                                   const CV *const *B_dev, const size_t *ncols, const size_t *ldb, CV *const *X_dev,   \
@@ -684,51 +792,86 @@ LHF_MATRIX_API(c, cflt, float _Complex)
 LHF_HIF_API(d, double, double)
 LHF_HIF_API(z, zdbl, double _Complex)
 
-// single precision (and the mixed sd / cz entry points that apply a single-precision hierarchy to double vectors,
-// libhifir.cpp:1192-1284): exported so that a libhifir user relinks, refused at run time
-#define LHF_REFUSED_API(T, CV)                                                                                        \
-  Lhf##T##HifHdl lhf##T##Create(const Lhf##T##MatrixHdl, const Lhf##T##MatrixHdl, const double[]) {                   \
-    set_msg(kNoSingle);                                                                                               \
-    return nullptr;                                                                                                   \
+// single precision: the reference's twelve entry points per family (no additive ones), and the mixed sd / cz entry points
+// that apply a single-precision hierarchy to double vectors (libhifir.cpp:1185-1284)
+#define LHF_SINGLE_API(T, V, CV)                                                                                      \
+  Lhf##T##HifHdl lhf##T##Create(const Lhf##T##MatrixHdl A, const Lhf##T##MatrixHdl S, const double params[]) {        \
+    return hif_create<Lhf##T##Hif, Lhf##T##Matrix, V>(A, S, params);                                                  \
   }                                                                                                                   \
-  LhfStatus lhf##T##Destroy(Lhf##T##HifHdl) { return LHF_SUCCESS; }                                                   \
-  LhfStatus lhf##T##Setup(Lhf##T##HifHdl hif, const Lhf##T##MatrixHdl, const Lhf##T##MatrixHdl, const double[]) {     \
-    return hif ? fail(kNoSingle) : LHF_NULL_OBJ;                                                                      \
+  LhfStatus lhf##T##Destroy(Lhf##T##HifHdl hif) { return hif_destroy(hif); }                                          \
+  LhfStatus lhf##T##Setup(Lhf##T##HifHdl hif, const Lhf##T##MatrixHdl A, const Lhf##T##MatrixHdl S,                   \
+                          const double params[]) {                                                                    \
+    return hif_setup<Lhf##T##Hif, Lhf##T##Matrix, V>(hif, A, S, params);                                              \
   }                                                                                                                   \
-  LhfStatus lhf##T##Update(Lhf##T##HifHdl hif, const Lhf##T##MatrixHdl) { return hif ? fail(kNoSingle) : LHF_NULL_OBJ; } \
-  LhfStatus lhf##T##Refactorize(Lhf##T##HifHdl hif, const Lhf##T##MatrixHdl, const double[]) {                        \
-    return hif ? fail(kNoSingle) : LHF_NULL_OBJ;                                                                      \
+  LhfStatus lhf##T##Update(Lhf##T##HifHdl hif, const Lhf##T##MatrixHdl A) { return hif_update(hif, A); }              \
+  LhfStatus lhf##T##Refactorize(Lhf##T##HifHdl hif, const Lhf##T##MatrixHdl S, const double params[]) {               \
+    if (!hif || !S) return LHF_NULL_OBJ;                                                                              \
+    return factorize_and_ship<V>(hif, S, params);                                                                     \
   }                                                                                                                   \
-  LhfStatus lhf##T##Apply(const Lhf##T##HifHdl hif, const LhfOperationType, const CV *, const int, const double *,    \
-                          const int, CV *, int *) {                                                                   \
-    return hif ? fail(kNoSingle) : LHF_NULL_OBJ;                                                                      \
+  LhfStatus lhf##T##Apply(const Lhf##T##HifHdl hif, const LhfOperationType op, const CV *b, const int nirs,           \
+                          const double *betas, const int rank, CV *x, int *ir_status) {                               \
+    return hif_apply<V, V>(hif, op, (const V *)b, 1, 1, nirs, betas, rank, (V *)x, 1, ir_status);                     \
   }                                                                                                                   \
-  LhfStatus lhf##T##Solve(const Lhf##T##HifHdl hif, const CV *, CV *) { return hif ? fail(kNoSingle) : LHF_NULL_OBJ; } \
-  LhfStatus lhf##T##GetStats(const Lhf##T##HifHdl, size_t stats[]) {                                                  \
-    for (int i = 0; i < 9; ++i) stats[i] = 0;                                                                         \
+  LhfStatus lhf##T##Solve(const Lhf##T##HifHdl hif, const CV *b, CV *x) {                                             \
+    return hif_apply<V, V>(hif, LHF_S, (const V *)b, 1, 1, 1, nullptr, 0, (V *)x, 1, nullptr);                        \
+  }                                                                                                                   \
+  LhfStatus lhf##T##GetStats(const Lhf##T##HifHdl hif, size_t stats[]) {                                              \
+    hif_stats<V>(hif, stats);                                                                                         \
     return LHF_SUCCESS;                                                                                               \
   }                                                                                                                   \
-  size_t lhf##T##GetNnz(const Lhf##T##HifHdl) { return 0; }                                                           \
-  size_t lhf##T##GetLevels(const Lhf##T##HifHdl) { return 0; }                                                        \
-  size_t lhf##T##GetSchurSize(const Lhf##T##HifHdl) { return 0; }                                                     \
-  size_t lhf##T##GetSchurRank(const Lhf##T##HifHdl) { return 0; }
+  size_t lhf##T##GetNnz(const Lhf##T##HifHdl hif) {                                                                   \
+    size_t s[9];                                                                                                      \
+    hif_stats<V>(hif, s);                                                                                             \
+    return s[0];                                                                                                      \
+  }                                                                                                                   \
+  size_t lhf##T##GetLevels(const Lhf##T##HifHdl hif) {                                                                \
+    size_t s[9];                                                                                                      \
+    hif_stats<V>(hif, s);                                                                                             \
+    return s[5];                                                                                                      \
+  }                                                                                                                   \
+  size_t lhf##T##GetSchurSize(const Lhf##T##HifHdl hif) {                                                             \
+    size_t s[9];                                                                                                      \
+    hif_stats<V>(hif, s);                                                                                             \
+    return s[8];                                                                                                      \
+  }                                                                                                                   \
+  size_t lhf##T##GetSchurRank(const Lhf##T##HifHdl hif) {                                                             \
+    size_t s[9];                                                                                                      \
+    hif_stats<V>(hif, s);                                                                                             \
+    return s[7];                                                                                                      \
+  }
 
-LHF_REFUSED_API(s, float)
-LHF_REFUSED_API(c, float _Complex)
+LHF_SINGLE_API(s, float, float)
+LHF_SINGLE_API(c, cflt, float _Complex)
 
-LhfStatus lhfsdUpdate(LhfsHifHdl hif, LhfdMatrixHdl) { return hif ? fail(kNoSingle) : LHF_NULL_OBJ; }
-LhfStatus lhfsdApply(const LhfsHifHdl hif, const LhfOperationType, const double *, const int, const double *, const int,
-                     double *, int *) {
-  return hif ? fail(kNoSingle) : LHF_NULL_OBJ;
+// (the double matrix of the mixed entry points is only remembered here, :1185-1190; it reaches the devices when an lhfsd /
+// lhfcz refinement asks for it)
+LhfStatus lhfsdUpdate(LhfsHifHdl hif, LhfdMatrixHdl A) {
+  if (!hif) return LHF_NULL_OBJ;
+  hif->Aw = A;
+  if (hif->resident && hif->resident != (const void *)hif->A) hif->resident = nullptr;
+  if (A && !hif->gpu.empty() && A->n != hif->nrows) return LHF_MISMATCHED_SIZES;
+  return LHF_SUCCESS;
 }
-LhfStatus lhfsdSolve(const LhfsHifHdl hif, const double *, double *) { return hif ? fail(kNoSingle) : LHF_NULL_OBJ; }
-LhfStatus lhfczUpdate(LhfcHifHdl hif, LhfzMatrixHdl) { return hif ? fail(kNoSingle) : LHF_NULL_OBJ; }
-LhfStatus lhfczApply(const LhfcHifHdl hif, const LhfOperationType, const double _Complex *, const int, const double *,
-                     const int, double _Complex *, int *) {
-  return hif ? fail(kNoSingle) : LHF_NULL_OBJ;
+LhfStatus lhfsdApply(const LhfsHifHdl hif, const LhfOperationType op, const double *b, const int nirs, const double *betas,
+                     const int rank, double *x, int *ir_status) {
+  return hif_apply<float, double>(hif, op, b, 1, 1, nirs, betas, rank, x, 1, ir_status);
 }
-LhfStatus lhfczSolve(const LhfcHifHdl hif, const double _Complex *, double _Complex *) {
-  return hif ? fail(kNoSingle) : LHF_NULL_OBJ;
+LhfStatus lhfsdSolve(const LhfsHifHdl hif, const double *b, double *x) {
+  return hif_apply<float, double>(hif, LHF_S, b, 1, 1, 1, nullptr, 0, x, 1, nullptr);
+}
+LhfStatus lhfczUpdate(LhfcHifHdl hif, LhfzMatrixHdl A) {
+  if (!hif) return LHF_NULL_OBJ;
+  hif->Aw = A;
+  if (hif->resident && hif->resident != (const void *)hif->A) hif->resident = nullptr;
+  if (A && !hif->gpu.empty() && A->n != hif->nrows) return LHF_MISMATCHED_SIZES;
+  return LHF_SUCCESS;
+}
+LhfStatus lhfczApply(const LhfcHifHdl hif, const LhfOperationType op, const double _Complex *b, const int nirs,
+                     const double *betas, const int rank, double _Complex *x, int *ir_status) {
+  return hif_apply<cflt, zdbl>(hif, op, (const zdbl *)b, 1, 1, nirs, betas, rank, (zdbl *)x, 1, ir_status);
+}
+LhfStatus lhfczSolve(const LhfcHifHdl hif, const double _Complex *b, double _Complex *x) {
+  return hif_apply<cflt, zdbl>(hif, LHF_S, (const zdbl *)b, 1, 1, 1, nullptr, 0, (zdbl *)x, 1, nullptr);
 }
 
 }  // extern "C"

@@ -14,12 +14,29 @@ LHF_DEFAULT_RANK = -2
 LHF_VERBOSE, LHF_NUMBER_PARAMS = 6, 17  # libhifir.h:94-117
 ROW_MAJOR = 1
 
+# the REAL libhifir: the reference's own libhifir/src/libhifir.cpp compiled where it lies (oracle/Makefile -> oracle/_ref/,
+# git-ignored, travels to the GPU box as a binary).  Test oracle for the entry points the golden fixtures do not cover.
+REF_PATH = os.path.join(ROOT, "oracle", "_ref", "libhifir_ref.so")
+
 _vp, _sz, _int, _dp = C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)
 _lib = None
+_ref = None
 
 
 def available():
     return os.path.exists(SHIM_PATH)
+
+
+def ref_available():
+    return os.path.exists(REF_PATH)
+
+
+def ref_lib():
+    """ctypes binding of the reference's own libhifir (91 symbols, no additive ones): a CHECKER."""
+    global _ref
+    if _ref is None:
+        _ref = _bind(C.CDLL(REF_PATH), additive=False)
+    return _ref
 
 
 def lib():
@@ -28,7 +45,12 @@ def lib():
         import hifir_amd  # noqa: F401  (torch first, then libhifir_amd.so: one HIP runtime per process)
 
         hifir_amd.lib()
-        L = C.CDLL(SHIM_PATH)
+        _lib = _bind(C.CDLL(SHIM_PATH), additive=True)
+    return _lib
+
+
+def _bind(L, additive):
+    if True:  # (one block: the binding is a flat list of signatures)
         L.lhfGetErrorMsg.restype = C.c_char_p
         L.lhfGetErrorMsg.argtypes = []
         L.lhfGetVersions.argtypes = [C.POINTER(_int)]
@@ -36,8 +58,9 @@ def lib():
             getattr(L, f).argtypes = [_dp]
         for f in ("lhfSetDroptol", "lhfSetAlpha", "lhfSetKappa"):
             getattr(L, f).argtypes = [C.c_double, _dp]
-        L.lhfSetDevices.argtypes = [C.POINTER(_int), _int]
-        L.lhfGetDeviceCount.restype = _int
+        if additive:
+            L.lhfSetDevices.argtypes = [C.POINTER(_int), _int]
+            L.lhfGetDeviceCount.restype = _int
         for t in "dszc":
             g = lambda name: getattr(L, f"lhf{t}{name}")
             g("CreateMatrix").restype = _vp
@@ -59,7 +82,7 @@ def lib():
             for q in ("GetNnz", "GetLevels", "GetSchurSize", "GetSchurRank"):
                 g(q).restype = _sz
                 g(q).argtypes = [_vp]
-        for t in "dz":
+        for t in ("dz" if additive else ""):
             g = lambda name: getattr(L, f"lhf{t}{name}")
             g("ApplyBatch").argtypes = [_vp, _int, _vp, _sz, _sz, _int, _dp, _int, _vp, _sz, C.POINTER(_int)]
             g("ApplyBatchDev").argtypes = [_vp, _int, _int, _vp, C.POINTER(_sz), C.POINTER(_sz), _vp, C.POINTER(_sz)]
@@ -75,8 +98,7 @@ def lib():
             getattr(L, f).argtypes = [_vp, _int, _vp, _int, _dp, _int, _vp, C.POINTER(_int)]
         for f in ("lhfsdSolve", "lhfczSolve"):
             getattr(L, f).argtypes = [_vp, _vp, _vp]
-        _lib = L
-    return _lib
+    return L
 
 
 def errmsg():
@@ -98,33 +120,51 @@ def _ptr(a):
 class Matrix:
     """lhf?CreateMatrix: the handle ALIASES the arrays (libhifir.cpp:316-321), so they are kept alive here."""
 
-    def __init__(self, t, indptr, indices, vals, rowmajor=True):
+    def __init__(self, t, indptr, indices, vals, rowmajor=True, L=None):
         self.t = t
+        self.L = L or lib()
         dt = {"d": np.float64, "z": np.complex128, "s": np.float32, "c": np.complex64}[t]
         self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
         self.indices = np.ascontiguousarray(indices, dtype=np.int32)
         self.vals = np.ascontiguousarray(vals, dtype=dt)
         self.n = len(self.indptr) - 1
-        self.h = getattr(lib(), f"lhf{t}CreateMatrix")(int(rowmajor), self.n, _ptr(self.indptr), _ptr(self.indices),
+        self.h = getattr(self.L, f"lhf{t}CreateMatrix")(int(rowmajor), self.n, _ptr(self.indptr), _ptr(self.indices),
                                                         _ptr(self.vals))
         assert self.h
 
     def close(self):
         if self.h:
-            getattr(lib(), f"lhf{self.t}DestroyMatrix")(self.h)
+            getattr(self.L, f"lhf{self.t}DestroyMatrix")(self.h)
             self.h = None
 
 
 class Hif:
-    def __init__(self, t, A=None, S=None, params=None, handle=None):
+    def __init__(self, t, A=None, S=None, params=None, handle=None, L=None):
         self.t = t
-        self.dt = np.float64 if t == "d" else np.complex128
+        self.L = L or lib()
+        self.dt = {"d": np.float64, "z": np.complex128, "s": np.float32, "c": np.complex64}[t]
         self.A = A
-        self.h = handle if handle is not None else getattr(lib(), f"lhf{t}Create")(
+        self.h = handle if handle is not None else getattr(self.L, f"lhf{t}Create")(
             A.h if A else None, S.h if S else None, params)
 
     def _f(self, name):
-        return getattr(lib(), f"lhf{self.t}{name}")
+        return getattr(self.L, f"lhf{self.t}{name}")
+
+    # the mixed entry points of a single-precision handle (libhifir.cpp:1185-1284): double vectors, double matrix
+    def mixed(self, name):
+        return getattr(self.L, "lhf%s%s" % ({"s": "sd", "c": "cz"}[self.t], name))
+
+    def mixed_solve(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float64 if self.t == "s" else np.complex128)
+        x = np.empty_like(b)
+        return self.mixed("Solve")(self.h, _ptr(b), _ptr(x)), x
+
+    def mixed_apply(self, op, b, nirs=1, betas=None, rank=LHF_DEFAULT_RANK):
+        b = np.ascontiguousarray(b, dtype=np.float64 if self.t == "s" else np.complex128)
+        x = np.empty_like(b)
+        bt = None if betas is None else (C.c_double * 2)(*betas)
+        irs = (C.c_int * 2)(-7, -7)
+        return self.mixed("Apply")(self.h, op, _ptr(b), nirs, bt, rank, _ptr(x), irs), x
 
     def solve(self, b):
         b = np.ascontiguousarray(b, dtype=self.dt)

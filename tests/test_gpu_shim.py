@@ -238,17 +238,42 @@ def test_apply_batch_dev_blocks_stay_in_hbm(case, request):
         assert L.lhfSetDevices(None, 0) == su.LHF_SUCCESS
 
 
-def test_single_precision_families_refuse(real_case):
+def test_apply_batch_dev_across_two_devices(real_case):
+    # The same flow with the replicas on TWO devices: the blocks live in each device's own memory, the gather crosses
+    # devices (do_copy_columns checks / enables peer access).  Skipped on a one-GPU box -- which is every box of this
+    # pool so far: the cross-device copy has never executed.
+    torch = pytest.importorskip("torch")
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices")
     levels, d, A, M = real_case
     L = su.lib()
-    As = su.Matrix("s", d["A_indptr"], d["A_indices"], d["A_vals"])
-    assert L.lhfsCreate(As.h, None, su.default_params()) is None and "single-precision" in su.errmsg()
-    fake = C.c_void_p(1)  # any non-NULL handle: the entry points refuse before touching it
-    b = np.zeros(A.n)
-    assert L.lhfsdSolve(fake, su._ptr(b), su._ptr(b.copy())) == su.LHF_HIFIR_ERROR and "single-precision" in su.errmsg()
-    assert L.lhfsdApply(fake, su.LHF_S, su._ptr(b), 1, None, -2, su._ptr(b.copy()), None) == su.LHF_HIFIR_ERROR
-    assert su.errmsg() and su.errmsg() is None
-    As.close()
+    st, X, _ = M.apply_batch(su.LHF_S, d["B4"])
+    assert st == 0
+    ids = (C.c_int * 2)(0, 1)
+    assert L.lhfSetDevices(ids, 2) == su.LHF_SUCCESS
+    try:
+        M3 = su.Hif("d", A, None, su.default_params())
+        assert M3.h, su.errmsg()
+        B = np.ascontiguousarray(d["B4"])
+        n = B.shape[0]
+        blocks = [np.ascontiguousarray(B[:, :3]), np.ascontiguousarray(B[:, 3:])]
+        Bd = [torch.from_numpy(b).to(f"cuda:{k}") for k, b in enumerate(blocks)]
+        Xd = [torch.empty_like(b) for b in Bd]
+        ncols = (C.c_size_t * 2)(3, 1)
+        Bp = (C.c_void_p * 2)(*[b.data_ptr() for b in Bd])
+        Xp = (C.c_void_p * 2)(*[x.data_ptr() for x in Xd])
+        assert L.lhfdApplyBatchDev(M3.h, su.LHF_S, 2, Bp, ncols, ncols, Xp, ncols) == su.LHF_SUCCESS, su.errmsg()
+        G = torch.zeros((n, 4), dtype=Bd[0].dtype, device="cuda:0")
+        for k in range(2):
+            torch.cuda.synchronize(k)
+        assert L.lhfdGatherBatchDev(M3.h, 2, Xp, ncols, ncols, C.c_void_p(G.data_ptr()), 4) == su.LHF_SUCCESS, su.errmsg()
+        assert L.lhfdSyncDevices(M3.h) == su.LHF_SUCCESS
+        assert np.array_equal(G.cpu().numpy(), X)
+        st, X3, _ = M3.apply_batch(su.LHF_S, d["B4"])  # host batch split over the two devices
+        assert st == 0 and np.array_equal(X3, X)
+        M3.close()
+    finally:
+        assert L.lhfSetDevices(None, 0) == su.LHF_SUCCESS
 
 
 def test_handle_finalized_for_a_narrow_batch_gives_the_same_bits(real_case, monkeypatch):

@@ -58,10 +58,14 @@ def test_versions_params_and_error_message():
     assert (p[0], p[1], p[4], p[5], p[2], p[3]) == (1e-2, 1e-2, 3.0, 3.0, 5.0, 5.0)
     L.lhfEnableWarning(), L.lhfDisableWarning()  # declared by the reference, defined nowhere there: no-ops here
     assert su.errmsg() is None
-    assert L.lhfsCreate(None, None, p) is None  # single precision is refused ...
+    h = L.lhfsCreate(None, None, p)  # a NULL matrix leaves an EMPTY handle behind (libhifir.cpp:383-396), every family
+    assert h
+    x = np.zeros(3, dtype=np.float32)
+    assert L.lhfsSolve(h, su._ptr(x), su._ptr(x.copy())) == su.LHF_HIFIR_ERROR  # ... which cannot solve ...
     m = su.errmsg()
-    assert m and "single-precision" in m  # ... with a message
+    assert m and "empty" in m  # ... and says why
     assert su.errmsg() is None  # returned once, then cleared (libhifir.cpp:224-229)
+    assert L.lhfsDestroy(h) == su.LHF_SUCCESS
 
 
 def test_matrix_handles_alias_and_null_safety():
