@@ -434,6 +434,11 @@ class Engine : public EngineBase {
   int top_gemm = 4;      // top / tail operator product: 4 k_top_gemm (64-row tiles, panel through LDS, K splits); 1 k_strip_gemm_d<4>,
                          // 2 k_strip_gemm4_d<2>, 3 k_strip_gemm4_d<4> (HIFIR_AMD_TOP_GEMM)
   DevBuf gemm_part;      // partial tiles of the K splits of k_top_gemm
+  DevBuf gemm_cnt;       // ... and one arrival counter per 64-row tile (the last split to arrive adds them: no k_top_reduce launch)
+  // HIFIR_AMD_TOP_LAST=1 (round 4, measured, OFF): the K splits summed inside k_top_gemm by the last split to arrive -- nine
+  // launches fewer, same bits, but the agent-scope release / acquire fences write back and invalidate a whole L2 per
+  // workgroup: k_top_gemm 40 -> 147 us, the apply 3.67 -> 4.61 ms
+  int top_last_arriver = 0;
   int cd_dbg = 0;        // development aid (HIFIR_AMD_CD_DBG): phases of k_band_cd switched off for timing experiments
   // Column-sliced component bands (kernels.hip.hpp k_band_cs): a component band of at most cs_max_wgs workgroups is cut
   // into 16-column slices (the heaviest component of a narrow band then runs on four compute units); a batch of fewer
@@ -513,6 +518,7 @@ class Engine : public EngineBase {
     ct_mode_z = env_int("HIFIR_AMD_CT_Z", 0);
     ct_mode_real = env_int("HIFIR_AMD_CT_REAL", 1);
     skip_rows = env_int("HIFIR_AMD_SKIP_ROWS", 3);
+    top_last_arriver = env_int("HIFIR_AMD_TOP_LAST", 0);
     list_early = env_int("HIFIR_AMD_LIST_EARLY", 0);
     spmm_rb = env_int("HIFIR_AMD_SPMM_RB", 1) == 2 ? 2 : 1;
     spmm_tiles_z = env_int("HIFIR_AMD_SPMM_TILES_Z", 1);
@@ -828,6 +834,11 @@ class Engine : public EngineBase {
         zero_dev(E->blk_tmp.p, E->blk_tmp.bytes);
       }
       if (gemm_part.bytes) E->gemm_part.alloc(gemm_part.bytes);
+      if (gemm_cnt.bytes) {
+        E->gemm_cnt.alloc(gemm_cnt.bytes);
+        zero_dev(E->gemm_cnt.p, E->gemm_cnt.bytes);
+      }
+      E->top_last_arriver = top_last_arriver;
       if (zt1.bytes) {
         E->zt1.alloc(zt1.bytes);
         E->zt2.alloc(zt2.bytes);
@@ -1259,6 +1270,8 @@ class Engine : public EngineBase {
       HIP_OK(hipStreamSynchronize(xfer_stream()));
     }
     if (top_rows_max > 0) gemm_part.alloc((size_t)kTopGemmSplits * (size_t)((top_rows_max + 63) / 64 * 64) * 64 * sizeof(double));
+    gemm_cnt.alloc(kTopGemmTilesMax * sizeof(unsigned));  // (tops and tails have at most top_max / tail_rows <= 64 x this many rows)
+    zero_dev(gemm_cnt.p, gemm_cnt.bytes);
     if (band_opt.dense_block > 0) {  // +32 rows: the MFMA kernel reads whole 32-k operand sets (masked)
       blk_tmp.alloc((size_t)(std::max<int64_t>(band_opt.dense_block, top_rows_max) + 32) * Rmax * sizeof(T));
       zero_dev(blk_tmp.p, blk_tmp.bytes);
@@ -1564,6 +1577,7 @@ class Engine : public EngineBase {
   // of workgroups fills the chip; the splits' partial tiles are added in order by k_top_reduce
   static constexpr size_t kTopGemmLds = 2 * 64 * 80 * sizeof(double);
   static constexpr int kTopGemmSplits = 8;
+  static constexpr int kTopGemmTilesMax = 4096;  // arrival counters of the last-arriver reduction (rows / 64)
   void launch_top_gemm(hipStream_t st, int nt, const double *G, const double *X, const int32_t *rowmap, double *Out,
                        int64_t &count) {
     const int lda = (int)round_up32(nt);
@@ -1578,10 +1592,11 @@ class Engine : public EngineBase {
       kper = (int)((lda + 63) / 64 * 64);
     }
     auto kern = nct == 1 ? k_top_gemm<1> : (nct == 2 ? k_top_gemm<2> : (nct == 3 ? k_top_gemm<3> : k_top_gemm<4>));
+    const bool fused_sum = top_last_arriver && nks > 1 && tiles <= kTopGemmTilesMax && gemm_cnt.p;
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)nks), dim3(1024), kTopGemmLds, st, nt, nt, kper, G, lda, X, rowmap,
-                       Out, gemm_part.as<double>(), pad);
+                       Out, gemm_part.as<double>(), pad, fused_sum ? gemm_cnt.as<unsigned>() : (unsigned *)nullptr);
     ++count;
-    if (nks > 1) {
+    if (nks > 1 && !fused_sum) {
       hipLaunchKernelGGL(k_top_reduce, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, st, nt, nks,
                          (const double *)gemm_part.as<double>(), pad, rowmap, Out, nct);
       ++count;

@@ -2160,7 +2160,11 @@ template <int NCT>
 __global__ void __launch_bounds__(1024) k_top_gemm(int nrows, int kvalid, int kper /* K range per split, multiple of 64 */,
                                                    const double *__restrict__ A, int lda, const double *__restrict__ X,
                                                    const int32_t *__restrict__ rowmap, double *__restrict__ Out,
-                                                   double *__restrict__ part, int nrows_pad) {
+                                                   double *__restrict__ part, int nrows_pad, unsigned *tile_cnt) {
+  // tile_cnt (round 4; NULL: the splits are added by k_top_reduce, a launch of its own): one counter per 64-row tile, zero
+  // between launches.  The workgroup that finds its tile's other K splits already counted adds the gridDim.y partial tiles
+  // in split order -- the order k_top_reduce uses: the same bits, replays stay bit-stable whichever split arrives last --
+  // and writes the rows out; release / acquire fences at agent scope carry the partials across the XCDs' L2s.
   constexpr int nct = NCT;
   constexpr int XS = 80;               // LDS row stride of the panel (doubles)
   extern __shared__ double tg_lds[];   // two chunks of 64 panel rows: 2 x 64 x 80 doubles = 80 KB; reused for the reduction
@@ -2249,15 +2253,39 @@ __global__ void __launch_bounds__(1024) k_top_gemm(int nrows, int kvalid, int kp
     }
     __syncthreads();
   }
-  if (jq != 0 || !live) return;
+  if (jq == 0 && live) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = 16 * strip + kq + 4 * r;
-    if (row >= nrows) continue;
-    double *dst = (gridDim.y > 1) ? part + (((int64_t)ksp * nrows_pad + row) << 6) : Out + ((int64_t)(rowmap ? rowmap[row] : row) << 6);
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * strip + kq + 4 * r;
+      if (row >= nrows) continue;
+      double *dst = (gridDim.y > 1) ? part + (((int64_t)ksp * nrows_pad + row) << 6) : Out + ((int64_t)(rowmap ? rowmap[row] : row) << 6);
 #pragma unroll
-    for (int t = 0; t < NCT; ++t) dst[16 * t + cl] = acc[t][r];
+      for (int t = 0; t < NCT; ++t) dst[16 * t + cl] = acc[t][r];
+    }
   }
+  if (gridDim.y == 1 || tile_cnt == nullptr) return;
+  // ---- the last split of this tile to arrive adds the partial tiles (fixed order) and writes the rows out
+  __shared__ int tg_last;
+  __threadfence();  // (release: this workgroup's partial tile)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned seen = atomicAdd(&tile_cnt[tile], 1u);
+    tg_last = (seen == gridDim.y - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!tg_last) return;
+  __threadfence();  // (acquire: the other splits' partial tiles)
+  {
+    const int row = 64 * tile + (int)(threadIdx.x >> 4), c4 = (int)(threadIdx.x & 15) * 4;  // 64 rows x 16 groups of 4 columns
+    if (row < nrows && c4 < 16 * nct) {
+      typedef double v4d __attribute__((ext_vector_type(4)));
+      const double *pp = part + ((int64_t)row << 6) + c4;
+      v4d sacc = *reinterpret_cast<const v4d *>(pp);
+      for (int q = 1; q < (int)gridDim.y; ++q) sacc += *reinterpret_cast<const v4d *>(pp + (((int64_t)q * nrows_pad) << 6));
+      *reinterpret_cast<v4d *>(Out + ((int64_t)(rowmap ? rowmap[row] : row) << 6) + c4) = sacc;
+    }
+  }
+  if (threadIdx.x == 0) tile_cnt[tile] = 0u;  // (ready for the next launch: kernel boundaries order it)
 }
 
 // the K splits of k_top_gemm, added in order

@@ -30,7 +30,8 @@ MODES = {
     "R64-fast-walk-real-tiles-complex": (6, 2048, {"HIFIR_AMD_CT": "1", "HIFIR_AMD_CT_Z": "1", "HIFIR_AMD_CT_REAL": "0"}),
     # ... with S7 of the child's rows on a side stream beside the second solve (off by default: measured slower), sparse-own
     # components everywhere so that the first solve's row flags are in force as well
-    "R64-fast-early-list": (6, 2048, {"HIFIR_AMD_LIST_EARLY": "1", "HIFIR_AMD_CD_SPARSE_MIN_ROWS": "0"}),
+    # (+ the K splits of the operator products summed by the last split to arrive, also off by default)
+    "R64-fast-early-list": (6, 2048, {"HIFIR_AMD_LIST_EARLY": "1", "HIFIR_AMD_CD_SPARSE_MIN_ROWS": "0", "HIFIR_AMD_TOP_LAST": "1"}),
 }
 
 
