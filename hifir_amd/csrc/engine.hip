@@ -456,6 +456,7 @@ class Engine : public EngineBase {
   int cs_max_wgs = 0;    // HIFIR_AMD_CS_MAX_WGS (full batches: measured equal to k_band_cd at every band width)
   int ct_wide_wgs = 128; // HIFIR_AMD_CT_WIDE: a component band with more workgroups than this takes two column tiles per workgroup
   int ct_wide4_wgs = 1 << 30;  // HIFIR_AMD_CT_WIDE4: ... and with more than this all four (one workgroup per component)
+  int narrow_tiles = 1;  // HIFIR_AMD_NARROW_TILES=0: the tiled Schur products always multiply all four column tiles
   int skip_rows = 3;  // HIFIR_AMD_SKIP_ROWS: bit 0 L rows / bit 1 U rows a level's first solve does not store (build_row_flags); 0: every row
   int ct_mode_real = 1;  // HIFIR_AMD_CT_REAL=0: real handles keep the entry walk while HIFIR_AMD_CT_Z stays as set (tests)
   int ct_mode_z = 0;     // HIFIR_AMD_CT_Z=1: complex component bands on coefficient tiles too (k_band_ct_z; measured SLOWER than the
@@ -518,6 +519,7 @@ class Engine : public EngineBase {
     ct_mode_z = env_int("HIFIR_AMD_CT_Z", 0);
     ct_mode_real = env_int("HIFIR_AMD_CT_REAL", 1);
     skip_rows = env_int("HIFIR_AMD_SKIP_ROWS", 3);
+    narrow_tiles = env_int("HIFIR_AMD_NARROW_TILES", 1);
     top_last_arriver = env_int("HIFIR_AMD_TOP_LAST", 0);
     list_early = env_int("HIFIR_AMD_LIST_EARLY", 0);
     spmm_rb = env_int("HIFIR_AMD_SPMM_RB", 1) == 2 ? 2 : 1;
@@ -699,6 +701,7 @@ class Engine : public EngineBase {
       E->ct_mode_z = ct_mode_z;
       E->ct_mode_real = ct_mode_real;
       E->skip_rows = skip_rows;
+      E->narrow_tiles = narrow_tiles;
       E->list_early = list_early;
       E->spmm_rb = spmm_rb;
       E->spmm_tiles_z = spmm_tiles_z;
@@ -770,6 +773,7 @@ class Engine : public EngineBase {
       E->ct_mode_z = ct_mode_z;
       E->ct_mode_real = ct_mode_real;
       E->skip_rows = skip_rows;
+      E->narrow_tiles = narrow_tiles;
       E->list_early = list_early;
       E->spmm_rb = spmm_rb;
       E->spmm_tiles_z = spmm_tiles_z;
@@ -1854,8 +1858,10 @@ class Engine : public EngineBase {
     if constexpr (std::is_same<T, double>::value) {
       // one block per workgroup, its groups dealt to the four waves: where the per-wave kernel would leave the chip short
       // of waves (with more blocks the product runs at the fabric's gather bandwidth either way: 95 vs 100 us, 101 vs 123 us)
+      const int nct = narrow_tiles ? std::min(4, (act_cols + 15) / 16) : 4;  // column tiles of the batch
       if (A.tl_nblk > 0 && A.tl_nblk < spmm_split_blocks && logR == 6 && spmm_split) {
-        auto k4 = A.tl_rb == 2 ? k_spmm_tile4<2> : k_spmm_tile4<1>;
+        auto k4 = A.tl_rb == 2 ? (nct == 1 ? k_spmm_tile4<2, 1> : nct == 2 ? k_spmm_tile4<2, 2> : nct == 3 ? k_spmm_tile4<2, 3> : k_spmm_tile4<2, 4>)
+                               : (nct == 1 ? k_spmm_tile4<1, 1> : nct == 2 ? k_spmm_tile4<1, 2> : nct == 3 ? k_spmm_tile4<1, 3> : k_spmm_tile4<1, 4>);
         hipLaunchKernelGGL(k4, dim3((unsigned)A.tl_nblk), dim3(256), 0, st, nrows, A.tl_nblk, A.tl_gptr.as<int32_t>(),
                            A.tl_ucol.as<int32_t>(), A.tl_coef.as<double>(), (const double *)x, bin, ldb, nrhs, L.p.as<int32_t>(),
                            L.s.as<double>(), roff, out);
@@ -1863,7 +1869,8 @@ class Engine : public EngineBase {
       }
       if (A.tl_nblk > 0 && logR == 6) {
         const unsigned grid = (unsigned)std::min<int64_t>((A.tl_nblk + 3) / 4, 256 * 16);
-        auto k1 = A.tl_rb == 2 ? k_spmm_tile<2> : k_spmm_tile<1>;
+        auto k1 = A.tl_rb == 2 ? (nct == 1 ? k_spmm_tile<2, 1> : nct == 2 ? k_spmm_tile<2, 2> : nct == 3 ? k_spmm_tile<2, 3> : k_spmm_tile<2, 4>)
+                               : (nct == 1 ? k_spmm_tile<1, 1> : nct == 2 ? k_spmm_tile<1, 2> : nct == 3 ? k_spmm_tile<1, 3> : k_spmm_tile<1, 4>);
         hipLaunchKernelGGL(k1, dim3(grid), dim3(256), 0, st, nrows, A.tl_nblk, A.tl_gptr.as<int32_t>(),
                            A.tl_ucol.as<int32_t>(), A.tl_coef.as<double>(), (const double *)x, bin, ldb, nrhs, L.p.as<int32_t>(),
                            L.s.as<double>(), roff, out);

@@ -1155,14 +1155,16 @@ __global__ void __launch_bounds__(256) k_spmm_epi_narrow(int64_t nrows, const in
 // 16-column tiles (lane l fetches x[ucol[4g + (l >> 4)]][16 ct + (l & 15)]), four MFMAs.  Two groups in flight.
 // Every distinct source row of a block is fetched once, not once per nonzero.  R = 64, real data, fast mode.
 // ---------------------------------------------------------------------------------------------
-template <int RB>
+template <int RB, int NCT>
 __global__ void __launch_bounds__(256) k_spmm_tile(int64_t nrows, int64_t nblk, const int32_t *__restrict__ blk_gptr,
                                                    const int32_t *__restrict__ ucol, const double *__restrict__ coef,
                                                    const double *__restrict__ x, IoPtr<const double> bin_, int64_t ldb,
                                                    int nrhs, const int32_t *__restrict__ p, const double *__restrict__ s,
                                                    int64_t roff, double *__restrict__ out) {
   // RB row tiles of 16 rows per block (host.hpp SpmmTiles::rb): a block's distinct columns are gathered ONCE for all of
-  // them -- the product runs at the fabric's gather rate, and 32-row blocks gather a quarter less than 16-row blocks
+  // them -- the product runs at the fabric's gather rate, and 32-row blocks gather a quarter less than 16-row blocks.
+  // NCT: 16-column tiles of the batch in use (round 4: a batch of <= 16 columns gathers 128 of a source row's 512 bytes
+  // and multiplies one tile per group; per column the arithmetic is the same whatever NCT: same bits at every width)
   const double *__restrict__ bin = bin_.get();
   const int lane = threadIdx.x & 63;
   const int kq = lane >> 4, jc = lane & 15;
@@ -1170,22 +1172,22 @@ __global__ void __launch_bounds__(256) k_spmm_tile(int64_t nrows, int64_t nblk, 
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t b = wave; b < nblk; b += nwaves) {
     const int32_t g0 = rfl(blk_gptr[b]), g1 = rfl(blk_gptr[b + 1]);
-    v4f64 acc[RB][4];
+    v4f64 acc[RB][NCT];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) acc[rb][ct] = v4f64{0.0, 0.0, 0.0, 0.0};
+      for (int ct = 0; ct < NCT; ++ct) acc[rb][ct] = v4f64{0.0, 0.0, 0.0, 0.0};
     // Software pipeline over the groups, all loads unconditional (indices clamped to the block's last group, whose
     // coefficient is then zeroed): source-row indices run 7 groups ahead, coefficient + B fragments 3 groups ahead of the
     // MFMAs -- the compiler counts its waits exactly, nothing but the oldest group is ever waited for.
     if (g0 < g1) {
       const int32_t gl = g1 - 1;
       int32_t src[8];
-      double av[4][RB], bv[4][4];
+      double av[4][RB], bv[4][NCT];
 #define HIFAMD_TL_SRC(slot, g) src[slot] = ucol[4 * (int64_t)min((g), gl) + kq];
 #define HIFAMD_TL_LOAD(slot, sslot, g)                                                                               \
   _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) av[slot][rb] = coef[64 * (RB * (int64_t)min((g), gl) + rb) + lane]; \
-  _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) bv[slot][ct] = x[((int64_t)src[sslot] << 6) + 16 * ct + jc];
+  _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct) bv[slot][ct] = x[((int64_t)src[sslot] << 6) + 16 * ct + jc];
 #pragma unroll
       for (int q = 0; q < 7; ++q) { HIFAMD_TL_SRC(q, g0 + q) }
 #pragma unroll
@@ -1200,7 +1202,7 @@ __global__ void __launch_bounds__(256) k_spmm_tile(int64_t nrows, int64_t nblk, 
           for (int rb = 0; rb < RB; ++rb) {
             const double am = cur < g1 ? av[dd & 3][rb] : 0.0;
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[rb][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bv[dd & 3][ct], acc[rb][ct], 0, 0, 0);
+            for (int ct = 0; ct < NCT; ++ct) acc[rb][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bv[dd & 3][ct], acc[rb][ct], 0, 0, 0);
           }
         }
       }
@@ -1217,7 +1219,7 @@ __global__ void __launch_bounds__(256) k_spmm_tile(int64_t nrows, int64_t nblk, 
           const int32_t srow = p[roff + i];
           const double sc = s[srow];
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) {
+          for (int ct = 0; ct < NCT; ++ct) {
             const int c = 16 * ct + jc;
             const double rhs = c < nrhs ? sc * bin[(int64_t)srow * ldb + c] : 0.0;
             out[(i << 6) + c] = rhs - acc[rb][ct][r];
@@ -1233,13 +1235,13 @@ __global__ void __launch_bounds__(256) k_spmm_tile(int64_t nrows, int64_t nblk, 
 // on average, 188 at most, 1,987 blocks of 16 rows -- fewer waves than the chip holds, and the launch lasts as long as
 // the longest chain): four waves per block cut every chain to a quarter and quadruple the gathers in flight.  Partial
 // tiles meet in LDS; wave w finishes column tile w of the block (fixed order: deterministic).
-template <int RB>
+template <int RB, int NCT>
 __global__ void __launch_bounds__(256) k_spmm_tile4(int64_t nrows, int64_t nblk, const int32_t *__restrict__ blk_gptr,
                                                     const int32_t *__restrict__ ucol, const double *__restrict__ coef,
                                                     const double *__restrict__ x, IoPtr<const double> bin_, int64_t ldb,
                                                     int nrhs, const int32_t *__restrict__ p, const double *__restrict__ s,
                                                     int64_t roff, double *__restrict__ out) {
-  __shared__ double red[4][4][4][64];  // [wave][tile][reg][lane], 32 KB (one row tile at a time)
+  __shared__ double red[4][NCT][4][64];  // [wave][tile][reg][lane], 8 KB per column tile (one row tile at a time)
   const double *__restrict__ bin = bin_.get();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1247,23 +1249,23 @@ __global__ void __launch_bounds__(256) k_spmm_tile4(int64_t nrows, int64_t nblk,
   const int64_t b = (int64_t)xcd_block();
   if (b >= nblk) return;
   const int32_t g0 = rfl(blk_gptr[b]), g1 = rfl(blk_gptr[b + 1]);
-  v4f64 acc[RB][4];
+  v4f64 acc[RB][NCT];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) acc[rb][ct] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int ct = 0; ct < NCT; ++ct) acc[rb][ct] = v4f64{0.0, 0.0, 0.0, 0.0};
   // this wave's groups: g0 + wave + 4 k, k = 0 .. ng - 1; same software pipeline as k_spmm_tile (loads unconditional,
   // indices clamped to the wave's last group, whose coefficient is then zeroed)
   const int32_t ng = (g1 - g0 > wave) ? (g1 - g0 - wave + 3) / 4 : 0;
   if (ng > 0) {
     const int32_t kl = ng - 1;
     int32_t src[8];
-    double av[4][RB], bv[4][4];
+    double av[4][RB], bv[4][NCT];
 #define HIFAMD_TL_GID(k) (g0 + wave + 4 * min((k), kl))
 #define HIFAMD_TL_SRC(slot, k) src[slot] = ucol[4 * (int64_t)HIFAMD_TL_GID(k) + kq];
 #define HIFAMD_TL_LOAD(slot, sslot, k)                                                                                \
   _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) av[slot][rb] = coef[64 * (RB * (int64_t)HIFAMD_TL_GID(k) + rb) + lane]; \
-  _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) bv[slot][ct] = x[((int64_t)src[sslot] << 6) + 16 * ct + jc];
+  _Pragma("unroll") for (int ct = 0; ct < NCT; ++ct) bv[slot][ct] = x[((int64_t)src[sslot] << 6) + 16 * ct + jc];
 #pragma unroll
     for (int q = 0; q < 7; ++q) { HIFAMD_TL_SRC(q, q) }
 #pragma unroll
@@ -1278,7 +1280,7 @@ __global__ void __launch_bounds__(256) k_spmm_tile4(int64_t nrows, int64_t nblk,
         for (int rb = 0; rb < RB; ++rb) {
           const double am = cur < ng ? av[dd & 3][rb] : 0.0;
 #pragma unroll
-          for (int ct = 0; ct < 4; ++ct) acc[rb][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bv[dd & 3][ct], acc[rb][ct], 0, 0, 0);
+          for (int ct = 0; ct < NCT; ++ct) acc[rb][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bv[dd & 3][ct], acc[rb][ct], 0, 0, 0);
         }
       }
     }
@@ -1291,11 +1293,12 @@ __global__ void __launch_bounds__(256) k_spmm_tile4(int64_t nrows, int64_t nblk,
   for (int rb = 0; rb < RB; ++rb) {
     if (rb) __syncthreads();  // (the previous row tile's partials have been read)
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[wave][ct][r][lane] = acc[rb][ct][r];
     __syncthreads();
     // epilogue of column tile `wave`: C layout col = l & 15, row = (l >> 4) + 4 * reg
+    if (wave >= NCT) continue;  // (a narrow batch: fewer column tiles than waves)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t i = 16 * (RB * b + rb) + kq + 4 * r;
