@@ -661,8 +661,10 @@ class Engine : public EngineBase {
     else
       analyze_level(H, band_opt, env_int("HIFIR_AMD_PLAN_DUMP", 0) != 0, li);
     analysis_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_an0).count();
+    seal_level(H);  // (what finalize must find again: import.hpp verify_level)
     host.levels.push_back(std::move(H));
   }
+  int64_t host_repairs = 0;  // arrays of the host copy that verify_level found changed and rebuilt (hifamd_stats_ext slot 21)
   std::vector<LevelAnalysis<T>> cached_analysis;  // (alive during hifamd_load only)
   int64_t levels_from_cache = 0;
   double analysis_seconds = 0.0;  // host seconds spent analyzing (or adopting the analysis of) the levels
@@ -671,6 +673,7 @@ class Engine : public EngineBase {
   void add_level_adjoint(const HostLevel<T> &P) {
     HostLevel<T> H = adjoint_level(P);
     analyze_level(H, band_opt, env_int("HIFIR_AMD_PLAN_DUMP", 0) != 0, host.levels.size());
+    seal_level(H);
     host.levels.push_back(std::move(H));
   }
 
@@ -1108,6 +1111,7 @@ class Engine : public EngineBase {
       std::fprintf(stderr, "FINALIZE level=%zu %-28s %.3f s\n", level, what, t - ft);
       ft = t;
     };
+    for (size_t l = 0; l < host.levels.size(); ++l) host_repairs += verify_level(host.levels[l], l, adjoint);
     for (size_t l = 0; l < host.levels.size(); ++l) check_level_invariants(host.levels[l], l, adjoint, &band_opt);
     tick("invariants (all levels)", 0);
     bind_device();
@@ -2778,7 +2782,7 @@ class Engine : public EngineBase {
     const double v[] = {finalize_seconds, capture_ms,     bytes_inverses,  bytes_top,     bytes_tail,           (double)tail_n,
                         (double)tail_level, tail_probe_err, tail_max_abs, (double)tail_rejected, tail_probe_tol, tail_max_growth,
                         (double)levels_from_cache, analysis_seconds, arena, (double)Rmax, tiles, factors, (double)max_nrhs,
-                        skip_w, skip_v};
+                        skip_w, skip_v, (double)host_repairs};
     const int nv = (int)(sizeof(v) / sizeof(v[0]));
     for (int i = 0; i < cap && i < nv; ++i) o[i] = v[i];
     return nv;

@@ -1587,6 +1587,10 @@ struct HostLevel {
   std::vector<uint8_t> top;         // per row; empty = no combined operator
   int64_t top_n = 0;                // |T|
   int32_t top_bandL = -1, top_bandU = -1;  // the bands of Lp / Up that hold exactly the rows of T
+  // checksums of the arrays above as they stood when the level had been imported and analyzed (import.hpp seal_level /
+  // verify_level): hifamd_finalize tells a host copy that changed in between -- twice in four rounds two row pointers of E
+  // did, cause unshown -- from the one it made, names the array, and rebuilds E / F's row forms from the imported arrays
+  std::vector<uint64_t> sums;
 };
 
 // Dense last level: A P = Q R (GEQP3 semantics), numerical rank as QRCP::factorize decides it

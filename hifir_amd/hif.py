@@ -203,7 +203,7 @@ class HIF:
         keys = ["finalize_s", "graph_capture_ms", "bytes_inverses", "bytes_top", "bytes_tail", "tail_rows", "tail_level",
                 "tail_probe_relerr", "tail_max_abs", "tail_rejected", "tail_probe_tol", "tail_max_growth",
                 "analysis_cached_levels", "analysis_s", "arena_bytes", "arena_cols", "tile_bytes", "factor_bytes", "max_nrhs",
-                "rows_not_stored_L", "rows_not_stored_U"]
+                "rows_not_stored_L", "rows_not_stored_U", "host_copy_repairs"]
         return {key: float(s[i]) for i, key in enumerate(keys[:max(0, k)])}
 
     def level_stats(self, level):

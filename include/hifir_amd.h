@@ -150,7 +150,9 @@ HifAmdStatus hifamd_stats(HifAmdHdl h, double *stats16);
  * fast kernels address a 64-column arena; max_nrhs bounds the batch width a call may pass, not the arena), 16 bytes of
  * the component bands' coefficient tiles, 17 bytes of the factors with their plan arrays, 18 max_nrhs of hifamd_finalize,
  * 19 / 20 rows (all levels) whose L / U result the FIRST solve of a level does not store because nothing reads it from
- * memory (real handles, sparse-own levels; HIFIR_AMD_SKIP_ROWS=0: none).
+ * memory (real handles, sparse-own levels; HIFIR_AMD_SKIP_ROWS=0: none), 21 arrays of the host copy that hifamd_finalize found
+ * changed since hifamd_add_level -- not by this library -- and rebuilt from the imported arrays (a warning names them on stderr;
+ * anything it cannot rebuild is refused).
  * -1 for a NULL handle. */
 int hifamd_stats_ext(HifAmdHdl h, double *out, int cap);
 /* Per-level sizes (what the SURVEY 8(d) byte formula needs level by level): 0 m, 1 n, 2 nnz(L_B), 3 nnz(U_B), 4 nnz(E),

@@ -38,6 +38,7 @@ struct Sink {  // what Engine<T> does on import, without a device
       ++adopted;
     else if (analyze)
       analyze_level(H, opt);
+    seal_level(H);  // (Engine::add_level does)
     host.levels.push_back(std::move(H));
   }
   // (hostile-file runs -- analyze == false -- only care that the block arrives with the right size)
@@ -123,6 +124,7 @@ static int compare(const Sink<T> &A, const Sink<T> &B, const char *what) {
 template <class T>
 static int finalize_host(Sink<T> &S, bool adjoint = false) {
   int bad = 0;
+  for (size_t l = 0; l < S.host.levels.size(); ++l) bad += verify_level(S.host.levels[l], l, adjoint);  // (0: untouched)
   for (size_t l = 0; l < S.host.levels.size(); ++l) check_level_invariants(S.host.levels[l], l, adjoint);
   std::vector<double> ops;
   for (auto &H : S.host.levels)
@@ -149,6 +151,50 @@ static int run_file(const char *path, const std::vector<unsigned char> &bytes, i
   bad += finalize_host(A);
   load_bytes(bytes, B);          // second handle while the first one is alive (the round-1 scenario)
   bad += finalize_host(B);
+  {  // the host copy changed behind the library's back (rounds 1 and 4 met two overwritten row pointers of E): E / F's row
+     // forms are rebuilt from the imported arrays and reported, anything else is refused
+    Sink<T> V;
+    V.opt = A.opt;
+    load_bytes(bytes, V);
+    for (size_t l = 0; l < V.host.levels.size(); ++l) {
+      HostLevel<T> &H = V.host.levels[l];
+      if (H.Er.ptr.size() >= 4) {
+        const Csr<T> keep = H.Er;
+        H.Er.ptr[H.Er.ptr.size() - 3] = 0;
+        H.Er.ptr[H.Er.ptr.size() - 2] = 1072693248;  // (the high word of 1.0)
+        if (verify_level(H, l, false) != 1 || !same_csr(H.Er, keep)) ++bad, std::fprintf(stderr, "%s: level %zu: E not rebuilt\n", path, l);
+        if (verify_level(H, l, false) != 0) ++bad, std::fprintf(stderr, "%s: level %zu: still different after the rebuild\n", path, l);
+      }
+      if (!H.Fr.val.empty()) {
+        const Csr<T> keep = H.Fr;
+        H.Fr.val[H.Fr.val.size() / 2] = T(12345.0);
+        if (verify_level(H, l, false) != 1 || !same_csr(H.Fr, keep)) ++bad, std::fprintf(stderr, "%s: level %zu: F not rebuilt\n", path, l);
+      }
+      if (!H.s.empty()) {
+        const double was = H.s[0];
+        H.s[0] = was + 1.0;
+        bool thrown = false;
+        try {
+          verify_level(H, l, false);
+        } catch (const Error &e) {
+          thrown = std::string(e.what()).find(" s ") != std::string::npos || std::string(e.what()).find(": s") != std::string::npos;
+        }
+        if (!thrown) ++bad, std::fprintf(stderr, "%s: level %zu: a changed scale vector was not refused by name\n", path, l);
+        H.s[0] = was;
+      }
+      if (!H.E.vals.empty() && !H.Er.val.empty()) {  // imported AND derived array changed: nothing to rebuild from
+        H.E.vals[0] = T(777.0);
+        H.Er.val[0] = T(777.0);
+        bool thrown = false;
+        try {
+          verify_level(H, l, false);
+        } catch (const Error &) {
+          thrown = true;
+        }
+        if (!thrown) ++bad, std::fprintf(stderr, "%s: level %zu: damaged imported arrays accepted\n", path, l);
+      }
+    }
+  }
   bad += compare(A, B, "sequential");
   // two more loads concurrently on two threads
   Sink<T> D;
