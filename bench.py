@@ -356,6 +356,21 @@ def main():
                          "roofline_frac": M.algorithmic_bytes(2 * args.nrhs) / (el2 / steps) / 1e9 / HBM_PEAK_GBS,
                          "first_tile_equals_64_column_result": bool(torch.equal(X2[:, :args.nrhs], X))}
             del B2, X2
+            # ... and 256 columns (four tiles over the same two lanes; four lanes measured no better)
+            B4 = torch.cat([B, B.flip(1), B, B.flip(1)], dim=1).contiguous()
+            X4 = torch.empty_like(B4)
+            M.solve_mrhs(B4, X4)
+            M.sync()
+            t1 = time.perf_counter()
+            for _ in range(max(3, steps // 2)):
+                M.solve_mrhs(B4, X4)
+            M.sync()
+            torch.cuda.synchronize()
+            el4 = (time.perf_counter() - t1) / max(3, steps // 2)
+            pipelined["nrhs_256"] = {"nrhs": 4 * args.nrhs, "ms_per_batch": 1e3 * el4, "rhs_applies_per_s": 4 * args.nrhs / el4,
+                                     "roofline_frac": M.algorithmic_bytes(4 * args.nrhs) / el4 / 1e9 / HBM_PEAK_GBS,
+                                     "last_tile_equals_the_second": bool(torch.equal(X4[:, 3 * args.nrhs:], X4[:, args.nrhs:2 * args.nrhs]))}
+            del B4, X4
         res = dict(ms_per_step=1e3 * el / steps, value=world * args.nrhs * steps / el, dev_ms=dev_ms, balg=balg, stage_bytes=stage_bytes, nrhs1_ms=nrhs1_ms, pipelined=pipelined,
                    launch_map=launch_map, level_bytes=level_bytes, setup=setup, narrow=narrow, ranks_cached=ranks_cached,
                    stats=st, cpu=cpu, gather_ms=gather_ms, parity=parity, levels=levels, strong=strong, exact=exact)
