@@ -605,6 +605,9 @@ class Engine : public EngineBase {
 
   ~Engine() override {
     if (stream) (void)hipSetDevice(device);
+    // nothing of this handle may still be in flight when its graphs, events, streams and pinned buffers go (the runtime
+    // completes asynchronous work on threads of its own; see DESIGN 8 on the host copy that changed twice in four rounds)
+    if (stream && !is_twin) (void)hipDeviceSynchronize();
     if (gm_ctl_host) (void)hipHostFree(gm_ctl_host);
 #ifdef HIFAMD_CSPROBE
     csprobe_dump();

@@ -488,7 +488,17 @@ static std::string first_difference(const char *name, const std::vector<V> &foun
       std::memcpy(&eb, &expect[i], std::min(sizeof(V), sizeof(eb)));
       std::snprintf(buf, sizeof(buf), "%s[%zu] (of %zu, %zu-byte entries, at %p): found 0x%llx, expected 0x%llx; %zu entries differ", name, i,
                     found.size(), sizeof(V), (const void *)&found[i], fb, eb, cnt);
-      return buf;
+      std::string out = buf;
+      // the 64 bytes around the first difference as they are now (whose data is it? doubles, pointers, text ...)
+      const unsigned char *base = reinterpret_cast<const unsigned char *>(found.data());
+      const size_t nbytes = found.size() * sizeof(V), at = i * sizeof(V);
+      const size_t lo = at >= 24 ? (at - 24) & ~(size_t)7 : 0, hi = std::min(nbytes, lo + 64);
+      out += "; bytes [" + std::to_string(lo) + ", " + std::to_string(hi) + "):";
+      for (size_t k = lo; k < hi; ++k) {
+        std::snprintf(buf, sizeof(buf), "%s%02x", (k % 8 == 0) ? " " : "", base[k]);
+        out += buf;
+      }
+      return out;
     }
   return std::string(name) + ": equal";
 }

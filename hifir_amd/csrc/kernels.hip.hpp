@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256) k_scatter_scale_list(const T *__restrict_
 #pragma unroll
     for (int u = 0; u < UR; ++u) q_[u] = qinv[i_[u]], t_[u] = t[i_[u]];
 #pragma unroll
-    for (int u = 0; u < UR; ++u) x_[u] = v[((int64_t)q_[u] << 6) + lane];
+    for (int u = 0; u < UR; ++u) x_[u] = v[((int64_t)q_[u] << 6) + min(lane, nrhs - 1)];  // (a narrow batch reads the columns it has)
 #pragma unroll
     for (int u = 0; u < UR; ++u)
       if (k0 + u < cnt && lane < nrhs) yout[i_[u] * ldy + lane] = vscale(t_[u], x_[u]);
