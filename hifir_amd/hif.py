@@ -148,6 +148,14 @@ class HIF:
 
     def finalize(self, max_nrhs=64):
         _check(lib().hifamd_finalize(self._h, int(max_nrhs)))
+        # (the host copy is sealed at import and verified here, DESIGN 8: a copy that changed behind the library's back and
+        #  was rebuilt is worth a Python warning as well -- pytest lists those even for tests that pass)
+        rep = self.stats_ext().get("host_copy_repairs", 0.0)
+        if rep:
+            import warnings
+
+            warnings.warn("hifir_amd: %d array(s) of the host copy had changed between add_level and finalize and were "
+                          "rebuilt from the imported arrays (details on stderr)" % int(rep), RuntimeWarning)
 
     def set_matrix(self, indptr, indices, vals):
         """Attach the user's CRS matrix for iterative refinement (what lhf?Setup keeps, libhifir.cpp:413)."""
