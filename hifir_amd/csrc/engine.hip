@@ -154,6 +154,10 @@ struct DevCsr {
   bool f_fused = false;
   // tile form of the dense-own component bands' walked entries (host.hpp build_ct_tiles, kernel k_band_ct)
   DevBuf rowflag;  // sparse-own plans: per slot, what a level's FIRST solve may leave out (build_row_flags; kernels RowSkip)
+  // U triangles of sparse-own plans: black rows in LDS, sinks streamed (host.hpp build_us_plan; kernel k_band_us)
+  DevBuf us_desc, us_rowid, us_oslot, us_mptr, us_mcol, us_mval, us_own_val, us_own_src, us_own_rptr, us_own_lvl;
+  std::vector<uint8_t> us_band_ok;
+  std::vector<int32_t> us_band_nbk, us_band_own, us_band_c0;
   DevBuf ct_desc, ct_sptr, ct_src, ct_coef;
   bool ct_on = false;
   int64_t ct_tiles = 0;
@@ -202,6 +206,10 @@ struct DevCsr {
     f_lrow.alias(o.f_lrow);
     f_fused = o.f_fused;
     rowflag.alias(o.rowflag);
+    us_desc.alias(o.us_desc), us_rowid.alias(o.us_rowid), us_oslot.alias(o.us_oslot), us_mptr.alias(o.us_mptr), us_mcol.alias(o.us_mcol);
+    us_mval.alias(o.us_mval), us_own_val.alias(o.us_own_val), us_own_src.alias(o.us_own_src), us_own_rptr.alias(o.us_own_rptr);
+    us_own_lvl.alias(o.us_own_lvl);
+    us_band_ok = o.us_band_ok, us_band_nbk = o.us_band_nbk, us_band_own = o.us_band_own, us_band_c0 = o.us_band_c0;
     ct_desc.alias(o.ct_desc);
     ct_sptr.alias(o.ct_sptr);
     ct_src.alias(o.ct_src);
@@ -456,6 +464,7 @@ class Engine : public EngineBase {
   int cs_max_wgs = 0;    // HIFIR_AMD_CS_MAX_WGS (full batches: measured equal to k_band_cd at every band width)
   int ct_wide_wgs = 128; // HIFIR_AMD_CT_WIDE: a component band with more workgroups than this takes two column tiles per workgroup
   int ct_wide4_wgs = 1 << 30;  // HIFIR_AMD_CT_WIDE4: ... and with more than this all four (one workgroup per component)
+  int us_mode = 1;  // HIFIR_AMD_US=0: sparse-own U bands keep every row of a component in LDS (k_band_cd)
   int narrow_tiles = 1;  // HIFIR_AMD_NARROW_TILES=0: the tiled Schur products always multiply all four column tiles
   int skip_rows = 3;  // HIFIR_AMD_SKIP_ROWS: bit 0 L rows / bit 1 U rows a level's first solve does not store (build_row_flags); 0: every row
   int ct_mode_real = 1;  // HIFIR_AMD_CT_REAL=0: real handles keep the entry walk while HIFIR_AMD_CT_Z stays as set (tests)
@@ -520,6 +529,7 @@ class Engine : public EngineBase {
     ct_mode_real = env_int("HIFIR_AMD_CT_REAL", 1);
     skip_rows = env_int("HIFIR_AMD_SKIP_ROWS", 3);
     narrow_tiles = env_int("HIFIR_AMD_NARROW_TILES", 1);
+    us_mode = env_int("HIFIR_AMD_US", 1);
     top_last_arriver = env_int("HIFIR_AMD_TOP_LAST", 0);
     list_early = env_int("HIFIR_AMD_LIST_EARLY", 0);
     spmm_rb = env_int("HIFIR_AMD_SPMM_RB", 1) == 2 ? 2 : 1;
@@ -586,6 +596,7 @@ class Engine : public EngineBase {
       HIP_OK(hipFuncSetAttribute((const void *)k_band_ct<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ct_lds_bytes(4)));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(false)));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cd_lds_bytes(false)));
+      HIP_OK(hipFuncSetAttribute((const void *)k_band_us, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(cd_lds_bytes(true), 160 * 1024)));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(cd_lds_bytes(true), 160 * 1024)));
       HIP_OK(hipFuncSetAttribute((const void *)k_band_cs<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min<size_t>(cs_lds_bytes(true), 160 * 1024)));
@@ -708,6 +719,7 @@ class Engine : public EngineBase {
       E->ct_mode_real = ct_mode_real;
       E->skip_rows = skip_rows;
       E->narrow_tiles = narrow_tiles;
+      E->us_mode = us_mode;
       E->list_early = list_early;
       E->spmm_rb = spmm_rb;
       E->spmm_tiles_z = spmm_tiles_z;
@@ -780,6 +792,7 @@ class Engine : public EngineBase {
       E->ct_mode_real = ct_mode_real;
       E->skip_rows = skip_rows;
       E->narrow_tiles = narrow_tiles;
+      E->us_mode = us_mode;
       E->list_early = list_early;
       E->spmm_rb = spmm_rb;
       E->spmm_tiles_z = spmm_tiles_z;
@@ -1201,6 +1214,18 @@ class Engine : public EngineBase {
       }
       if constexpr (std::is_same<T, double>::value) {
         if (skip_rows && band_opt.dense_block > 0) build_row_flags(H, L);
+        if (us_mode && band_opt.dense_block > 0 && L.U.cd_sparse && Rmax == 64) {
+          UsPlan<T> Up2;
+          build_us_plan(H.Up, H.Ur, Up2);
+          if (Up2.any) check_us_plan(H.Up, H.Ur, Up2);
+          if (Up2.any) {
+            DevCsr &M = L.U;
+            M.us_desc.upload(Up2.desc, 8), M.us_rowid.upload(Up2.rowid, 8), M.us_oslot.upload(Up2.oslot, 8), M.us_mptr.upload(Up2.mptr, 8);
+            M.us_mcol.upload(Up2.mcol, 8), M.us_mval.upload(Up2.mval, 8), M.us_own_val.upload(Up2.own_val, 8);
+            M.us_own_src.upload(Up2.own_src, 8), M.us_own_rptr.upload(Up2.own_rptr, 8), M.us_own_lvl.upload(Up2.own_lvl, 8);
+            M.us_band_ok = Up2.band_ok, M.us_band_nbk = Up2.band_nbk, M.us_band_own = Up2.band_own, M.us_band_c0 = Up2.band_c0;
+          }
+        }
       }
       L.d.upload(H.d);
       L.s.upload(H.s);
@@ -1709,6 +1734,10 @@ class Engine : public EngineBase {
     const int nslz = std::min(4, (act_cols + 15) / 16);
     return L.U.cd_sparse || (ct_mode && L.U.ct_on) || (cs_mode && nslz < 4);
   }
+  static size_t us_lds_bytes(int32_t lds_black, int32_t own_cap) {  // k_band_us: black rows, own values, S7 scales, row ids, S7 rows, offsets, sources, levels
+    return (size_t)lds_black * 64 * sizeof(double) + (size_t)own_cap * sizeof(double) + 256 * sizeof(double) + 2 * 256 * sizeof(int32_t) +
+           260 * sizeof(uint16_t) + (size_t)own_cap + 264;
+  }
   size_t cd_lds_bytes_z() const {  // complex: two real planes of the component's right-hand sides + row ids
     const size_t rows = (size_t)band_opt.cd_rows;
     return rows * 128 * sizeof(double) + ((rows + 1) & ~(size_t)1) * sizeof(int32_t);
@@ -1745,6 +1774,20 @@ class Engine : public EngineBase {
                            M.ct_coef.as<double>(), pre ? 0 : 1, (int32_t)(g1 - g0), (int32_t)nslc, ps0, ps1, single_c0, lds_rows,
                            cd_dbg | (no_walk ? 1 : 0), fl, lu);
         return;
+      }
+      if (!LOWER && us_mode && M.cd_sparse && nsl == 4 && !pre && !extra && !with_f && band < M.us_band_ok.size() && M.us_band_ok[band] &&
+          !(cs_mode && (g1 - g0 <= cs_max_wgs || cs_sparse))) {  // black rows in LDS, sinks streamed: two workgroups per unit
+        const int32_t own_cap2 = (M.us_band_own[band] + 63) & ~63;
+        const int32_t lds_black = std::max(1, M.us_band_nbk[band]);
+        const size_t lds2 = us_lds_bytes(lds_black, own_cap2);
+        if (lds2 <= 160 * 1024) {
+          hipLaunchKernelGGL(k_band_us, dim3((unsigned)(g1 - g0)), dim3(1024), lds2, st, M.us_band_c0[band], M.us_desc.as<int32_t>(),
+                             M.us_rowid.as<int32_t>(), M.us_oslot.as<int32_t>(), M.us_mptr.as<int32_t>(), M.us_mcol.as<int32_t>(),
+                             M.us_mval.as<double>(), M.us_own_val.as<double>(), M.us_own_src.as<uint8_t>(), M.us_own_rptr.as<uint16_t>(),
+                             M.us_own_lvl.as<uint8_t>(), L.d.as<double>(), (const double *)L.w.as<double>(), L.v.as<double>(), lds_black,
+                             own_cap2, fl, lu, M.cd_sparse ? rs : RowSkip{nullptr});
+          return;
+        }
       }
       if (cs_mode && (nsl < 4 || g1 - g0 <= cs_max_wgs || (cs_sparse && M.cd_sparse)) && fits) {
         auto kcs = M.cd_sparse ? k_band_cs<LOWER, true> : k_band_cs<LOWER, false>;

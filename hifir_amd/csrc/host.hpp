@@ -943,6 +943,198 @@ inline void build_cd_streams(BandPlan &P, const std::vector<int32_t> &aptr /* ro
 }
 
 // ---------------------------------------------------------------------------------------------
+// Sparse-own U bands with streamed SINKS (round 4; kernel k_band_us).  Level 0 of a PDE hierarchy: two thirds of a
+// component's rows are sinks of the U solve INSIDE the component -- no row of the component reads their result (their column
+// of the component's own block is empty).  Such a row needs no LDS slot: the component's other ("black") rows are solved
+// level by level in LDS as k_band_cd<false, sparse> does, then every sink is streamed -- right-hand side in, its own entries
+// gathered from the black rows in LDS, result out.  LDS per component: black rows x 512 B instead of all rows x 512 B (33 KB
+// instead of 98 KB on the reference's 1M-row hierarchy) => two workgroups per compute unit, which the band kernels of level 0
+// are bound by.  Per row the arithmetic and its order are k_band_cd's (right-hand side, outside entries in CSR
+// order, own entries in CSR order): the same bits.
+// The component's rows are renumbered black first (relative order kept: dependency order), sinks behind:
+//   desc   : per component 8 words: s0 (first slot, = the plan's), nb, nbk (black rows), own0, orp0, lvl0, nlvl, 0
+//   rowid  : per NEW slot the row id;  oslot: per new slot the plan's slot (for arrays kept in plan order)
+//   mptr / mcol / mval : per new slot its outside entries [split, csplit) (source ROW, value), CSR order
+//   own_val / own_src  : per new slot its own entries (value, NEW local index of the source: always a black row)
+//   own_rptr : per component nb + 1 offsets relative to own0;  own_lvl : per component nlvl + 1 black-row boundaries
+// band_ok[b]: every workgroup of band b owns exactly one component and the band touches its rows first;
+// band_nbk[b] / band_own[b]: most black rows / own entries of one component of the band (LDS sizing).
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct UsPlan {
+  std::vector<int32_t> desc, rowid, oslot, mptr, mcol;
+  std::vector<T> mval, own_val;
+  std::vector<uint8_t> own_src, own_lvl;
+  std::vector<uint16_t> own_rptr;
+  std::vector<uint8_t> band_ok;
+  std::vector<int32_t> band_nbk, band_own, band_c0;
+  int64_t sinks = 0, blacks = 0;
+  bool any = false;
+};
+constexpr int kUsDescWords = 8;
+
+template <class T>
+void build_us_plan(const BandPlan &P, const Csr<T> &A /* slot order */, UsPlan<T> &U) {
+  U = UsPlan<T>();
+  const int64_t nb_bands = P.nbands();
+  if (!P.cd_sparse || P.band_cd.empty() || nb_bands <= 0) return;
+  const int64_t m = A.nrows;
+  const size_t ngrp = P.grp_slot_ptr.size() - 1;
+  U.desc.assign(ngrp * (size_t)kUsDescWords, 0);
+  U.rowid.assign((size_t)m, 0);
+  U.oslot.assign((size_t)m, 0);
+  for (int64_t sl = 0; sl < m; ++sl) U.rowid[(size_t)sl] = A.rowid[(size_t)sl], U.oslot[(size_t)sl] = (int32_t)sl;
+  U.mptr.assign((size_t)m + 1, 0);
+  U.band_ok.assign((size_t)nb_bands, 0);
+  U.band_nbk.assign((size_t)nb_bands, 0);
+  U.band_own.assign((size_t)nb_bands, 0);
+  U.band_c0.assign((size_t)nb_bands, 0);
+  std::vector<int32_t> mcnt((size_t)m, 0);
+  // pass 1: the new order of every qualifying component
+  std::vector<int32_t> newpos((size_t)m, -1);  // plan slot -> new slot (identity outside qualifying bands)
+  for (int64_t sl = 0; sl < m; ++sl) newpos[(size_t)sl] = (int32_t)sl;
+  for (int64_t b = 0; b < nb_bands; ++b) {
+    if (!P.band_cd[(size_t)b]) continue;
+    if (!P.band_dense.empty() && P.band_dense[(size_t)b]) continue;
+    if (!P.band_prefix.empty() && P.band_prefix[(size_t)b]) continue;
+    if (!P.band_fused.empty() && P.band_fused[(size_t)b]) continue;
+    const int32_t g0 = P.band_wg_ptr[(size_t)b], g1 = P.band_wg_ptr[(size_t)b + 1];
+    const int32_t c0 = P.wg_grp_ptr[(size_t)g0], c1 = P.wg_grp_ptr[(size_t)g1];
+    if (c1 - c0 != g1 - g0 || c1 <= c0) continue;  // (bags: the component kernel of the plan keeps them)
+    bool ok = true;
+    for (int32_t c = c0; c < c1 && ok; ++c) ok = P.grp_slot_ptr[(size_t)c + 1] - P.grp_slot_ptr[(size_t)c] <= 255;
+    if (!ok) continue;
+    U.band_ok[(size_t)b] = 1;
+    U.band_c0[(size_t)b] = c0;
+    U.any = true;
+    for (int32_t c = c0; c < c1; ++c) {
+      const int32_t s0 = P.grp_slot_ptr[(size_t)c], nb = P.grp_slot_ptr[(size_t)c + 1] - s0;
+      std::vector<uint8_t> read((size_t)nb, 0);
+      for (int32_t r = 0; r < nb; ++r)
+        for (int32_t k = P.csplit[(size_t)(s0 + r)]; k < A.ptr[(size_t)(s0 + r) + 1]; ++k) read[(size_t)(P.srcslot[(size_t)k] - s0)] = 1;
+      int32_t nbk = 0;
+      for (int32_t r = 0; r < nb; ++r)
+        if (read[(size_t)r]) newpos[(size_t)(s0 + r)] = s0 + nbk++;
+      int32_t q = nbk;
+      for (int32_t r = 0; r < nb; ++r)
+        if (!read[(size_t)r]) newpos[(size_t)(s0 + r)] = s0 + q++;
+      int32_t *dsc = &U.desc[(size_t)c * kUsDescWords];
+      dsc[0] = s0, dsc[1] = nb, dsc[2] = nbk;
+      U.band_nbk[(size_t)b] = std::max(U.band_nbk[(size_t)b], nbk);
+      U.blacks += nbk;
+      U.sinks += nb - nbk;
+    }
+  }
+  if (!U.any) return;
+  for (int64_t sl = 0; sl < m; ++sl) {
+    const int32_t ns = newpos[(size_t)sl];
+    U.rowid[(size_t)ns] = A.rowid[(size_t)sl];
+    U.oslot[(size_t)ns] = (int32_t)sl;
+  }
+  // pass 2: outside entries per new slot
+  for (int64_t ns = 0; ns < m; ++ns) {
+    const int32_t sl = U.oslot[(size_t)ns];
+    U.mptr[(size_t)ns + 1] = U.mptr[(size_t)ns] + (P.csplit[(size_t)sl] - P.split[(size_t)sl]);
+  }
+  U.mcol.resize((size_t)U.mptr[(size_t)m]);
+  U.mval.resize((size_t)U.mptr[(size_t)m]);
+  for (int64_t ns = 0; ns < m; ++ns) {
+    const int32_t sl = U.oslot[(size_t)ns];
+    int32_t o = U.mptr[(size_t)ns];
+    for (int32_t k = P.split[(size_t)sl]; k < P.csplit[(size_t)sl]; ++k, ++o) U.mcol[(size_t)o] = A.col[(size_t)k], U.mval[(size_t)o] = A.val[(size_t)k];
+  }
+  // pass 3: own entries, row offsets and black levels per component (new order)
+  for (int64_t b = 0; b < nb_bands; ++b) {
+    if (!U.band_ok[(size_t)b]) continue;
+    const int32_t g0 = P.band_wg_ptr[(size_t)b], g1 = P.band_wg_ptr[(size_t)b + 1];
+    for (int32_t c = P.wg_grp_ptr[(size_t)g0]; c < P.wg_grp_ptr[(size_t)g1]; ++c) {
+      int32_t *dsc = &U.desc[(size_t)c * kUsDescWords];
+      const int32_t s0 = dsc[0], nb = dsc[1], nbk = dsc[2];
+      const int64_t own0 = (int64_t)U.own_val.size(), orp0 = (int64_t)U.own_rptr.size(), lvl0 = (int64_t)U.own_lvl.size();
+      std::vector<int32_t> lev((size_t)nb, 0);
+      int32_t cur = 0;
+      U.own_lvl.push_back(0);
+      for (int32_t r = 0; r < nb; ++r) {  // r: NEW local index
+        const int32_t sl = U.oslot[(size_t)(s0 + r)];
+        U.own_rptr.push_back((uint16_t)((int64_t)U.own_val.size() - own0));
+        int32_t need = 0;
+        for (int32_t k = P.csplit[(size_t)sl]; k < A.ptr[(size_t)sl + 1]; ++k) {
+          const int32_t q = newpos[(size_t)P.srcslot[(size_t)k]] - s0;  // (a black row: somebody reads it)
+          U.own_val.push_back(A.val[(size_t)k]);
+          U.own_src.push_back((uint8_t)q);
+          need = std::max(need, lev[(size_t)q] + 1);
+        }
+        if (r < nbk) {
+          if (need > cur) {
+            cur = need;
+            U.own_lvl.push_back((uint8_t)r);
+          }
+          lev[(size_t)r] = cur;
+        }
+      }
+      U.own_rptr.push_back((uint16_t)((int64_t)U.own_val.size() - own0));
+      U.own_lvl.push_back((uint8_t)nbk);
+      const int64_t nown = (int64_t)U.own_val.size() - own0, nlvl = (int64_t)U.own_lvl.size() - lvl0 - 1;
+      if (nown > 65535) {  // (uint16 offsets: such a component keeps the plan's kernel)
+        U.band_ok[(size_t)b] = 0;
+      }
+      dsc[3] = (int32_t)own0, dsc[4] = (int32_t)orp0, dsc[5] = (int32_t)lvl0, dsc[6] = (int32_t)nlvl;
+      U.band_own[(size_t)b] = std::max<int32_t>(U.band_own[(size_t)b], (int32_t)nown);
+    }
+  }
+}
+
+// what k_band_us indexes with, re-derived from the arrays themselves (finalize calls it before the upload: no index out of
+// range reaches the kernel, whatever built the plan)
+template <class T>
+void check_us_plan(const BandPlan &P, const Csr<T> &A, const UsPlan<T> &U) {
+  auto fail = [](const char *why) { throw Error(4, std::string("internal error: streamed-sink plan: ") + why); };
+  const int64_t m = A.nrows;
+  if ((int64_t)U.rowid.size() != m || (int64_t)U.oslot.size() != m || (int64_t)U.mptr.size() != m + 1) fail("array lengths");
+  std::vector<uint8_t> seen((size_t)m, 0);
+  for (int64_t ns = 0; ns < m; ++ns) {
+    const int32_t sl = U.oslot[(size_t)ns];
+    if (sl < 0 || sl >= m || seen[(size_t)sl]) fail("slot permutation");
+    seen[(size_t)sl] = 1;
+    if (U.rowid[(size_t)ns] != A.rowid[(size_t)sl]) fail("row ids");
+    if (U.mptr[(size_t)ns + 1] < U.mptr[(size_t)ns]) fail("outside-entry offsets");
+  }
+  if ((size_t)U.mptr[(size_t)m] != U.mcol.size() || U.mcol.size() != U.mval.size()) fail("outside-entry arrays");
+  for (int32_t c : U.mcol)
+    if (c < 0 || c >= A.ncols) fail("outside-entry source");
+  for (int64_t b = 0; b < P.nbands(); ++b) {
+    if (!U.band_ok[(size_t)b]) continue;
+    const int32_t g0 = P.band_wg_ptr[(size_t)b], g1 = P.band_wg_ptr[(size_t)b + 1];
+    if (U.band_c0[(size_t)b] != P.wg_grp_ptr[(size_t)g0] || P.wg_grp_ptr[(size_t)g1] - P.wg_grp_ptr[(size_t)g0] != g1 - g0) fail("one component per workgroup");
+    for (int32_t c = P.wg_grp_ptr[(size_t)g0]; c < P.wg_grp_ptr[(size_t)g1]; ++c) {
+      const int32_t *dsc = &U.desc[(size_t)c * kUsDescWords];
+      const int32_t s0 = dsc[0], nb = dsc[1], nbk = dsc[2], own0 = dsc[3], orp0 = dsc[4], lvl0 = dsc[5], nlvl = dsc[6];
+      if (s0 != P.grp_slot_ptr[(size_t)c] || nb != P.grp_slot_ptr[(size_t)c + 1] - s0 || nb < 1 || nb > 255 || nbk < 0 || nbk > nb) fail("descriptor");
+      if (nbk > U.band_nbk[(size_t)b]) fail("black rows exceed the band's LDS size");
+      if (orp0 < 0 || (size_t)orp0 + (size_t)nb + 1 > U.own_rptr.size() || lvl0 < 0 || nlvl < 1 || (size_t)lvl0 + (size_t)nlvl + 1 > U.own_lvl.size()) fail("offset arrays");
+      const int32_t nown = U.own_rptr[(size_t)orp0 + (size_t)nb];
+      if (own0 < 0 || (size_t)own0 + (size_t)nown > U.own_val.size() || U.own_val.size() != U.own_src.size() || nown > U.band_own[(size_t)b]) fail("own entries");
+      if (U.own_lvl[(size_t)lvl0] != 0 || U.own_lvl[(size_t)lvl0 + (size_t)nlvl] != nbk) fail("level ends");
+      std::vector<int32_t> lev((size_t)nb, -1);
+      for (int32_t lv = 0; lv < nlvl; ++lv) {
+        const int32_t a = U.own_lvl[(size_t)lvl0 + (size_t)lv], e = U.own_lvl[(size_t)lvl0 + (size_t)lv + 1];
+        if (e < a) fail("levels not monotone");
+        for (int32_t r = a; r < e; ++r) lev[(size_t)r] = lv;
+      }
+      for (int32_t r = 0; r < nb; ++r) {
+        const int32_t eb = U.own_rptr[(size_t)orp0 + (size_t)r], ee = U.own_rptr[(size_t)orp0 + (size_t)r + 1];
+        if (ee < eb || ee > nown) fail("own offsets");
+        for (int32_t e = eb; e < ee; ++e) {
+          const int32_t q = U.own_src[(size_t)own0 + (size_t)e];
+          if (q >= nbk) fail("an own entry reads a sink");
+          if (r < nbk && !(lev[(size_t)q] < lev[(size_t)r])) fail("a black row reads a row of its own or a later level");
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Tile form of what a dense-own component band walks (round 4; kernel k_band_ct).  The entries [split, csplit) of a
 // component's rows -- sources finished by earlier launches -- are a small sparse matrix (rows x distinct sources) whose
 // rows share most of their sources (measured on the reference's 1M-row hierarchies: a 16-row strip of a component

@@ -2736,6 +2736,166 @@ __global__ void __launch_bounds__(1024) k_band_cd(int32_t wg0, const int32_t *__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Sparse-own U band with streamed sinks (round 4; host.hpp build_us_plan).  One component per workgroup (1,024 threads), R = 64.
+//   phase 0  descriptors, the component's own entries / row offsets / black levels into LDS; output rows of a fused S7
+//   phase A  the BLACK rows' right-hand sides (w / d, or -- RowSkip -- s b[p] / d) minus their outside entries -> LDS;
+//            the first batch of sink right-hand sides is requested here too and arrives during phase B
+//   phase B  the black rows level by level in LDS, a wave per row (k_band_cd<false, sparse>'s loop); results stored
+//   phase C  the sinks, a wave per row, eight rows of a wave in flight: right-hand side, outside entries, own entries
+//            gathered from the black rows in LDS, result stored -- a sink never touches LDS
+// Per row: the operations of k_band_cd in the same order -- the same bits (width independence is tested against the slice
+// kernel k_band_cs, which narrow batches keep).  LDS: black rows x 512 B + the own entries: two workgroups per compute unit
+// on the reference's hierarchies (<= 64 VGPRs), the occupancy the level-0 bands are bound by.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+    k_band_us(int32_t c0, const int32_t *__restrict__ desc, const int32_t *__restrict__ rowid, const int32_t *__restrict__ oslot,
+              const int32_t *__restrict__ mptr, const int32_t *__restrict__ mcol, const double *__restrict__ mval,
+              const double *__restrict__ own_val, const uint8_t *__restrict__ own_src, const uint16_t *__restrict__ own_rptr,
+              const uint8_t *__restrict__ own_lvl, const double *__restrict__ d, const double *__restrict__ w, double *v,
+              int32_t lds_black, int32_t own_cap, FirstL<double> fl, LastU<double> lu, RowSkip rs) {
+  extern __shared__ double us_tb[];  // [lds_black][64] black rows; then own values, row ids, S7 rows, own sources, offsets, levels
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  constexpr int NW = 16;
+  const int32_t *dsc = desc + (int64_t)(c0 + (int32_t)blockIdx.x) * 8;
+  const int32_t s0 = dsc[0], nb = dsc[1], nbk = dsc[2], own0 = dsc[3], orp0 = dsc[4], lvl0 = dsc[5], nlvl = dsc[6];
+  double *ow_val = us_tb + (size_t)lds_black * 64;
+  double *s_ot = ow_val + own_cap;
+  int32_t *s_rowid = reinterpret_cast<int32_t *>(s_ot + 256);
+  int32_t *s_oi = s_rowid + 256;
+  uint16_t *ow_rptr = reinterpret_cast<uint16_t *>(s_oi + 256);
+  uint8_t *ow_src = reinterpret_cast<uint8_t *>(ow_rptr + 260);
+  uint8_t *ow_lvl = ow_src + own_cap;
+  const bool last_u = lu.on();
+  const bool from_b = rs.flag != nullptr;
+  const double *bsrc = from_b ? fl.bin.get() : nullptr;
+  double *yout = last_u ? lu.out.get() : nullptr;
+  // ---- phase 0
+  const int32_t nown = own_rptr[orp0 + nb];
+  for (int32_t t = (int32_t)threadIdx.x; t < nown; t += 1024) {
+    ow_val[t] = own_val[own0 + t];
+    ow_src[t] = own_src[own0 + t];
+  }
+  for (int32_t t = (int32_t)threadIdx.x; t <= nb; t += 1024) ow_rptr[t] = own_rptr[orp0 + t];
+  for (int32_t t = (int32_t)threadIdx.x; t <= nlvl; t += 1024) ow_lvl[t] = own_lvl[lvl0 + t];
+  for (int32_t t = (int32_t)threadIdx.x; t < nb; t += 1024) {
+    const int32_t i = rowid[s0 + t];
+    const int hf = from_b ? (int)rs.flag[oslot[s0 + t]] : 0;
+    s_rowid[t] = (hf & 1) ? ~i : i;  // (negative: not stored)
+    if (last_u) {
+      const int32_t oi = lu.q[i];
+      s_oi[t] = oi;
+      s_ot[t] = lu.t[oi];
+    }
+  }
+  // one row's right-hand side as k_band_cd forms it: w[i] / d[i], or (RowSkip bit 1) (s[p[i]] * b[p[i]]) / d[i]
+  // lane k of a wave holds the scalars of the wave's k-th row of the batch
+  auto row_scalars = [&](int32_t r, bool valid, int32_t &h_i, int32_t &h_p, double &h_d, double &h_s, int32_t &h_m0, int32_t &h_m1) {
+    h_i = 0, h_p = -1, h_d = 1.0, h_s = 0.0, h_m0 = 0, h_m1 = 0;
+    if (valid) {
+      h_i = rowid[s0 + r];
+      h_m0 = mptr[s0 + r];
+      h_m1 = mptr[s0 + r + 1];
+      h_d = d[h_i];
+      if (from_b && (rs.flag[oslot[s0 + r]] & 2)) {
+        h_p = fl.p[h_i];
+        h_s = fl.s[h_p];
+      }
+    }
+  };
+  // ---- phase A: black rows w, w + 16, ... (at most 16 per wave: 256 rows / 16 waves), eight at a time
+  for (int32_t kb = 0; wave + NW * kb < nbk; kb += 8) {
+    int32_t h_i, h_p, h_m0, h_m1;
+    double h_d, h_s;
+    const int32_t myr = wave + NW * (kb + lane);
+    row_scalars(myr, lane < 8 && myr < nbk, h_i, h_p, h_d, h_s, h_m0, h_m1);
+    double t_[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int32_t i = rl32(h_i, q), pb = rl32(h_p, q);
+      const double *src = (pb >= 0) ? bsrc + (int64_t)pb * fl.ldb + min(lane, fl.nrhs - 1) : w + ((int64_t)i << 6) + lane;
+      t_[q] = (wave + NW * (kb + q) < nbk) ? *src : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int32_t r = wave + NW * (kb + q);
+      if (r < nbk) {
+        double tq = t_[q];
+        if (rl32(h_p, q) >= 0) tq = lane < fl.nrhs ? rl64(h_s, q) * tq : 0.0;
+        double acc = tq / rl64(h_d, q);
+        const int32_t m0 = rl32(h_m0, q), m1 = rl32(h_m1, q);  // (outside entries: few rows of level 0 have any)
+        for (int32_t e = m0; e < m1; ++e) acc = acc - mval[e] * v[((int64_t)mcol[e] << 6) + lane];
+        us_tb[(r << 6) + lane] = acc;
+      }
+    }
+  }
+  // the first batch of sinks: rows nbk + w, nbk + w + 16, ... requested NOW (nothing of the black solve feeds their loads)
+  int32_t g_i, g_p, g_m0, g_m1;
+  double g_d, g_s;
+  double st_[8];
+  {
+    const int32_t myr = nbk + wave + NW * lane;
+    row_scalars(myr, lane < 8 && myr < nb, g_i, g_p, g_d, g_s, g_m0, g_m1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int32_t i = rl32(g_i, q), pb = rl32(g_p, q);
+      const double *src = (pb >= 0) ? bsrc + (int64_t)pb * fl.ldb + min(lane, fl.nrhs - 1) : w + ((int64_t)i << 6) + lane;
+      st_[q] = (nbk + wave + NW * q < nb) ? *src : 0.0;
+    }
+  }
+  __syncthreads();
+  // ---- phase B: the black rows, depth level by depth level
+  for (int lv = 0; lv < nlvl; ++lv) {
+    const int r_lo = ow_lvl[lv], r_hi = ow_lvl[lv + 1];
+    for (int r = r_lo + wave; r < r_hi; r += NW) {
+      double a2 = us_tb[(r << 6) + lane];
+      const int eb = ow_rptr[r], ee = ow_rptr[r + 1];
+      for (int e = eb; e < ee; ++e) a2 = a2 - ow_val[e] * us_tb[((int)ow_src[e] << 6) + lane];
+      if (ee > eb) us_tb[(r << 6) + lane] = a2;
+      if (last_u) {
+        if (lane < lu.nrhs) yout[(int64_t)s_oi[r] * lu.ldy + lane] = s_ot[r] * a2;
+      } else {
+        const int32_t rid = s_rowid[r];
+        if (rid >= 0) v[((int64_t)rid << 6) + lane] = a2;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- phase C: the sinks (eight rows of this wave per batch; the first batch is already in registers)
+  for (int32_t kb = 0; nbk + wave + NW * kb < nb; kb += 8) {
+    if (kb) {
+      const int32_t myr = nbk + wave + NW * (kb + lane);
+      row_scalars(myr, lane < 8 && myr < nb, g_i, g_p, g_d, g_s, g_m0, g_m1);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int32_t i = rl32(g_i, q), pb = rl32(g_p, q);
+        const double *src = (pb >= 0) ? bsrc + (int64_t)pb * fl.ldb + min(lane, fl.nrhs - 1) : w + ((int64_t)i << 6) + lane;
+        st_[q] = (nbk + wave + NW * (kb + q) < nb) ? *src : 0.0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int32_t r = nbk + wave + NW * (kb + q);
+      if (r < nb) {
+        double tq = st_[q];
+        if (rl32(g_p, q) >= 0) tq = lane < fl.nrhs ? rl64(g_s, q) * tq : 0.0;
+        double a2 = tq / rl64(g_d, q);
+        const int32_t m0 = rl32(g_m0, q), m1 = rl32(g_m1, q);
+        for (int32_t e = m0; e < m1; ++e) a2 = a2 - mval[e] * v[((int64_t)mcol[e] << 6) + lane];
+        const int eb = ow_rptr[r], ee = ow_rptr[r + 1];
+        for (int e = eb; e < ee; ++e) a2 = a2 - ow_val[e] * us_tb[((int)ow_src[e] << 6) + lane];
+        if (last_u) {
+          if (lane < lu.nrhs) yout[(int64_t)s_oi[r] * lu.ldy + lane] = s_ot[r] * a2;
+        } else {
+          const int32_t rid = s_rowid[r];
+          if (rid >= 0) v[((int64_t)rid << 6) + lane] = a2;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Column-sliced component band (round 3).  The same plan, descriptors and packed streams as k_band_cd, but a workgroup
 // solves ONE component for a SLICE of 16 right-hand-side columns: blockIdx.x = component-workgroup * nsl + slice, and
 // every step of the solve is column-separable, so the nsl slices of a component never talk to each other.  Why:

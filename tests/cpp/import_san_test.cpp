@@ -137,6 +137,11 @@ static int finalize_host(Sink<T> &S, bool adjoint = false) {
       }
     }
   for (size_t l = 0; l < S.host.levels.size(); ++l) check_level_invariants(S.host.levels[l], l, adjoint);
+  for (auto &H : S.host.levels) {  // the streamed-sink form of sparse-own U triangles (k_band_us): built and re-derived
+    UsPlan<T> U;
+    build_us_plan(H.Up, H.Ur, U);
+    if (U.any) check_us_plan(H.Up, H.Ur, U);
+  }
   return bad;
 }
 
@@ -151,6 +156,13 @@ static int run_file(const char *path, const std::vector<unsigned char> &bytes, i
   bad += finalize_host(A);
   load_bytes(bytes, B);          // second handle while the first one is alive (the round-1 scenario)
   bad += finalize_host(B);
+  {  // sparse-own components on every shallow triangle (level 0 of the large hierarchies), here on the small fixtures
+    Sink<T> W;
+    W.opt = A.opt;
+    W.opt.cd_sparse_min_rows = 0;
+    load_bytes(bytes, W);
+    bad += finalize_host(W);
+  }
   {  // the host copy changed behind the library's back (rounds 1 and 4 met two overwritten row pointers of E): E / F's row
      // forms are rebuilt from the imported arrays and reported, anything else is refused
     Sink<T> V;

@@ -31,7 +31,9 @@ MODES = {
     # ... with S7 of the child's rows on a side stream beside the second solve (off by default: measured slower), sparse-own
     # components everywhere so that the first solve's row flags are in force as well
     # (+ the K splits of the operator products summed by the last split to arrive, also off by default)
-    "R64-fast-early-list": (6, 2048, {"HIFIR_AMD_LIST_EARLY": "1", "HIFIR_AMD_CD_SPARSE_MIN_ROWS": "0", "HIFIR_AMD_TOP_LAST": "1"}),
+    # (+ sparse-own U bands with every row of a component in LDS -- k_band_cd<false, sparse>, the form before k_band_us)
+    "R64-fast-early-list": (6, 2048, {"HIFIR_AMD_LIST_EARLY": "1", "HIFIR_AMD_CD_SPARSE_MIN_ROWS": "0", "HIFIR_AMD_TOP_LAST": "1",
+                                      "HIFIR_AMD_US": "0"}),
 }
 
 
