@@ -10,7 +10,8 @@ Constants (microseconds; all measured on one MI355X this round or the last, see 
   a dependent launch inside a replayed graph ...................... 1.8   (tests/microbench/launch_floor.hip)
   skeleton of a tile band (descriptor -> row ids -> right-hand sides -> LDS -> barrier -> product of one small component
   -> stores) ........................................................ 6.7   (bands with tiles and carried work switched off)
-  streamed bytes of a band (rows x 1 KB in + out, inverse strips) .... 4.0 TB/s (level >= 1 leaf bands), 3.45 TB/s (level 0)
+  streamed bytes of a band (rows x 1 KB in + out, inverse strips) .... 4.0 TB/s (level >= 1 leaf bands), 3.45 TB/s (level 0 L bands),
+                                                                     4.7 TB/s (level 0 U bands: sinks streamed, two workgroups per unit)
   one wave's tile chain ............................................ 0.2 per tile of the band's longest wave, minus 2
   tile throughput, whole chip ...................................... 20 ns per tile and 16-column slice and unit (one slice per
                                                                      workgroup), 38 ns per tile and 32-column slice
@@ -24,7 +25,7 @@ import json
 import sys
 
 LAUNCH, SKEL = 1.8, 6.7
-BW_BAND, BW_L0 = 4.0e6, 3.45e6  # bytes per microsecond
+BW_BAND, BW_L0, BW_L0_U = 4.0e6, 3.45e6, 4.7e6  # bytes per microsecond
 TILE_CHAIN, TILE_CHAIN_OFF = 0.2, 2.0
 TILE_THR1, TILE_THR2 = 0.020, 0.038
 CARRY0, CARRY = 2.0, 3.0e-5
@@ -52,7 +53,8 @@ def band_time(b, nxt, sparse_level0=False, tiles=True, carry=True):
     rows = b["rows"]
     if b.get("sparse"):  # level 0: sparse-own components, bandwidth
         extra = b["nnz"] * 12
-        return LAUNCH + 5.0 + (rows * 1024 + extra) / BW_L0
+        # (U bands stream their sinks -- k_band_us, two workgroups per unit -- and run at the rate a bare copy reaches)
+        return LAUNCH + 5.0 + (rows * 1024 + extra) / (BW_L0_U if b.get("tri") == "U" else BW_L0)
     t = LAUNCH + SKEL + (rows * 1024 + b.get("inv_bytes", 0)) / BW_BAND
     if tiles and b.get("ct_tiles", 0) > 0:
         nct2 = b["wgs"] > CT_WIDE
